@@ -1,0 +1,15 @@
+"""ballista_amd — MI355X-native physical execution layer for Ballista's executor hot path.
+
+`ballista_amd.plan` mirrors the DataFusion `ExecutionPlan` operator interface the reference's
+executor calls (rust/executor/src/flight_service.rs:117-121); all compute runs in
+`lib/libballista_hip.so` (hand-written HIP kernels for gfx950) behind the C ABI of
+`include/ballista_hip.h`.  There is no CPU fallback: without the built library, or without a
+GPU, calls fail with the library's error.
+"""
+from . import expr, plan, tpch  # noqa: F401
+from ._lib import (BallistaError, ExecutionError, HipError, NotImplementedOnGpu, PlanError, LIB_PATH)  # noqa: F401
+from .plan import (Context, RecordBatch, RecordBatchStream, ExecutionPlan, Partitioning, MemoryExec, FilterExec,  # noqa: F401
+                   ProjectionExec, HashAggregateExec, HashJoinExec, SortExec, RepartitionExec, CoalesceBatchesExec,
+                   MergeExec, GlobalLimitExec, LocalLimitExec)
+
+__version__ = "0.1.0"

@@ -1,0 +1,287 @@
+// arrow_c.cpp — Arrow C Data / C Stream interface at the host edge of the library.
+//
+// The Arrow C Stream Interface (get_schema / get_next / get_last_error / release) is the C
+// analogue of the reference's `RecordBatchStream` (rust/core/src/memory_stream.rs:57-92); the
+// C Data Interface carries one RecordBatch as a struct array.  The Rust executor side would
+// produce/consume these through arrow-rs' `ffi` module.
+#include <cstdlib>
+#include <cstring>
+
+#include "plan.hpp"
+
+using namespace bhip;
+
+namespace {
+
+int dtype_from_format(const char* f) {
+    if (!strcmp(f, "i")) return DT_INT32;
+    if (!strcmp(f, "l")) return DT_INT64;
+    if (!strcmp(f, "C")) return DT_UINT8;
+    if (!strcmp(f, "L")) return DT_UINT64;
+    if (!strcmp(f, "g")) return DT_FLOAT64;
+    if (!strcmp(f, "tdD")) return DT_DATE32;
+    if (!strcmp(f, "b")) return DT_BOOLEAN;
+    if (!strcmp(f, "u")) return DT_UTF8;
+    return 0;
+}
+
+const char* format_of(int dt) {
+    switch (dt) {
+        case DT_INT32: return "i";
+        case DT_INT64: return "l";
+        case DT_UINT8: return "C";
+        case DT_UINT64: return "L";
+        case DT_FLOAT64: return "g";
+        case DT_DATE32: return "tdD";
+        case DT_BOOLEAN: return "b";
+        default: return "u";
+    }
+}
+
+// copy n bits starting at bit `off` of src into a fresh, zero-padded bitmap
+std::vector<uint8_t> realign_bits(const uint8_t* src, int64_t off, int64_t n) {
+    std::vector<uint8_t> out((size_t)((n + 63) / 64) * 8 + 8, 0);
+    if ((off & 7) == 0) { memcpy(out.data(), src + off / 8, (size_t)((n + 7) / 8)); }
+    else
+        for (int64_t i = 0; i < n; ++i) {
+            const int64_t s = off + i;
+            if ((src[s >> 3] >> (s & 7)) & 1) out[(size_t)(i >> 3)] |= (uint8_t)(1u << (i & 7));
+        }
+    // clear bits past n in the last byte
+    if (n & 7) out[(size_t)(n >> 3)] &= (uint8_t)((1u << (n & 7)) - 1u);
+    return out;
+}
+
+// ---- export ------------------------------------------------------------------------------------------
+struct ExportedArray {
+    std::vector<void*> owned;                 // malloc'd buffers
+    std::vector<const void*> buffers;
+    std::vector<ArrowArray> child_storage;
+    std::vector<ArrowArray*> child_ptrs;
+    std::vector<ExportedArray*> child_priv;
+    ~ExportedArray() { for (void* p : owned) free(p); }
+};
+
+void release_array(ArrowArray* a) {
+    if (!a || !a->release) return;
+    auto* priv = static_cast<ExportedArray*>(a->private_data);
+    for (auto& c : priv->child_storage)
+        if (c.release) c.release(&c);
+    delete priv;
+    a->release = nullptr;
+}
+
+struct ExportedSchema {
+    std::string format, name;
+    std::vector<ArrowSchema> child_storage;
+    std::vector<ArrowSchema*> child_ptrs;
+};
+
+void release_schema(ArrowSchema* s) {
+    if (!s || !s->release) return;
+    auto* priv = static_cast<ExportedSchema*>(s->private_data);
+    for (auto& c : priv->child_storage)
+        if (c.release) c.release(&c);
+    delete priv;
+    s->release = nullptr;
+}
+
+void export_schema(const Schema& schema, ArrowSchema* out) {
+    auto* top = new ExportedSchema();
+    top->format = "+s";
+    top->name = "";
+    top->child_storage.resize(schema.fields.size());
+    for (size_t i = 0; i < schema.fields.size(); ++i) {
+        auto* cp = new ExportedSchema();
+        cp->format = format_of(schema.fields[i].dtype);
+        cp->name = schema.fields[i].name;
+        ArrowSchema& c = top->child_storage[i];
+        memset(&c, 0, sizeof(c));
+        c.format = cp->format.c_str();
+        c.name = cp->name.c_str();
+        c.flags = schema.fields[i].nullable ? ARROW_FLAG_NULLABLE : 0;
+        c.release = release_schema;
+        c.private_data = cp;
+        top->child_ptrs.push_back(&c);
+    }
+    memset(out, 0, sizeof(*out));
+    out->format = top->format.c_str();
+    out->name = top->name.c_str();
+    out->n_children = (int64_t)schema.fields.size();
+    out->children = top->child_ptrs.data();
+    out->release = release_schema;
+    out->private_data = top;
+}
+
+void export_batch(const Batch& b, ArrowArray* out) {
+    b.ctx->set_device();
+    HIP_CHECK(hipDeviceSynchronize());
+    auto* top = new ExportedArray();
+    std::unique_ptr<ExportedArray> guard(top);
+    top->child_storage.resize(b.cols.size());
+    for (auto& c : top->child_storage) memset(&c, 0, sizeof(c));
+    for (size_t i = 0; i < b.cols.size(); ++i) {
+        const Column& c = b.cols[i];
+        auto* cp = new ExportedArray();
+        ArrowArray& a = top->child_storage[i];
+        a.private_data = cp;
+        a.release = release_array;
+        auto host_copy = [&](const void* dev, size_t bytes) -> void* {
+            void* h = malloc(bytes ? bytes : 8);
+            if (!h) fail(BHIP_EOOM, "host allocation failed");
+            cp->owned.push_back(h);
+            if (bytes) HIP_CHECK(hipMemcpy(h, dev, bytes, hipMemcpyDeviceToHost));
+            return h;
+        };
+        const int64_t n = b.n_rows;
+        const void* validity = c.validity ? host_copy(c.validity->ptr(), (size_t)((n + 7) / 8)) : nullptr;
+        cp->buffers.push_back(validity);
+        if (c.dtype == DT_UTF8) {
+            cp->buffers.push_back(host_copy(c.offsets->ptr(), (size_t)(n + 1) * 4));
+            cp->buffers.push_back(host_copy(c.data->ptr(), (size_t)c.data_bytes));
+        } else if (c.dtype == DT_BOOLEAN) {
+            cp->buffers.push_back(host_copy(c.data->ptr(), (size_t)((n + 7) / 8)));
+        } else {
+            cp->buffers.push_back(host_copy(c.data->ptr(), (size_t)n * dtype_width(c.dtype)));
+        }
+        a.length = n;
+        a.null_count = c.validity ? -1 : 0;
+        a.offset = 0;
+        a.n_buffers = (int64_t)cp->buffers.size();
+        a.buffers = cp->buffers.data();
+        top->child_ptrs.push_back(&a);
+    }
+    top->buffers.push_back(nullptr);
+    memset(out, 0, sizeof(*out));
+    out->length = b.n_rows;
+    out->null_count = 0;
+    out->n_buffers = 1;
+    out->buffers = top->buffers.data();
+    out->n_children = (int64_t)b.cols.size();
+    out->children = top->child_ptrs.data();
+    out->release = release_array;
+    out->private_data = guard.release();
+}
+
+// ---- C stream ------------------------------------------------------------------------------------------
+struct StreamPriv {
+    bhip_stream* s;
+    std::string last_error;
+};
+
+int stream_get_schema(ArrowArrayStream* st, ArrowSchema* out) {
+    auto* p = static_cast<StreamPriv*>(st->private_data);
+    try {
+        export_schema(*p->s->s->schema(), out);
+        return 0;
+    } catch (const std::exception& e) { p->last_error = e.what(); return 5 /* EIO */; }
+}
+
+int stream_get_next(ArrowArrayStream* st, ArrowArray* out) {
+    auto* p = static_cast<StreamPriv*>(st->private_data);
+    try {
+        p->s->ex.ctx->set_device();
+        BatchPtr b = p->s->s->next();
+        if (!b) { memset(out, 0, sizeof(*out)); return 0; }   // released array = end of stream
+        HIP_CHECK(hipStreamSynchronize(p->s->ex.stream));
+        export_batch(*b, out);
+        return 0;
+    } catch (const std::exception& e) { p->last_error = e.what(); return 5; }
+}
+
+const char* stream_last_error(ArrowArrayStream* st) { return static_cast<StreamPriv*>(st->private_data)->last_error.c_str(); }
+
+void stream_release(ArrowArrayStream* st) {
+    if (!st || !st->release) return;
+    auto* p = static_cast<StreamPriv*>(st->private_data);
+    delete p->s;
+    delete p;
+    st->release = nullptr;
+}
+
+}  // namespace
+
+extern "C" {
+
+bhip_status bhip_batch_import_arrow(bhip_ctx* ctx, struct ArrowArray* array, struct ArrowSchema* schema, bhip_batch** out) {
+    try {
+        if (!ctx || !array || !schema || !out) fail(BHIP_EINVAL, "null argument");
+        if (!schema->format || strcmp(schema->format, "+s") != 0) fail(BHIP_EINVAL, "expected a struct array (RecordBatch)");
+        if (array->n_children != schema->n_children) fail(BHIP_EINVAL, "array / schema children mismatch");
+        const int n_cols = (int)array->n_children;
+        const int64_t n_rows = array->length;
+        std::vector<bhip_column_desc> descs(n_cols);
+        std::vector<std::vector<uint8_t>> bit_storage;
+        std::vector<std::vector<int32_t>> off_storage;
+        for (int i = 0; i < n_cols; ++i) {
+            const ArrowSchema* cs = schema->children[i];
+            const ArrowArray* ca = array->children[i];
+            const int dt = dtype_from_format(cs->format);
+            if (!dt) fail(BHIP_ENOTIMPL, std::string("unsupported Arrow type '") + cs->format + "' for column " + (cs->name ? cs->name : ""));
+            if (ca->dictionary) fail(BHIP_ENOTIMPL, "dictionary arrays are not supported");
+            const int64_t off = ca->offset + array->offset;
+            bhip_column_desc& d = descs[i];
+            memset(&d, 0, sizeof(d));
+            d.name = cs->name ? cs->name : "";
+            d.dtype = dt;
+            d.nullable = (cs->flags & ARROW_FLAG_NULLABLE) ? 1 : 0;
+            const uint8_t* validity = ca->n_buffers > 0 ? static_cast<const uint8_t*>(ca->buffers[0]) : nullptr;
+            if (validity && ca->null_count != 0) {
+                bit_storage.push_back(realign_bits(validity, off, n_rows));
+                d.validity = bit_storage.back().data();
+            }
+            if (dt == DT_UTF8) {
+                const int32_t* offsets = static_cast<const int32_t*>(ca->buffers[1]) + off;
+                // rebase to 0 so only the referenced bytes are shipped
+                off_storage.emplace_back((size_t)n_rows + 1);
+                auto& o = off_storage.back();
+                const int32_t first = n_rows >= 0 && ca->buffers[1] ? offsets[0] : 0;
+                for (int64_t r = 0; r <= n_rows; ++r) o[(size_t)r] = offsets[r] - first;
+                d.offsets = o.data();
+                d.data = static_cast<const uint8_t*>(ca->buffers[2]) + first;
+                d.data_bytes = o[(size_t)n_rows];
+                if (!ca->buffers[2]) d.data = "";
+            } else if (dt == DT_BOOLEAN) {
+                bit_storage.push_back(realign_bits(static_cast<const uint8_t*>(ca->buffers[1]), off, n_rows));
+                d.data = bit_storage.back().data();
+            } else {
+                d.data = static_cast<const uint8_t*>(ca->buffers[1]) + off * dtype_width(dt);
+            }
+        }
+        BatchPtr b = batch_from_host(ctx->p, n_cols, descs.data(), n_rows, false);
+        // schema nullability follows the Arrow field flag
+        auto s = std::make_shared<Schema>(*b->schema);
+        for (int i = 0; i < n_cols; ++i) s->fields[i].nullable = descs[i].nullable || descs[i].validity;
+        auto nb = std::make_shared<Batch>(*b);
+        nb->schema = s;
+        auto h = new bhip_batch();
+        h->p = nb;
+        *out = h;
+        if (array->release) array->release(array);
+        return BHIP_OK;
+    } catch (const bhip::Error& e) { set_last_error(e.what()); return e.code; }
+    catch (const std::exception& e) { set_last_error(e.what()); return BHIP_EINVAL; }
+}
+
+bhip_status bhip_batch_export_arrow(bhip_batch* batch, struct ArrowArray* out_array, struct ArrowSchema* out_schema) {
+    try {
+        if (!batch || !out_array || !out_schema) fail(BHIP_EINVAL, "null argument");
+        export_schema(*batch->p->schema, out_schema);
+        try { export_batch(*batch->p, out_array); } catch (...) { release_schema(out_schema); throw; }
+        return BHIP_OK;
+    } catch (const bhip::Error& e) { set_last_error(e.what()); return e.code; }
+    catch (const std::exception& e) { set_last_error(e.what()); return BHIP_EINVAL; }
+}
+
+bhip_status bhip_stream_export_arrow(bhip_stream* stream, struct ArrowArrayStream* out) {
+    if (!stream || !out) { set_last_error("null argument"); return BHIP_EINVAL; }
+    auto* p = new StreamPriv{stream, ""};
+    out->get_schema = stream_get_schema;
+    out->get_next = stream_get_next;
+    out->get_last_error = stream_last_error;
+    out->release = stream_release;
+    out->private_data = p;
+    return BHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,278 @@
+// core.cpp — context (allocator, streams), buffers, batches.
+#include "core.hpp"
+
+#include <cstdlib>
+
+namespace bhip {
+
+static thread_local std::string t_last_error;
+void set_last_error(const std::string& m) { t_last_error = m; }
+const char* get_last_error() { return t_last_error.c_str(); }
+
+const char* dtype_name(int dt) {
+    switch (dt) {
+        case DT_INT32: return "Int32";
+        case DT_INT64: return "Int64";
+        case DT_UINT8: return "UInt8";
+        case DT_UINT64: return "UInt64";
+        case DT_FLOAT64: return "Float64";
+        case DT_DATE32: return "Date32";
+        case DT_BOOLEAN: return "Boolean";
+        case DT_UTF8: return "Utf8";
+        default: return "?";
+    }
+}
+
+int dtype_width(int dt) {
+    switch (dt) {
+        case DT_INT32:
+        case DT_DATE32: return 4;
+        case DT_INT64:
+        case DT_UINT64:
+        case DT_FLOAT64: return 8;
+        case DT_UINT8: return 1;
+        default: return 0;
+    }
+}
+
+// ---- context -----------------------------------------------------------------------------------
+Context::Context(int device) : device_(device) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        fail(BHIP_EHIP, std::string("no HIP device available: ") + hipGetErrorString(e));
+    if (device < 0 || device >= count) fail(BHIP_EINVAL, "device index out of range");
+    HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    cus_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const char* t = getenv("BHIP_KERNEL_TIMING");
+    timing_ = t && atoi(t) != 0;
+}
+
+Context::~Context() {
+    hipSetDevice(device_);
+    hipDeviceSynchronize();
+    for (auto& kv : free_blocks_) {
+        hipFree(kv.second.ptr);
+        if (kv.second.ready) hipEventDestroy(kv.second.ready);
+    }
+    for (auto& kv : live_) hipFree(kv.second.ptr);
+    for (auto s : stream_pool_) hipStreamDestroy(s);
+}
+
+static size_t round_size(size_t bytes) {
+    if (bytes < 512) return 512;
+    if (bytes < (1u << 20)) return (bytes + 511) & ~(size_t)511;
+    return (bytes + ((1u << 20) - 1)) & ~(size_t)((1u << 20) - 1);
+}
+
+void* Context::alloc(size_t bytes, hipStream_t stream) {
+    const size_t want = round_size(bytes);
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        // best fit within 25 % slack
+        auto it = free_blocks_.lower_bound(want);
+        if (it != free_blocks_.end() && it->first <= want + want / 4 + 4096) {
+            Block b = it->second;
+            free_blocks_.erase(it);
+            cached_ -= b.bytes;
+            if (b.last_stream != stream && b.ready) HIP_CHECK(hipStreamWaitEvent(stream, b.ready, 0));
+            b.last_stream = stream;
+            live_[b.ptr] = b;
+            in_use_ += b.bytes;
+            if (in_use_ > peak_) peak_ = in_use_;
+            return b.ptr;
+        }
+    }
+    set_device();
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+        trim();   // give cached blocks back and retry once
+        e = hipMalloc(&p, want);
+    }
+    if (e != hipSuccess) fail(BHIP_EOOM, "hipMalloc of " + std::to_string(want) + " bytes failed: " + hipGetErrorString(e));
+    Block b;
+    b.ptr = p;
+    b.bytes = want;
+    b.last_stream = stream;
+    std::lock_guard<std::mutex> g(mu_);
+    live_[p] = b;
+    in_use_ += want;
+    if (in_use_ > peak_) peak_ = in_use_;
+    return p;
+}
+
+void Context::free(void* ptr, hipStream_t stream) {
+    if (!ptr) return;
+    std::lock_guard<std::mutex> g(mu_);
+    auto it = live_.find(ptr);
+    if (it == live_.end()) return;
+    Block b = it->second;
+    live_.erase(it);
+    in_use_ -= b.bytes;
+    hipSetDevice(device_);
+    if (!b.ready) hipEventCreateWithFlags(&b.ready, hipEventDisableTiming);
+    // work that used the block was enqueued on `stream` (the owning task's stream)
+    hipEventRecord(b.ready, stream);
+    b.last_stream = stream;
+    cached_ += b.bytes;
+    free_blocks_.emplace(b.bytes, b);
+}
+
+void Context::trim() {
+    std::lock_guard<std::mutex> g(mu_);
+    hipSetDevice(device_);
+    hipDeviceSynchronize();
+    for (auto& kv : free_blocks_) {
+        hipFree(kv.second.ptr);
+        if (kv.second.ready) hipEventDestroy(kv.second.ready);
+    }
+    free_blocks_.clear();
+    cached_ = 0;
+}
+
+void Context::memory(uint64_t* in_use, uint64_t* peak) {
+    std::lock_guard<std::mutex> g(mu_);
+    if (in_use) *in_use = in_use_;
+    if (peak) *peak = peak_;
+}
+
+hipStream_t Context::acquire_stream() {
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        if (!stream_pool_.empty()) {
+            hipStream_t s = stream_pool_.back();
+            stream_pool_.pop_back();
+            return s;
+        }
+    }
+    set_device();
+    hipStream_t s;
+    HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    return s;
+}
+
+void Context::release_stream(hipStream_t s) {
+    std::lock_guard<std::mutex> g(mu_);
+    stream_pool_.push_back(s);
+}
+
+void Context::add_kernel_time(double ms, uint64_t launches) {
+    std::lock_guard<std::mutex> g(mu_);
+    k_ms_ += ms;
+    k_launches_ += launches;
+}
+
+void Context::kernel_time(bool reset, double* ms, uint64_t* launches) {
+    std::lock_guard<std::mutex> g(mu_);
+    if (ms) *ms = k_ms_;
+    if (launches) *launches = k_launches_;
+    if (reset) { k_ms_ = 0; k_launches_ = 0; }
+}
+
+// ---- buffers ------------------------------------------------------------------------------------
+Buffer::Buffer(ContextPtr ctx, size_t bytes, hipStream_t stream)
+    : ctx_(std::move(ctx)), ptr_(nullptr), bytes_(bytes), owned_(true), stream_(stream) {
+    ptr_ = ctx_->alloc(bytes ? bytes : 8, stream);
+}
+Buffer::Buffer(ContextPtr ctx, void* borrowed, size_t bytes)
+    : ctx_(std::move(ctx)), ptr_(borrowed), bytes_(bytes), owned_(false), stream_(nullptr) {}
+Buffer::~Buffer() {
+    if (owned_ && ptr_) ctx_->free(ptr_, stream_);
+}
+
+BufferPtr make_buffer(const Exec& ex, size_t bytes) { return std::make_shared<Buffer>(ex.ctx, bytes, ex.stream); }
+
+int64_t Column::memory_size() const {
+    int64_t b = 0;
+    if (dtype == DT_UTF8) b += data_bytes + (length + 1) * 4;
+    else if (dtype == DT_BOOLEAN) b += (length + 7) / 8;
+    else b += length * dtype_width(dtype);
+    if (validity) b += (length + 7) / 8;
+    return b;
+}
+
+int64_t Batch::memory_size() const {
+    int64_t b = 0;
+    for (const auto& c : cols) b += c.memory_size();
+    return b;
+}
+
+// ---- host <-> device -------------------------------------------------------------------------------
+BatchPtr batch_from_host(const ContextPtr& ctx, int n_cols, const bhip_column_desc* cols, int64_t n_rows, bool device_ptrs) {
+    if (n_rows < 0 || n_rows > 0xFFFFFFF0ll) fail(BHIP_EINVAL, "batch row count out of range (max 2^32-16 rows per batch)");
+    ctx->set_device();
+    auto schema = std::make_shared<Schema>();
+    auto batch = std::make_shared<Batch>();
+    batch->ctx = ctx;
+    batch->n_rows = n_rows;
+    hipStream_t st = nullptr;   // null stream: synchronous wrt the caller
+    Exec ex{ctx, st};
+    for (int i = 0; i < n_cols; ++i) {
+        const bhip_column_desc& d = cols[i];
+        if (!d.name) fail(BHIP_EINVAL, "column without a name");
+        if (d.dtype < DT_INT32 || d.dtype > DT_UTF8) fail(BHIP_ENOTIMPL, std::string("unsupported data type for column ") + d.name);
+        schema->fields.push_back(Field{d.name, d.dtype, d.nullable != 0 || d.validity != nullptr});
+        Column c;
+        c.dtype = d.dtype;
+        c.length = n_rows;
+        size_t data_bytes;
+        if (d.dtype == DT_UTF8) {
+            if (!d.offsets) fail(BHIP_EINVAL, std::string("Utf8 column without offsets: ") + d.name);
+            data_bytes = (size_t)d.data_bytes;
+            c.data_bytes = d.data_bytes;
+        } else if (d.dtype == DT_BOOLEAN) {
+            data_bytes = (size_t)((n_rows + 7) / 8);
+        } else {
+            data_bytes = (size_t)n_rows * dtype_width(d.dtype);
+        }
+        if (!d.data && data_bytes > 0) fail(BHIP_EINVAL, std::string("column without data: ") + d.name);
+        if (device_ptrs) {
+            c.data = std::make_shared<Buffer>(ctx, const_cast<void*>(d.data), data_bytes);
+            if (d.offsets) c.offsets = std::make_shared<Buffer>(ctx, const_cast<int32_t*>(d.offsets), (size_t)(n_rows + 1) * 4);
+            if (d.validity) c.validity = std::make_shared<Buffer>(ctx, const_cast<uint8_t*>(d.validity), bitmap_bytes(n_rows));
+        } else {
+            // device copies are padded to whole 64-bit words (bitmaps are read as u64)
+            const size_t padded = d.dtype == DT_BOOLEAN ? bitmap_bytes(n_rows) : data_bytes;
+            c.data = make_buffer(ex, padded + 8);
+            if (d.dtype == DT_BOOLEAN) HIP_CHECK(hipMemset(c.data->ptr(), 0, padded + 8));
+            if (data_bytes) HIP_CHECK(hipMemcpy(c.data->ptr(), d.data, data_bytes, hipMemcpyHostToDevice));
+            if (d.offsets) {
+                c.offsets = make_buffer(ex, (size_t)(n_rows + 1) * 4);
+                HIP_CHECK(hipMemcpy(c.offsets->ptr(), d.offsets, (size_t)(n_rows + 1) * 4, hipMemcpyHostToDevice));
+            }
+            if (d.validity) {
+                c.validity = make_buffer(ex, bitmap_bytes(n_rows) + 8);
+                HIP_CHECK(hipMemset(c.validity->ptr(), 0, bitmap_bytes(n_rows) + 8));
+                HIP_CHECK(hipMemcpy(c.validity->ptr(), d.validity, (size_t)((n_rows + 7) / 8), hipMemcpyHostToDevice));
+            }
+        }
+        batch->cols.push_back(std::move(c));
+    }
+    batch->schema = schema;
+    return batch;
+}
+
+void column_to_host(const Batch& b, int i, void* data, int32_t* offsets, uint8_t* validity) {
+    if (i < 0 || i >= (int)b.cols.size()) fail(BHIP_EINVAL, "column index out of range");
+    b.ctx->set_device();
+    HIP_CHECK(hipDeviceSynchronize());
+    const Column& c = b.cols[i];
+    if (data) {
+        size_t bytes;
+        if (c.dtype == DT_UTF8) bytes = (size_t)c.data_bytes;
+        else if (c.dtype == DT_BOOLEAN) bytes = (size_t)((c.length + 7) / 8);
+        else bytes = (size_t)c.length * dtype_width(c.dtype);
+        if (bytes) HIP_CHECK(hipMemcpy(data, c.data->ptr(), bytes, hipMemcpyDeviceToHost));
+    }
+    if (offsets && c.offsets) HIP_CHECK(hipMemcpy(offsets, c.offsets->ptr(), (size_t)(c.length + 1) * 4, hipMemcpyDeviceToHost));
+    if (validity) {
+        const size_t bytes = (size_t)((c.length + 7) / 8);
+        if (c.validity) { if (bytes) HIP_CHECK(hipMemcpy(validity, c.validity->ptr(), bytes, hipMemcpyDeviceToHost)); }
+        else memset(validity, 0xFF, bytes);
+    }
+}
+
+}  // namespace bhip

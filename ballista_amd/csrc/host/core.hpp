@@ -1,0 +1,200 @@
+// core.hpp — host-side runtime objects: errors, the per-GPU context (caching allocator, stream
+// pool, pinned staging), device buffers, columns, schemas, record batches.
+//
+// Reference conventions being mirrored: RecordBatch columns are Arc'd immutable buffers
+// (rust/core/src/memory_stream.rs:29-92); errors are Result<_, DataFusionError> values, never
+// panics (rust/core/src/execution_plans/unresolved_shuffle.rs:83-90; rust/core/src/error.rs).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/ballista_hip.h"
+#include "../kernels.h"
+
+namespace bhip {
+
+// ---- errors ---------------------------------------------------------------------------------
+struct Error : std::runtime_error {
+    bhip_status code;
+    Error(bhip_status c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+[[noreturn]] inline void fail(bhip_status c, const std::string& m) { throw Error(c, m); }
+inline void hip_check(hipError_t e, const char* what) {
+    if (e != hipSuccess) {
+        if (e == hipErrorOutOfMemory) fail(BHIP_EOOM, std::string(what) + ": " + hipGetErrorString(e));
+        fail(BHIP_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+    }
+}
+#define HIP_CHECK(expr) ::bhip::hip_check((expr), #expr)
+
+void set_last_error(const std::string& m);
+const char* get_last_error();
+
+const char* dtype_name(int dt);
+int dtype_width(int dt);   // bytes of a fixed-width value; 0 for Utf8 / Boolean
+
+// ---- context ----------------------------------------------------------------------------------
+class Context;
+
+struct Block {               // one allocation of the caching allocator
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    hipStream_t last_stream = nullptr;
+    hipEvent_t ready = nullptr;   // recorded when the block was released
+};
+
+class Context : public std::enable_shared_from_this<Context> {
+public:
+    explicit Context(int device);
+    ~Context();
+    int device() const { return device_; }
+    int cus() const { return cus_; }
+    void set_device() const { HIP_CHECK(hipSetDevice(device_)); }
+
+    // stream-aware caching allocator: a released block is reused by the same stream at once and
+    // by another stream only after the release event
+    void* alloc(size_t bytes, hipStream_t stream);
+    void free(void* ptr, hipStream_t stream);
+    void memory(uint64_t* in_use, uint64_t* peak);
+    void trim();
+
+    hipStream_t acquire_stream();
+    void release_stream(hipStream_t s);
+
+    // kernel timing hook (bench roofline): accumulated by the aggregate operator
+    void add_kernel_time(double ms, uint64_t launches);
+    void kernel_time(bool reset, double* ms, uint64_t* launches);
+    bool timing_enabled() const { return timing_; }
+
+private:
+    int device_;
+    int cus_ = 256;
+    bool timing_ = false;
+    std::mutex mu_;
+    std::multimap<size_t, Block> free_blocks_;
+    std::map<void*, Block> live_;
+    uint64_t in_use_ = 0, peak_ = 0, cached_ = 0;
+    std::vector<hipStream_t> stream_pool_;
+    double k_ms_ = 0;
+    uint64_t k_launches_ = 0;
+};
+using ContextPtr = std::shared_ptr<Context>;
+
+// execution context of one task: the context + the HIP stream every kernel of the task runs on
+struct Exec {
+    ContextPtr ctx;
+    hipStream_t stream;
+    LaunchCfg cfg() const { return LaunchCfg{ctx->cus(), stream}; }
+};
+
+// ---- device buffers -----------------------------------------------------------------------------
+class Buffer {
+public:
+    Buffer(ContextPtr ctx, size_t bytes, hipStream_t stream);          // owned
+    Buffer(ContextPtr ctx, void* borrowed, size_t bytes);              // borrowed device pointer
+    ~Buffer();
+    Buffer(const Buffer&) = delete;
+    Buffer& operator=(const Buffer&) = delete;
+    void* ptr() const { return ptr_; }
+    size_t bytes() const { return bytes_; }
+    template <class T> T* as() const { return reinterpret_cast<T*>(ptr_); }
+    void set_stream(hipStream_t s) { stream_ = s; }
+private:
+    ContextPtr ctx_;
+    void* ptr_;
+    size_t bytes_;
+    bool owned_;
+    hipStream_t stream_;
+};
+using BufferPtr = std::shared_ptr<Buffer>;
+BufferPtr make_buffer(const Exec& ex, size_t bytes);
+inline size_t bitmap_bytes(int64_t n_bits) { return (size_t)((n_bits + 63) / 64) * 8; }
+
+// scratch that lives for one operator call
+struct Temp {
+    const Exec& ex;
+    std::vector<BufferPtr> held;
+    explicit Temp(const Exec& e) : ex(e) {}
+    template <class T> T* get(size_t count) {
+        held.push_back(make_buffer(ex, count * sizeof(T) + 16));
+        return held.back()->as<T>();
+    }
+};
+
+// ---- columns / schema / batches -------------------------------------------------------------------
+struct Column {
+    int dtype = 0;
+    int64_t length = 0;
+    BufferPtr data;        // values | Utf8 bytes | Boolean bitmap
+    BufferPtr offsets;     // Utf8
+    BufferPtr validity;    // may be null
+    int64_t data_bytes = 0;   // Utf8 value bytes
+    ColumnRef ref() const {
+        ColumnRef r;
+        r.data = data ? data->ptr() : nullptr;
+        r.offsets = offsets ? offsets->as<int32_t>() : nullptr;
+        r.validity = validity ? validity->as<uint64_t>() : nullptr;
+        r.dtype = dtype;
+        r.pad = 0;
+        return r;
+    }
+    int64_t memory_size() const;
+};
+
+struct Field {
+    std::string name;
+    int dtype;
+    bool nullable;
+};
+
+struct Schema {
+    std::vector<Field> fields;
+    int index_of(const std::string& name) const {
+        for (size_t i = 0; i < fields.size(); ++i)
+            if (fields[i].name == name) return (int)i;
+        return -1;
+    }
+};
+using SchemaPtr = std::shared_ptr<const Schema>;
+
+struct Batch {
+    SchemaPtr schema;
+    std::vector<Column> cols;
+    int64_t n_rows = 0;
+    ContextPtr ctx;
+    int64_t memory_size() const;
+};
+using BatchPtr = std::shared_ptr<const Batch>;
+
+// host <-> device movement
+BatchPtr batch_from_host(const ContextPtr& ctx, int n_cols, const bhip_column_desc* cols, int64_t n_rows, bool device_ptrs);
+void column_to_host(const Batch& b, int i, void* data, int32_t* offsets, uint8_t* validity);
+
+// whole-batch operations (ops_basic.cpp)
+BatchPtr take_batch(const Exec& ex, const Batch& in, const uint32_t* indices, int64_t n_out, SchemaPtr schema = nullptr);
+Column take_column(const Exec& ex, const Column& c, const uint32_t* indices, int64_t n_out);
+BatchPtr concat_batches(const Exec& ex, const SchemaPtr& schema, const std::vector<BatchPtr>& parts);
+BatchPtr slice_head(const Exec& ex, const Batch& in, int64_t n);
+
+// read a small device value after synchronising the task's stream
+template <class T>
+T read_device(const Exec& ex, const T* dev) {
+    T host;
+    HIP_CHECK(hipMemcpyAsync(&host, dev, sizeof(T), hipMemcpyDeviceToHost, ex.stream));
+    HIP_CHECK(hipStreamSynchronize(ex.stream));
+    return host;
+}
+
+}  // namespace bhip
+
+// opaque C handles
+struct bhip_ctx { bhip::ContextPtr p; std::atomic<int> rc{1}; };
+struct bhip_batch { bhip::BatchPtr p; std::atomic<int> rc{1}; std::vector<std::string> names; };

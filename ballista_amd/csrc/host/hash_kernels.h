@@ -1,0 +1,47 @@
+// hash_kernels.h — launchers of kernels_hash.hip (device-wide hash tables: high-cardinality
+// aggregation, join build/probe) — internal C++ interface.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../kernels.h"
+
+namespace bhip {
+
+// ---- aggregation ------------------------------------------------------------------------------
+struct HashAggTable {
+    uint32_t* owner;          // [capacity] 0 = empty, else id+1 of the row whose key defines the slot
+    uint64_t mask;            // capacity - 1 (capacity is a power of two)
+    const uint64_t* keys128;  // packed keys of every input row (all batches, 2 x u64 per row)
+    uint64_t* acc;            // [capacity][n_acc]
+    uint64_t* nvalid;         // [capacity][n_acc]   (only with NULLs)
+    uint64_t* rows;           // [capacity]
+    int32_t n_acc;
+    int32_t pad;
+};
+struct MergeAccKinds { uint8_t kind[VM_MAX_ACC]; };
+
+hipError_t launch_scan_agg_hash(const LaunchCfg& cfg, const ScanParams& P, const HashAggTable& T, uint32_t row_base,
+                                ScanStatus* status);
+hipError_t launch_hash_agg_init(const LaunchCfg& cfg, const HashAggTable& T, const MergeAccKinds& kinds);
+hipError_t launch_hash_agg_flags(const LaunchCfg& cfg, const HashAggTable& T, uint32_t* flags);
+hipError_t launch_hash_agg_compact(const LaunchCfg& cfg, const HashAggTable& T, const uint64_t* dense_index, bool nulls,
+                                   GroupRec* out);
+
+// ---- join -------------------------------------------------------------------------------------
+struct JoinTable {
+    uint32_t* owner;          // [capacity] id+1 of the build row whose key defines the slot
+    uint32_t* head;           // [capacity] id+1 of the most recently inserted build row of the slot's key
+    uint32_t* next;           // [n_left]   id+1 of the next build row with the same key
+    uint64_t mask;
+    const uint64_t* keys128;  // packed keys of the build rows
+};
+hipError_t launch_join_build(const LaunchCfg& cfg, const JoinTable& T, const uint64_t* sel, uint32_t n_left);
+hipError_t launch_join_probe_count(const LaunchCfg& cfg, const JoinTable& T, const uint64_t* rkeys128, const uint64_t* rsel,
+                                   uint32_t n_right, bool right_outer, uint32_t* counts);
+hipError_t launch_join_probe_emit(const LaunchCfg& cfg, const JoinTable& T, const uint64_t* rkeys128, const uint64_t* rsel,
+                                  uint32_t n_right, bool right_outer, const uint64_t* offsets, uint32_t* left_idx,
+                                  uint32_t* right_idx, uint32_t* matched);
+hipError_t launch_join_unmatched_flags(const LaunchCfg& cfg, const uint32_t* matched, uint32_t n_left, uint32_t* flags);
+hipError_t launch_compact_flags(const LaunchCfg& cfg, const uint32_t* flags, const uint64_t* offsets, uint32_t n, uint32_t* out);
+
+}  // namespace bhip

@@ -1,0 +1,443 @@
+// ops_agg.cpp — HashAggregateExec (Partial / Final) over the fused scan kernels.
+//
+// Reference: built at rust/core/src/serde/physical_plan/from_proto.rs:173-252 (mode :181-184,
+// aggregates via create_aggregate_expr :230-236; only Sum/Avg/Count are serialisable,
+// to_proto.rs:352-363); the stage split Partial | Final is rust/scheduler/src/planner.rs:149-171.
+// State layout: SUM -> [sum]; AVG -> [count: UInt64, sum: Float64];
+// COUNT -> [count: UInt64].  Final merges by position: state columns follow the group columns
+// in aggregate order.
+//
+// execute() folds the FilterExec / CoalesceBatchesExec / ProjectionExec chain below the
+// aggregate into the aggregate's own kernel (predicate fused, projection expressions
+// substituted), i.e. the whole of TPC-H Q1/Q6 stage 1 is one kernel launch per input batch.
+#include "../util_kernels.h"
+#include "hash_kernels.h"
+#include "plan.hpp"
+
+namespace bhip {
+
+static int sum_type(int t) {
+    if (t == DT_FLOAT64) return DT_FLOAT64;
+    if (t == DT_UINT8 || t == DT_UINT64) return DT_UINT64;
+    return DT_INT64;
+}
+
+static const char* agg_name(int fn) {
+    switch (fn) {
+        case BHIP_AGG_SUM: return "SUM";
+        case BHIP_AGG_AVG: return "AVG";
+        case BHIP_AGG_COUNT: return "COUNT";
+        case BHIP_AGG_MIN: return "MIN";
+        default: return "MAX";
+    }
+}
+
+HashAggregateExec::HashAggregateExec(int mode, std::vector<std::pair<ExprPtr, std::string>> group_exprs,
+                                     std::vector<AggregateDesc> aggr, PlanPtr input)
+    : mode_(mode), group_(std::move(group_exprs)), aggr_(std::move(aggr)) {
+    input_ = std::move(input);
+    ctx_ = input_->context();
+    if (mode != BHIP_AGG_PARTIAL && mode != BHIP_AGG_FINAL) fail(BHIP_EINVAL, "Unsupported aggregate mode");
+    const Schema& in = *input_->schema();
+    auto s = std::make_shared<Schema>();
+    for (auto& g : group_) s->fields.push_back(Field{g.second, expr_type(g.first, in), expr_nullable(g.first, in)});
+    size_t state_pos = group_.size();
+    for (auto& a : aggr_) {
+        if (a.fn < BHIP_AGG_SUM || a.fn > BHIP_AGG_MAX) fail(BHIP_ENOTIMPL, "Unsupported aggregate function");
+        if (mode == BHIP_AGG_PARTIAL) {
+            const int t = expr_type(a.arg, in);
+            if ((a.fn == BHIP_AGG_SUM || a.fn == BHIP_AGG_AVG) && (t == DT_UTF8 || t == DT_BOOLEAN))
+                fail(BHIP_EINVAL, std::string(agg_name(a.fn)) + " does not support " + dtype_name(t));
+            switch (a.fn) {
+                case BHIP_AGG_SUM: s->fields.push_back(Field{a.name + "[sum]", sum_type(t), true}); break;
+                case BHIP_AGG_AVG:
+                    s->fields.push_back(Field{a.name + "[count]", DT_UINT64, false});
+                    s->fields.push_back(Field{a.name + "[sum]", DT_FLOAT64, true});
+                    break;
+                case BHIP_AGG_COUNT: s->fields.push_back(Field{a.name + "[count]", DT_UINT64, false}); break;
+                case BHIP_AGG_MIN: s->fields.push_back(Field{a.name + "[min]", t, true}); break;
+                default: s->fields.push_back(Field{a.name + "[max]", t, true}); break;
+            }
+        } else {
+            const size_t need = a.fn == BHIP_AGG_AVG ? 2 : 1;
+            if (state_pos + need > in.fields.size()) fail(BHIP_EINVAL, "Final aggregate: input has too few state columns");
+            switch (a.fn) {
+                case BHIP_AGG_AVG: s->fields.push_back(Field{a.name, DT_FLOAT64, true}); break;
+                case BHIP_AGG_COUNT: s->fields.push_back(Field{a.name, DT_UINT64, false}); break;
+                default: s->fields.push_back(Field{a.name, in.fields[state_pos].dtype, true}); break;
+            }
+            state_pos += need;
+        }
+    }
+    schema_ = s;
+}
+
+PlanPtr HashAggregateExec::with_new_children(const std::vector<PlanPtr>& c) const {
+    if (c.size() != 1) fail(BHIP_EINVAL, "HashAggregateExec wrong number of children");
+    return std::make_shared<HashAggregateExec>(mode_, group_, aggr_, c[0]);
+}
+
+std::string HashAggregateExec::describe() const {
+    std::string s = std::string("HashAggregateExec: mode=") + (mode_ == BHIP_AGG_PARTIAL ? "Partial" : "Final") + ", gby=[";
+    for (size_t i = 0; i < group_.size(); ++i) s += (i ? ", " : "") + group_[i].first->to_string();
+    s += "], aggr=[";
+    for (size_t i = 0; i < aggr_.size(); ++i)
+        s += (i ? ", " : "") + std::string(agg_name(aggr_[i].fn)) + "(" + aggr_[i].arg->to_string() + ")";
+    return s + "]";
+}
+
+StreamPtr HashAggregateExec::execute(int partition, const Exec& ex) const {
+    check_partition(*this, partition);
+    auto self = std::static_pointer_cast<const HashAggregateExec>(shared_from_this());
+    return StreamPtr(new LazyStream(schema_, [self, partition, ex]() { return self->run(partition, ex); }));
+}
+
+namespace {
+
+struct EmitPlan {
+    EmitValueSpec spec;
+};
+
+struct FusedInput {
+    PlanPtr source;
+    ExprPtr predicate;                       // over source schema, may be null
+    std::vector<ExprPtr> group;              // over source schema
+    std::vector<ExprPtr> args;               // Partial: aggregate arguments; Final: unused
+};
+
+FusedInput fuse_below(const PlanPtr& input, std::vector<ExprPtr> group, std::vector<ExprPtr> args) {
+    FusedInput f;
+    f.source = input;
+    f.group = std::move(group);
+    f.args = std::move(args);
+    for (;;) {
+        if (auto* flt = dynamic_cast<const FilterExec*>(f.source.get())) {
+            f.predicate = f.predicate ? make_binary(flt->predicate(), "And", f.predicate) : flt->predicate();
+            f.source = flt->input();
+        } else if (auto* co = dynamic_cast<const CoalesceBatchesExec*>(f.source.get())) {
+            f.source = co->input();
+        } else if (auto* pr = dynamic_cast<const ProjectionExec*>(f.source.get())) {
+            std::map<std::string, ExprPtr> subst;
+            for (auto& en : pr->exprs()) subst[en.second] = en.first;
+            for (auto& g : f.group) g = substitute(g, subst);
+            for (auto& a : f.args) a = substitute(a, subst);
+            if (f.predicate) f.predicate = substitute(f.predicate, subst);
+            f.source = pr->input();
+        } else {
+            break;
+        }
+    }
+    return f;
+}
+
+struct TimedLaunches {
+    const Exec& ex;
+    bool on;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    explicit TimedLaunches(const Exec& e) : ex(e), on(e.ctx->timing_enabled()) {}
+    void begin() {
+        if (!on) return;
+        hipEvent_t a, b;
+        HIP_CHECK(hipEventCreate(&a));
+        HIP_CHECK(hipEventCreate(&b));
+        HIP_CHECK(hipEventRecord(a, ex.stream));
+        ev.push_back({a, b});
+    }
+    void end() {
+        if (on) HIP_CHECK(hipEventRecord(ev.back().second, ex.stream));
+    }
+    void collect() {   // call after the stream was synchronised
+        if (!on) return;
+        double ms = 0;
+        for (auto& p : ev) {
+            float t = 0;
+            if (hipEventElapsedTime(&t, p.first, p.second) == hipSuccess) ms += t;
+            hipEventDestroy(p.first);
+            hipEventDestroy(p.second);
+        }
+        ex.ctx->add_kernel_time(ms, ev.size());
+        ev.clear();
+    }
+};
+
+// high-cardinality path (device-wide hash table); filled in by ops_agg_hash.cpp
+GroupRec* hash_aggregate(const Exec& ex, Temp& tmp, const ScanParams& P0, const ProgramBuilder& pb,
+                         const std::vector<BatchPtr>& inputs, bool nullable, int64_t* n_groups, ScanStatus* status,
+                         TimedLaunches& timer) {
+    const LaunchCfg cfg = ex.cfg();
+    int64_t total_rows = 0;
+    for (auto& b : inputs) total_rows += b->n_rows;
+    if (total_rows > 0xFFFFFFF0ll) fail(BHIP_ENOTIMPL, "hash aggregate over more than 2^32 input rows per partition");
+    // capacity: power of two >= 2 x rows (every row could be its own group)
+    uint64_t cap = 1024;
+    while (cap < 2ull * (uint64_t)total_rows) cap <<= 1;
+    const int n_acc = P0.n_acc > 0 ? P0.n_acc : 1;
+    HashAggTable T;
+    memset(&T, 0, sizeof(T));
+    T.mask = cap - 1;
+    T.n_acc = P0.n_acc;
+    T.owner = tmp.get<uint32_t>(cap);
+    uint64_t* keys = tmp.get<uint64_t>(2 * (size_t)total_rows);
+    T.keys128 = keys;
+    T.acc = tmp.get<uint64_t>(cap * n_acc);
+    T.rows = tmp.get<uint64_t>(cap);
+    if (nullable) T.nvalid = tmp.get<uint64_t>(cap * n_acc);
+    HIP_CHECK(hipMemsetAsync(T.owner, 0, cap * 4, ex.stream));
+    HIP_CHECK(hipMemsetAsync(T.rows, 0, cap * 8, ex.stream));
+    if (nullable) HIP_CHECK(hipMemsetAsync(T.nvalid, 0, cap * n_acc * 8, ex.stream));
+    MergeAccKinds kinds;
+    for (int i = 0; i < VM_MAX_ACC; ++i) kinds.kind[i] = i < P0.n_acc ? P0.acc[i].kind : (uint8_t)ACC_COUNT_ROWS;
+    if (P0.n_acc > 0) HIP_CHECK(launch_hash_agg_init(cfg, T, kinds));
+    HIP_CHECK(hipMemsetAsync(status, 0, sizeof(ScanStatus), ex.stream));
+    uint32_t row_base = 0;
+    for (auto& b : inputs) {
+        ScanParams P = P0;
+        ProgramBuilder::bind(P, pb.columns(), *b, nullable);
+        HIP_CHECK(launch_scan_keys(cfg, P, keys + 2ull * row_base, nullptr, nullptr, status));
+        timer.begin();
+        HIP_CHECK(launch_scan_agg_hash(cfg, P, T, row_base, status));
+        timer.end();
+        row_base += (uint32_t)b->n_rows;
+    }
+    check_scan_status(ex, status);
+    timer.collect();
+    // used slots -> dense records (slot order: deterministic for a given input)
+    uint32_t* flags = tmp.get<uint32_t>(cap);
+    uint64_t* dense = tmp.get<uint64_t>(cap + 1);
+    uint64_t* total = tmp.get<uint64_t>(1);
+    void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes((int64_t)cap));
+    HIP_CHECK(launch_hash_agg_flags(cfg, T, flags));
+    HIP_CHECK(exclusive_scan_u32_u64(ex.stream, flags, (int64_t)cap, dense, false, total, scan_tmp));
+    const uint64_t ng = read_device(ex, total);
+    GroupRec* table = tmp.get<GroupRec>(ng ? ng : 1);
+    if (ng) HIP_CHECK(launch_hash_agg_compact(cfg, T, dense, nullable, table));
+    *n_groups = (int64_t)ng;
+    return table;
+}
+
+}  // namespace
+
+std::vector<BatchPtr> HashAggregateExec::run(int partition, const Exec& ex) const {
+    const Schema& in_schema = *input_->schema();
+    // ---- expressions over the (fused) source ---------------------------------------------------
+    std::vector<ExprPtr> group, args;
+    for (auto& g : group_) group.push_back(g.first);
+    if (mode_ == BHIP_AGG_PARTIAL) {
+        for (auto& a : aggr_) args.push_back(a.arg);
+    } else {
+        size_t pos = group_.size();
+        for (auto& a : aggr_) {
+            args.push_back(make_column(in_schema.fields[pos].name));
+            if (a.fn == BHIP_AGG_AVG) args.push_back(make_column(in_schema.fields[pos + 1].name));
+            pos += a.fn == BHIP_AGG_AVG ? 2 : 1;
+        }
+    }
+    FusedInput f = fuse_below(input_, group, args);
+    const Schema& src_schema = *f.source->schema();
+
+    ProgramBuilder pb(src_schema);
+    if (f.predicate) pb.set_predicate(f.predicate);
+    for (auto& g : f.group) pb.add_key(g);
+
+    std::vector<EmitValueSpec> emits;   // one per output state/value column
+    auto emit = [&](int kind, int a, int b, int dtype) { emits.push_back(EmitValueSpec{kind, a, b, 0, dtype}); };
+    size_t ai = 0;
+    for (auto& a : aggr_) {
+        if (mode_ == BHIP_AGG_PARTIAL) {
+            const ExprPtr& arg = f.args[ai++];
+            const int t = expr_type(arg, src_schema);
+            const bool lit_nonnull = arg->kind == BHIP_EXPR_LITERAL && !arg->is_null;
+            switch (a.fn) {
+                case BHIP_AGG_SUM: {
+                    Operand x = pb.compile(arg);
+                    const int acc = pb.add_acc(t == DT_FLOAT64 ? ACC_SUM_F64 : ACC_SUM_I64, x);
+                    emit(EMIT_VALUE, acc, 0, sum_type(t));
+                } break;
+                case BHIP_AGG_AVG: {
+                    ExprPtr farg = arg;
+                    if (t != DT_FLOAT64) {
+                        auto c = std::make_shared<Expr>();
+                        c->kind = BHIP_EXPR_CAST;
+                        c->dtype = DT_FLOAT64;
+                        c->args = {arg};
+                        farg = c;
+                    }
+                    Operand x = pb.compile(farg);
+                    const int acc = pb.add_acc(ACC_SUM_F64, x);
+                    emit(EMIT_COUNT, acc, 0, DT_UINT64);
+                    emit(EMIT_VALUE, acc, 0, DT_FLOAT64);
+                } break;
+                case BHIP_AGG_COUNT: {
+                    if (lit_nonnull || !expr_nullable(arg, src_schema)) { emit(EMIT_ROWS, 0, 0, DT_UINT64); break; }
+                    Operand x = pb.compile(arg);
+                    if (x.is_utf8_col) fail(BHIP_ENOTIMPL, "COUNT over a nullable Utf8 column");
+                    const int acc = pb.add_acc(x.vclass == VC_BOOL ? ACC_COUNT_VALID_B : ACC_COUNT_VALID, x);
+                    emit(EMIT_RAW, acc, 0, DT_UINT64);
+                } break;
+                default: {
+                    if (t == DT_UTF8 || t == DT_BOOLEAN) fail(BHIP_ENOTIMPL, "MIN/MAX over Utf8 or Boolean");
+                    Operand x = pb.compile(arg);
+                    const bool is_min = a.fn == BHIP_AGG_MIN;
+                    const int kind = t == DT_FLOAT64 ? (is_min ? ACC_MIN_F64 : ACC_MAX_F64) : (is_min ? ACC_MIN_I64 : ACC_MAX_I64);
+                    emit(EMIT_VALUE, pb.add_acc(kind, x), 0, t);
+                } break;
+            }
+        } else {
+            const ExprPtr& st0 = f.args[ai++];
+            const int t = expr_type(st0, src_schema);
+            switch (a.fn) {
+                case BHIP_AGG_SUM: {
+                    const int acc = pb.add_acc(t == DT_FLOAT64 ? ACC_SUM_F64 : ACC_SUM_I64, pb.compile(st0));
+                    emit(EMIT_VALUE, acc, 0, t);
+                } break;
+                case BHIP_AGG_AVG: {
+                    const ExprPtr& st1 = f.args[ai++];
+                    const int acc_c = pb.add_acc(ACC_SUM_I64, pb.compile(st0));
+                    const int acc_s = pb.add_acc(ACC_SUM_F64, pb.compile(st1));
+                    emit(EMIT_AVG_ACC, acc_s, acc_c, DT_FLOAT64);
+                } break;
+                case BHIP_AGG_COUNT: emit(EMIT_RAW, pb.add_acc(ACC_SUM_I64, pb.compile(st0)), 0, DT_UINT64); break;
+                default: {
+                    const bool is_min = a.fn == BHIP_AGG_MIN;
+                    const int kind = t == DT_FLOAT64 ? (is_min ? ACC_MIN_F64 : ACC_MAX_F64) : (is_min ? ACC_MIN_I64 : ACC_MAX_I64);
+                    emit(EMIT_VALUE, pb.add_acc(kind, pb.compile(st0)), 0, t);
+                } break;
+            }
+        }
+    }
+    ScanParams P0;
+    pb.finish(P0);
+    const int n_acc = P0.n_acc;
+
+    // ---- input ------------------------------------------------------------------------------------
+    std::vector<BatchPtr> inputs;
+    {
+        auto s = f.source->execute(partition, ex);
+        while (BatchPtr b = s->next())
+            if (b->n_rows > 0) inputs.push_back(b);
+    }
+    bool nullable = pb.creates_nulls();
+    for (auto& b : inputs)
+        for (int ci : pb.columns())
+            if (b->cols[ci].validity) nullable = true;
+
+    Temp tmp(ex);
+    const LaunchCfg cfg = ex.cfg();
+    ScanStatus* status = tmp.get<ScanStatus>(1);
+    GroupRec* table = nullptr;
+    int64_t n_groups = 0;
+    TimedLaunches timer(ex);
+
+    int gmax = group_.empty() ? 1 : 4;
+    const int hint = path_hint_.load();
+    if (hint == 8 || hint == -1) gmax = hint;
+    if (n_acc > AGG_NACC) gmax = -1;
+
+    while (!inputs.empty()) {
+        if (gmax == -1) {
+            // ---- hash path: one device-wide table, atomics ----------------------------------------
+            table = hash_aggregate(ex, tmp, P0, pb, inputs, nullable, &n_groups, status, timer);
+            break;
+        }
+        // ---- register path ----------------------------------------------------------------------
+        const int max_grid = scan_agg_lowcard_max_grid(cfg);
+        const size_t max_parts = inputs.size() * (size_t)max_grid;
+        GroupRec* partials = tmp.get<GroupRec>(max_parts * gmax);
+        uint32_t* partial_ng = tmp.get<uint32_t>(max_parts);
+        HIP_CHECK(hipMemsetAsync(status, 0, sizeof(ScanStatus), ex.stream));
+        int n_part = 0;
+        for (auto& b : inputs) {
+            ScanParams P = P0;
+            ProgramBuilder::bind(P, pb.columns(), *b, nullable);
+            int grid = 0;
+            timer.begin();
+            HIP_CHECK(launch_scan_agg_lowcard(cfg, P, gmax, partials + (size_t)n_part * gmax, partial_ng + n_part,
+                                              max_grid, status, &grid));
+            timer.end();
+            n_part += grid;
+        }
+        const int cap = 1024;
+        table = tmp.get<GroupRec>(cap);
+        uint32_t* entry_group = tmp.get<uint32_t>((size_t)n_part * gmax);
+        AccSpec specs[VM_MAX_ACC];
+        for (int i = 0; i < n_acc; ++i) specs[i] = P0.acc[i];
+        HIP_CHECK(launch_merge_partials(cfg, partials, partial_ng, n_part, gmax, specs, n_acc, table, cap, entry_group, status));
+        ScanStatus st;
+        check_scan_status(ex, status, &st);
+        timer.collect();
+        if (st.flags & SCAN_OVERFLOW_GROUPS) {
+            gmax = gmax == 4 ? 8 : -1;       // more groups than the register path holds: widen, then hash
+            path_hint_.store(gmax);
+            continue;
+        }
+        n_groups = st.n_groups;
+        break;
+    }
+
+    if (n_groups == 0 && group_.empty()) {
+        // no GROUP BY: exactly one output row even for empty input (SUM = NULL, COUNT = 0)
+        GroupRec id;
+        memset(&id, 0, sizeof(id));
+        for (int i = 0; i < n_acc; ++i) {
+            switch (P0.acc[i].kind) {
+                case ACC_MIN_F64: { double v = __builtin_huge_val(); memcpy(&id.acc[i], &v, 8); } break;
+                case ACC_MAX_F64: { double v = -__builtin_huge_val(); memcpy(&id.acc[i], &v, 8); } break;
+                case ACC_MIN_I64: id.acc[i] = (uint64_t)INT64_MAX; break;
+                case ACC_MAX_I64: id.acc[i] = (uint64_t)INT64_MIN; break;
+                default: break;
+            }
+        }
+        table = tmp.get<GroupRec>(1);
+        HIP_CHECK(hipMemcpyAsync(table, &id, sizeof(id), hipMemcpyHostToDevice, ex.stream));
+        HIP_CHECK(hipStreamSynchronize(ex.stream));
+        n_groups = 1;
+    }
+
+    // ---- group table -> output batch ------------------------------------------------------------
+    auto out = std::make_shared<Batch>();
+    out->schema = schema_;
+    out->ctx = ex.ctx;
+    out->n_rows = n_groups;
+    const auto& kinfo = pb.key_info();
+    for (size_t gi = 0; gi < group_.size(); ++gi) {
+        Column c;
+        c.dtype = schema_->fields[gi].dtype;
+        c.length = n_groups;
+        EmitKeySpec ks{kinfo[gi].pos, kinfo[gi].width, kinfo[gi].nullable, c.dtype};
+        if (kinfo[gi].nullable) c.validity = make_buffer(ex, bitmap_bytes(n_groups) + 8);
+        uint64_t* vptr = c.validity ? c.validity->as<uint64_t>() : nullptr;
+        if (c.dtype == DT_UTF8) {
+            uint32_t* lengths = tmp.get<uint32_t>((size_t)n_groups + 1);
+            c.offsets = make_buffer(ex, (size_t)(n_groups + 1) * 4);
+            uint64_t* total = tmp.get<uint64_t>(1);
+            void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes(n_groups));
+            if (n_groups) HIP_CHECK(launch_emit_group_key(cfg, table, n_groups, ks, nullptr, vptr, lengths));
+            HIP_CHECK(exclusive_scan_u32_i32(ex.stream, lengths, n_groups, c.offsets->as<int32_t>(), true, total, scan_tmp));
+            c.data_bytes = (int64_t)read_device(ex, total);
+            c.data = make_buffer(ex, (size_t)c.data_bytes + 8);
+            if (n_groups) HIP_CHECK(launch_emit_group_utf8(cfg, table, n_groups, ks, c.offsets->as<int32_t>(), c.data->as<uint8_t>()));
+        } else {
+            const size_t bytes = c.dtype == DT_BOOLEAN ? bitmap_bytes(n_groups) : (size_t)n_groups * dtype_width(c.dtype);
+            c.data = make_buffer(ex, bytes + 8);
+            if (n_groups) HIP_CHECK(launch_emit_group_key(cfg, table, n_groups, ks, c.data->ptr(), vptr, nullptr));
+        }
+        out->cols.push_back(std::move(c));
+    }
+    for (size_t k = 0; k < emits.size(); ++k) {
+        EmitValueSpec sp = emits[k];
+        sp.count_is_rows = nullable ? 0 : 1;
+        const Field& fld = schema_->fields[group_.size() + k];
+        Column c;
+        c.dtype = fld.dtype;
+        c.length = n_groups;
+        c.data = make_buffer(ex, (size_t)n_groups * dtype_width(c.dtype) + 8);
+        if (fld.nullable) c.validity = make_buffer(ex, bitmap_bytes(n_groups) + 8);
+        if (n_groups)
+            HIP_CHECK(launch_emit_group_value(cfg, table, n_groups, sp, c.data->ptr(), c.validity ? c.validity->as<uint64_t>() : nullptr));
+        out->cols.push_back(std::move(c));
+    }
+    HIP_CHECK(hipStreamSynchronize(ex.stream));
+    return {out};
+}
+
+}  // namespace bhip

@@ -1,0 +1,235 @@
+// ops_join.cpp — HashJoinExec (Inner / Left / Right), left = build side.
+//
+// Reference: HashJoinExec::try_new(left, right, on: &[(String, String)], join_type) built at
+// rust/core/src/serde/physical_plan/from_proto.rs:253-276 (join types :268-272, key pairs by
+// column NAME :256-260); the 4-argument constructor of that DataFusion revision is the
+// collect-left mode: every task drains the whole left child and probes it with one right
+// partition.  Output schema = left fields then right fields, a right key column
+// dropped when it has the same name as its left partner (Appendix A).  Row order unspecified.
+#include <mutex>
+
+#include "../util_kernels.h"
+#include "hash_kernels.h"
+#include "plan.hpp"
+
+namespace bhip {
+
+struct JoinBuildSide {
+    BatchPtr batch;                 // all left rows
+    BufferPtr keys, sel, owner, head, next;
+    JoinTable table;
+    bool has_sel = false;
+};
+
+static const char* join_name(int t) { return t == BHIP_JOIN_INNER ? "Inner" : (t == BHIP_JOIN_LEFT ? "Left" : "Right"); }
+
+HashJoinExec::HashJoinExec(PlanPtr left, PlanPtr right, std::vector<std::pair<std::string, std::string>> on, int join_type)
+    : left_(std::move(left)), right_(std::move(right)), on_(std::move(on)), join_type_(join_type) {
+    ctx_ = left_->context();
+    if (join_type < BHIP_JOIN_INNER || join_type > BHIP_JOIN_RIGHT) fail(BHIP_ENOTIMPL, "Unsupported join type");
+    const Schema& ls = *left_->schema();
+    const Schema& rs = *right_->schema();
+    for (auto& p : on_) {
+        const int li = ls.index_of(p.first), ri = rs.index_of(p.second);
+        if (li < 0) fail(BHIP_EINVAL, "The left side of the join does not have column '" + p.first + "'");
+        if (ri < 0) fail(BHIP_EINVAL, "The right side of the join does not have column '" + p.second + "'");
+        if (ls.fields[li].dtype != rs.fields[ri].dtype)
+            fail(BHIP_EINVAL, "join keys " + p.first + " / " + p.second + " have different types (" +
+                                  dtype_name(ls.fields[li].dtype) + " vs " + dtype_name(rs.fields[ri].dtype) + ")");
+    }
+    auto s = std::make_shared<Schema>();
+    for (auto f : ls.fields) {
+        if (join_type == BHIP_JOIN_RIGHT) f.nullable = true;
+        s->fields.push_back(f);
+    }
+    for (size_t i = 0; i < rs.fields.size(); ++i) {
+        bool drop = false;
+        for (auto& p : on_)
+            if (p.second == rs.fields[i].name && p.first == p.second) drop = true;
+        if (drop) continue;
+        Field f = rs.fields[i];
+        if (join_type == BHIP_JOIN_LEFT) f.nullable = true;
+        if (s->index_of(f.name) >= 0) fail(BHIP_EINVAL, "join output would have two columns named '" + f.name + "'");
+        s->fields.push_back(f);
+        right_cols_.push_back((int)i);
+    }
+    schema_ = s;
+    // key layout must be valid (surfaces BHIP_ENOTIMPL at plan time)
+    ProgramBuilder pb(ls);
+    for (auto& p : on_) pb.add_key(make_column(p.first), true);
+    ScanParams P;
+    pb.finish(P);
+    cache_ = std::make_shared<BuildCache>();
+}
+
+PlanPtr HashJoinExec::with_new_children(const std::vector<PlanPtr>& c) const {
+    if (c.size() != 2) fail(BHIP_EINVAL, "HashJoinExec wrong number of children");
+    return std::make_shared<HashJoinExec>(c[0], c[1], on_, join_type_);
+}
+
+std::string HashJoinExec::describe() const {
+    std::string s = std::string("HashJoinExec: mode=CollectLeft, join_type=") + join_name(join_type_) + ", on=[";
+    for (size_t i = 0; i < on_.size(); ++i) s += (i ? ", " : "") + std::string("(") + on_[i].first + ", " + on_[i].second + ")";
+    return s + "]";
+}
+
+// packed keys (+ "no NULL key" selection) of one side
+static void side_keys(const Exec& ex, const Batch& b, const std::vector<std::string>& cols, BufferPtr& keys, BufferPtr& sel,
+                      bool& has_sel) {
+    ProgramBuilder pb(*b.schema);
+    ExprPtr pred;
+    for (auto& c : cols) {
+        const int ci = b.schema->index_of(c);
+        if (b.schema->fields[ci].nullable || b.cols[ci].validity) {
+            auto e = std::make_shared<Expr>();
+            e->kind = BHIP_EXPR_IS_NOT_NULL;
+            e->args = {make_column(c)};
+            pred = pred ? make_binary(pred, "And", e) : ExprPtr(e);
+        }
+    }
+    if (pred) pb.set_predicate(pred);
+    for (auto& c : cols) pb.add_key(make_column(c), true);
+    ScanParams P;
+    pb.finish(P);
+    ProgramBuilder::bind(P, pb.columns(), b, pb.creates_nulls());
+    keys = make_buffer(ex, (size_t)b.n_rows * 16 + 16);
+    has_sel = (bool)pred;
+    if (has_sel) sel = make_buffer(ex, bitmap_bytes(b.n_rows) + 8);
+    if (b.n_rows == 0) return;
+    Temp tmp(ex);
+    ScanStatus* st = tmp.get<ScanStatus>(1);
+    HIP_CHECK(hipMemsetAsync(st, 0, sizeof(ScanStatus), ex.stream));
+    HIP_CHECK(launch_scan_keys(ex.cfg(), P, keys->as<uint64_t>(), nullptr, has_sel ? sel->as<uint64_t>() : nullptr, st));
+    check_scan_status(ex, st);
+}
+
+std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) const {
+    std::lock_guard<std::mutex> g(cache_->mu);
+    if (cache_->built) return cache_->built;
+    auto bs = std::make_shared<JoinBuildSide>();
+    std::vector<BatchPtr> parts;
+    const int np = left_->output_partitioning().count;
+    for (int p = 0; p < np; ++p) {
+        auto s = left_->execute(p, ex);
+        while (BatchPtr b = s->next())
+            if (b->n_rows > 0) parts.push_back(b);
+    }
+    if (parts.empty()) {
+        auto e = std::make_shared<Batch>();
+        e->schema = left_->schema();
+        e->ctx = ex.ctx;
+        for (auto& f : e->schema->fields) {
+            Column c;
+            c.dtype = f.dtype;
+            c.data = make_buffer(ex, 8);
+            if (f.dtype == DT_UTF8) { c.offsets = make_buffer(ex, 8); HIP_CHECK(hipMemsetAsync(c.offsets->ptr(), 0, 8, ex.stream)); }
+            e->cols.push_back(c);
+        }
+        bs->batch = e;
+    } else {
+        bs->batch = concat_batches(ex, left_->schema(), parts);
+    }
+    const int64_t n = bs->batch->n_rows;
+    std::vector<std::string> lcols;
+    for (auto& p : on_) lcols.push_back(p.first);
+    side_keys(ex, *bs->batch, lcols, bs->keys, bs->sel, bs->has_sel);
+    uint64_t cap = 1024;
+    while (cap < 2ull * (uint64_t)n) cap <<= 1;
+    bs->owner = make_buffer(ex, cap * 4);
+    bs->head = make_buffer(ex, cap * 4);
+    bs->next = make_buffer(ex, (size_t)(n + 1) * 4);
+    HIP_CHECK(hipMemsetAsync(bs->owner->ptr(), 0, cap * 4, ex.stream));
+    HIP_CHECK(hipMemsetAsync(bs->head->ptr(), 0, cap * 4, ex.stream));
+    bs->table.owner = bs->owner->as<uint32_t>();
+    bs->table.head = bs->head->as<uint32_t>();
+    bs->table.next = bs->next->as<uint32_t>();
+    bs->table.mask = cap - 1;
+    bs->table.keys128 = bs->keys->as<uint64_t>();
+    HIP_CHECK(launch_join_build(ex.cfg(), bs->table, bs->has_sel ? bs->sel->as<uint64_t>() : nullptr, (uint32_t)n));
+    // other tasks (other HIP streams) will read the table: it must be complete before it is published
+    HIP_CHECK(hipStreamSynchronize(ex.stream));
+    cache_->built = bs;
+    return bs;
+}
+
+StreamPtr HashJoinExec::execute(int partition, const Exec& ex) const {
+    check_partition(*this, partition);
+    auto self = std::static_pointer_cast<const HashJoinExec>(shared_from_this());
+    return StreamPtr(new LazyStream(schema_, [self, partition, ex]() {
+        std::vector<BatchPtr> out;
+        auto bs = self->build_side(ex);
+        const Batch& L = *bs->batch;
+        const int64_t n_left = L.n_rows;
+        const bool right_outer = self->join_type_ == BHIP_JOIN_RIGHT;
+        const bool left_outer = self->join_type_ == BHIP_JOIN_LEFT;
+        const LaunchCfg cfg = ex.cfg();
+        BufferPtr matched;
+        if (left_outer) {
+            matched = make_buffer(ex, (size_t)(n_left / 32 + 2) * 4);
+            HIP_CHECK(hipMemsetAsync(matched->ptr(), 0, (size_t)(n_left / 32 + 2) * 4, ex.stream));
+        }
+        std::vector<std::string> rcols;
+        for (auto& p : self->on_) rcols.push_back(p.second);
+
+        auto emit = [&](const Batch* R, const uint32_t* lidx, const uint32_t* ridx, int64_t n_out) {
+            auto b = std::make_shared<Batch>();
+            b->schema = self->schema_;
+            b->ctx = ex.ctx;
+            b->n_rows = n_out;
+            for (auto& c : L.cols) b->cols.push_back(right_outer ? take_column_nullable(ex, c, lidx, n_out)
+                                                                  : take_batch_column(ex, c, lidx, n_out));
+            for (int ci : self->right_cols_) {
+                if (R) b->cols.push_back(left_outer ? take_column_nullable(ex, R->cols[ci], ridx, n_out)
+                                                    : take_batch_column(ex, R->cols[ci], ridx, n_out));
+                else b->cols.push_back(null_column(ex, self->right_->schema()->fields[ci].dtype, n_out));
+            }
+            out.push_back(b);
+        };
+
+        auto rs = self->right_->execute(partition, ex);
+        while (BatchPtr rb = rs->next()) {
+            const int64_t n_right = rb->n_rows;
+            if (n_right == 0) continue;
+            BufferPtr rkeys, rsel;
+            bool has_rsel = false;
+            side_keys(ex, *rb, rcols, rkeys, rsel, has_rsel);
+            Temp tmp(ex);
+            uint32_t* counts = tmp.get<uint32_t>((size_t)n_right + 1);
+            uint64_t* offsets = tmp.get<uint64_t>((size_t)n_right + 1);
+            uint64_t* total = tmp.get<uint64_t>(1);
+            void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes(n_right));
+            const uint64_t* rselp = has_rsel ? rsel->as<uint64_t>() : nullptr;
+            HIP_CHECK(launch_join_probe_count(cfg, bs->table, rkeys->as<uint64_t>(), rselp, (uint32_t)n_right, right_outer, counts));
+            HIP_CHECK(exclusive_scan_u32_u64(ex.stream, counts, n_right, offsets, false, total, scan_tmp));
+            const uint64_t n_out = read_device(ex, total);
+            if (n_out > 0xFFFFFFF0ull) fail(BHIP_EEXEC, "join output of one probe batch exceeds 2^32 rows");
+            if (n_out == 0) continue;
+            uint32_t* lidx = tmp.get<uint32_t>((size_t)n_out);
+            uint32_t* ridx = tmp.get<uint32_t>((size_t)n_out);
+            HIP_CHECK(launch_join_probe_emit(cfg, bs->table, rkeys->as<uint64_t>(), rselp, (uint32_t)n_right, right_outer, offsets,
+                                             lidx, ridx, left_outer ? matched->as<uint32_t>() : nullptr));
+            emit(rb.get(), lidx, ridx, (int64_t)n_out);
+            HIP_CHECK(hipStreamSynchronize(ex.stream));   // index scratch is released at the end of the iteration
+        }
+        if (left_outer && n_left > 0) {
+            // left rows no probe row matched: right columns NULL
+            Temp tmp(ex);
+            uint32_t* flags = tmp.get<uint32_t>((size_t)n_left + 1);
+            uint64_t* offsets = tmp.get<uint64_t>((size_t)n_left + 1);
+            uint64_t* total = tmp.get<uint64_t>(1);
+            void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes(n_left));
+            HIP_CHECK(launch_join_unmatched_flags(cfg, matched->as<uint32_t>(), (uint32_t)n_left, flags));
+            HIP_CHECK(exclusive_scan_u32_u64(ex.stream, flags, n_left, offsets, false, total, scan_tmp));
+            const uint64_t n_un = read_device(ex, total);
+            if (n_un) {
+                uint32_t* lidx = tmp.get<uint32_t>((size_t)n_un);
+                HIP_CHECK(launch_compact_flags(cfg, flags, offsets, (uint32_t)n_left, lidx));
+                emit(nullptr, lidx, nullptr, (int64_t)n_un);
+                HIP_CHECK(hipStreamSynchronize(ex.stream));
+            }
+        }
+        return out;
+    }));
+}
+
+}  // namespace bhip

@@ -1,0 +1,203 @@
+// ops_sort.cpp — SortExec and RepartitionExec over the stable radix pass (kernels_sort.hip).
+//
+// SortExec: rust/core/src/serde/physical_plan/from_proto.rs:291-331 — single input partition, all
+// rows, lexicographic over PhysicalSortExpr{expr, descending, nulls_first}.  Implemented as LSD
+// over the sort keys (last key first), each key an order-preserving u64 image (Utf8: 8-byte
+// big-endian chunks, then the length), NULL placement as one more 1-bit key.  Ties keep input
+// order (the reference leaves tie order unspecified).
+//
+// RepartitionExec: from_proto.rs:133-164 — Hash(exprs, n): row -> partition row_hash % n (equal
+// keys co-locate; rows keep their input order inside a partition); RoundRobinBatch(n): batch i ->
+// partition i mod n.
+#include "../sort_kernels.h"
+#include "../util_kernels.h"
+#include "plan.hpp"
+
+namespace bhip {
+
+void radix_sort_pairs(const Exec& ex, BufferPtr& keys, BufferPtr& perm, int64_t n) {
+    if (n <= 1) return;
+    const LaunchCfg cfg = ex.cfg();
+    Temp tmp(ex);
+    uint64_t* diff_dev = tmp.get<uint64_t>(1);
+    HIP_CHECK(radix_key_diff(cfg, keys->as<uint64_t>(), n, diff_dev));
+    const uint64_t diff = read_device(ex, diff_dev);
+    if (diff == 0) return;   // all keys equal: already in order
+    BufferPtr keys2 = make_buffer(ex, (size_t)n * 8 + 8), perm2 = make_buffer(ex, (size_t)n * 4 + 8);
+    void* pass_tmp = tmp.get<uint8_t>(radix_sort_temp_bytes(n));
+    for (int byte = 0; byte < 8; ++byte) {
+        if (((diff >> (8 * byte)) & 0xFF) == 0) continue;   // this byte is the same in every key
+        HIP_CHECK(radix_pass(cfg, keys->as<uint64_t>(), perm->as<uint32_t>(), n, byte, keys2->as<uint64_t>(),
+                             perm2->as<uint32_t>(), pass_tmp));
+        std::swap(keys, keys2);
+        std::swap(perm, perm2);
+    }
+}
+
+// ---- SortExec ---------------------------------------------------------------------------------------
+SortExec::SortExec(std::vector<SortDesc> exprs, PlanPtr input) : exprs_(std::move(exprs)) {
+    input_ = std::move(input);
+    ctx_ = input_->context();
+    for (auto& s : exprs_) {
+        const int t = expr_type(s.expr, *input_->schema());
+        if (t == DT_UTF8 && s.expr->kind != BHIP_EXPR_COLUMN) fail(BHIP_ENOTIMPL, "sort key expression producing Utf8");
+    }
+}
+PlanPtr SortExec::with_new_children(const std::vector<PlanPtr>& c) const {
+    if (c.size() != 1) fail(BHIP_EINVAL, "SortExec wrong number of children");
+    return std::make_shared<SortExec>(exprs_, c[0]);
+}
+std::string SortExec::describe() const {
+    std::string s = "SortExec: [";
+    for (size_t i = 0; i < exprs_.size(); ++i)
+        s += (i ? ", " : "") + exprs_[i].expr->to_string() + (exprs_[i].descending ? " DESC" : " ASC") +
+             (exprs_[i].nulls_first ? " NULLS FIRST" : " NULLS LAST");
+    return s + "]";
+}
+
+StreamPtr SortExec::execute(int partition, const Exec& ex) const {
+    if (partition != 0) fail(BHIP_EINVAL, "SortExec invalid partition " + std::to_string(partition));
+    if (input_->output_partitioning().count != 1) fail(BHIP_EINVAL, "SortExec requires a single input partition");
+    auto self = std::static_pointer_cast<const SortExec>(shared_from_this());
+    return StreamPtr(new LazyStream(schema(), [self, ex]() -> std::vector<BatchPtr> {
+        std::vector<BatchPtr> parts;
+        {
+            auto s = self->input_->execute(0, ex);
+            while (BatchPtr b = s->next())
+                if (b->n_rows > 0) parts.push_back(b);
+        }
+        if (parts.empty()) return {};
+        BatchPtr in = concat_batches(ex, self->schema(), parts);
+        const int64_t n = in->n_rows;
+        const LaunchCfg cfg = ex.cfg();
+        BufferPtr perm = make_buffer(ex, (size_t)n * 4 + 8);
+        BufferPtr keys = make_buffer(ex, (size_t)n * 8 + 8);
+        HIP_CHECK(launch_iota_u32(cfg, perm->as<uint32_t>(), n, 0));
+        for (size_t k = self->exprs_.size(); k-- > 0;) {
+            const SortDesc& sd = self->exprs_[k];
+            const Column col = evaluate_column(ex, *in, sd.expr);
+            const ColumnRef cr = col.ref();
+            if (col.dtype == DT_UTF8) {
+                Temp tmp(ex);
+                uint32_t* maxlen_dev = tmp.get<uint32_t>(1);
+                HIP_CHECK(launch_utf8_max_len(cfg, col.offsets->as<int32_t>(), n, maxlen_dev));
+                const uint32_t maxlen = read_device(ex, maxlen_dev);
+                // least significant first: the length, then the 8-byte chunks from the last to the first
+                HIP_CHECK(launch_sort_key_utf8(cfg, cr, perm->as<uint32_t>(), n, -1, sd.descending, keys->as<uint64_t>()));
+                radix_sort_pairs(ex, keys, perm, n);
+                for (int chunk = (int)((maxlen + 7) / 8) - 1; chunk >= 0; --chunk) {
+                    HIP_CHECK(launch_sort_key_utf8(cfg, cr, perm->as<uint32_t>(), n, chunk, sd.descending, keys->as<uint64_t>()));
+                    radix_sort_pairs(ex, keys, perm, n);
+                }
+            } else {
+                HIP_CHECK(launch_sort_key_fixed(cfg, cr, perm->as<uint32_t>(), n, sd.descending, keys->as<uint64_t>()));
+                radix_sort_pairs(ex, keys, perm, n);
+            }
+            if (col.validity) {
+                HIP_CHECK(launch_sort_key_null(cfg, col.validity->as<uint64_t>(), perm->as<uint32_t>(), n, sd.nulls_first,
+                                               keys->as<uint64_t>()));
+                radix_sort_pairs(ex, keys, perm, n);
+            }
+        }
+        BatchPtr out = take_batch(ex, *in, perm->as<uint32_t>(), n);
+        HIP_CHECK(hipStreamSynchronize(ex.stream));
+        return {out};
+    }));
+}
+
+// ---- hash partitioning ----------------------------------------------------------------------------------
+std::vector<BatchPtr> hash_partition_batch(const Exec& ex, const BatchPtr& in, const std::vector<ExprPtr>& exprs, int n_parts) {
+    const int64_t n = in->n_rows;
+    const LaunchCfg cfg = ex.cfg();
+    std::vector<BatchPtr> out((size_t)n_parts);
+    BufferPtr perm = make_buffer(ex, (size_t)n * 4 + 8);
+    std::vector<uint32_t> first((size_t)n_parts + 1, 0);
+    if (n > 0) {
+        ProgramBuilder pb(*in->schema);
+        pb.set_hash_only();
+        for (auto& e : exprs) pb.add_key(e);
+        ScanParams P;
+        pb.finish(P);
+        ProgramBuilder::bind(P, pb.columns(), *in, pb.creates_nulls());
+        Temp tmp(ex);
+        uint64_t* hashes = tmp.get<uint64_t>((size_t)n);
+        ScanStatus* st = tmp.get<ScanStatus>(1);
+        HIP_CHECK(hipMemsetAsync(st, 0, sizeof(ScanStatus), ex.stream));
+        HIP_CHECK(launch_scan_keys(cfg, P, nullptr, hashes, nullptr, st));
+        BufferPtr keys = make_buffer(ex, (size_t)n * 8 + 8);
+        HIP_CHECK(launch_hash_to_pid(cfg, hashes, n, (uint32_t)n_parts, keys->as<uint64_t>()));
+        HIP_CHECK(launch_iota_u32(cfg, perm->as<uint32_t>(), n, 0));
+        check_scan_status(ex, st);
+        radix_sort_pairs(ex, keys, perm, n);
+        uint32_t* first_dev = tmp.get<uint32_t>((size_t)n_parts + 1);
+        HIP_CHECK(launch_partition_bounds(cfg, keys->as<uint64_t>(), n, (uint32_t)n_parts, first_dev));
+        HIP_CHECK(hipMemcpyAsync(first.data(), first_dev, ((size_t)n_parts + 1) * 4, hipMemcpyDeviceToHost, ex.stream));
+        HIP_CHECK(hipStreamSynchronize(ex.stream));
+    }
+    for (int p = 0; p < n_parts; ++p) {
+        const int64_t cnt = (int64_t)first[p + 1] - (int64_t)first[p];
+        out[p] = take_batch(ex, *in, perm->as<uint32_t>() + first[p], cnt);
+    }
+    HIP_CHECK(hipStreamSynchronize(ex.stream));   // `perm` is released when this returns
+    return out;
+}
+
+// ---- RepartitionExec ----------------------------------------------------------------------------------------
+RepartitionExec::RepartitionExec(PlanPtr input, Partitioning part) : part_(std::move(part)) {
+    input_ = std::move(input);
+    ctx_ = input_->context();
+    if (part_.scheme == BHIP_PART_HASH) {
+        ProgramBuilder pb(*input_->schema());
+        pb.set_hash_only();
+        for (auto& e : part_.exprs) pb.add_key(e);   // type checks, BHIP_ENOTIMPL at plan time
+    }
+    cache_ = std::make_shared<SplitCache>();
+}
+PlanPtr RepartitionExec::with_new_children(const std::vector<PlanPtr>& c) const {
+    if (c.size() != 1) fail(BHIP_EINVAL, "RepartitionExec wrong number of children");
+    return std::make_shared<RepartitionExec>(c[0], part_);
+}
+std::string RepartitionExec::describe() const {
+    std::string s = "RepartitionExec: partitioning=";
+    if (part_.scheme == BHIP_PART_HASH) {
+        s += "Hash([";
+        for (size_t i = 0; i < part_.exprs.size(); ++i) s += (i ? ", " : "") + part_.exprs[i]->to_string();
+        s += "], " + std::to_string(part_.count) + ")";
+    } else {
+        s += (part_.scheme == BHIP_PART_ROUND_ROBIN ? "RoundRobinBatch(" : "UnknownPartitioning(") + std::to_string(part_.count) + ")";
+    }
+    return s;
+}
+
+StreamPtr RepartitionExec::execute(int partition, const Exec& ex) const {
+    check_partition(*this, partition);
+    auto self = std::static_pointer_cast<const RepartitionExec>(shared_from_this());
+    return StreamPtr(new LazyStream(schema(), [self, partition, ex]() {
+        std::lock_guard<std::mutex> g(self->cache_->mu);
+        if (!self->cache_->done) {
+            // the first task to arrive splits every input partition; the others take their share
+            auto& parts = self->cache_->parts;
+            parts.assign((size_t)self->part_.count, {});
+            const int n_in = self->input_->output_partitioning().count;
+            int64_t batch_no = 0;
+            for (int p = 0; p < n_in; ++p) {
+                auto s = self->input_->execute(p, ex);
+                while (BatchPtr b = s->next()) {
+                    if (self->part_.scheme == BHIP_PART_HASH) {
+                        auto split = hash_partition_batch(ex, b, self->part_.exprs, self->part_.count);
+                        for (int q = 0; q < self->part_.count; ++q)
+                            if (split[q]->n_rows > 0) parts[q].push_back(split[q]);
+                    } else {
+                        parts[(size_t)(batch_no % self->part_.count)].push_back(b);
+                    }
+                    ++batch_no;
+                }
+            }
+            HIP_CHECK(hipStreamSynchronize(ex.stream));
+            self->cache_->done = true;
+        }
+        return self->cache_->parts[(size_t)partition];
+    }));
+}
+
+}  // namespace bhip

@@ -1,0 +1,286 @@
+// plan.hpp — the operator tree: a C++ mirror of DataFusion's `ExecutionPlan` /
+// `RecordBatchStream` traits as the reference uses them.
+//
+//   trait ExecutionPlan { as_any, schema, output_partitioning, children, with_new_children,
+//                         async execute(partition) -> stream }
+//       rust/core/src/execution_plans/query_stage.rs:49-85 (in-tree implementation showing every method)
+//   trait RecordBatchStream = Stream<Item = ArrowResult<RecordBatch>> + schema()
+//       rust/core/src/memory_stream.rs:57-92
+//
+// One class per operator the physical-plan serde can build
+// (rust/core/src/serde/physical_plan/from_proto.rs:58-346).  `execute` fuses the
+// Filter / Projection / CoalesceBatches chain under a pipeline breaker into the breaker's scan
+// kernel, so those operators only run stand-alone when they are at the top of a stage.
+#pragma once
+#include <functional>
+#include <mutex>
+
+#include "core.hpp"
+#include "expr.hpp"
+
+namespace bhip {
+
+struct Partitioning {
+    int scheme = BHIP_PART_UNKNOWN;
+    int count = 1;
+    std::vector<ExprPtr> exprs;
+};
+
+class RecordBatchStream {
+public:
+    virtual ~RecordBatchStream() = default;
+    virtual SchemaPtr schema() const = 0;
+    virtual BatchPtr next() = 0;   // nullptr = end of stream
+};
+using StreamPtr = std::unique_ptr<RecordBatchStream>;
+
+class ExecutionPlan;
+using PlanPtr = std::shared_ptr<const ExecutionPlan>;
+
+class ExecutionPlan : public std::enable_shared_from_this<ExecutionPlan> {
+public:
+    virtual ~ExecutionPlan() = default;
+    virtual const char* name() const = 0;                                   // as_any()
+    virtual SchemaPtr schema() const = 0;
+    virtual Partitioning output_partitioning() const = 0;
+    virtual std::vector<PlanPtr> children() const = 0;
+    virtual PlanPtr with_new_children(const std::vector<PlanPtr>& children) const = 0;
+    virtual StreamPtr execute(int partition, const Exec& ex) const = 0;
+    virtual std::string describe() const { return name(); }                 // fmt::Debug one-liner
+    ContextPtr context() const { return ctx_; }
+protected:
+    ContextPtr ctx_;
+};
+
+std::string display_plan(const PlanPtr& p);
+void check_partition(const ExecutionPlan& p, int partition);
+std::vector<BatchPtr> drain(RecordBatchStream& s);
+
+// ---- streams -----------------------------------------------------------------------------------
+class VecStream : public RecordBatchStream {   // MemoryStream (memory_stream.rs:29-55)
+public:
+    VecStream(SchemaPtr s, std::vector<BatchPtr> b) : schema_(std::move(s)), batches_(std::move(b)) {}
+    SchemaPtr schema() const override { return schema_; }
+    BatchPtr next() override { return pos_ < batches_.size() ? batches_[pos_++] : nullptr; }
+private:
+    SchemaPtr schema_;
+    std::vector<BatchPtr> batches_;
+    size_t pos_ = 0;
+};
+
+// computes its batches on first pull
+class LazyStream : public RecordBatchStream {
+public:
+    LazyStream(SchemaPtr s, std::function<std::vector<BatchPtr>()> f) : schema_(std::move(s)), fn_(std::move(f)) {}
+    SchemaPtr schema() const override { return schema_; }
+    BatchPtr next() override {
+        if (!ran_) { batches_ = fn_(); ran_ = true; }
+        return pos_ < batches_.size() ? batches_[pos_++] : nullptr;
+    }
+private:
+    SchemaPtr schema_;
+    std::function<std::vector<BatchPtr>()> fn_;
+    std::vector<BatchPtr> batches_;
+    bool ran_ = false;
+    size_t pos_ = 0;
+};
+
+// ---- operators ---------------------------------------------------------------------------------
+class MemoryExec : public ExecutionPlan {
+public:
+    MemoryExec(ContextPtr ctx, SchemaPtr schema, std::vector<std::vector<BatchPtr>> partitions);
+    const char* name() const override { return "MemoryExec"; }
+    SchemaPtr schema() const override { return schema_; }
+    Partitioning output_partitioning() const override { return Partitioning{BHIP_PART_UNKNOWN, (int)parts_.size(), {}}; }
+    std::vector<PlanPtr> children() const override { return {}; }
+    PlanPtr with_new_children(const std::vector<PlanPtr>& c) const override;
+    StreamPtr execute(int partition, const Exec& ex) const override;
+    const std::vector<std::vector<BatchPtr>>& partitions() const { return parts_; }
+private:
+    SchemaPtr schema_;
+    std::vector<std::vector<BatchPtr>> parts_;
+};
+
+class EmptyExec : public ExecutionPlan {
+public:
+    EmptyExec(ContextPtr ctx, SchemaPtr schema, bool produce_one_row);
+    const char* name() const override { return "EmptyExec"; }
+    SchemaPtr schema() const override { return schema_; }
+    Partitioning output_partitioning() const override { return Partitioning{BHIP_PART_UNKNOWN, 1, {}}; }
+    std::vector<PlanPtr> children() const override { return {}; }
+    PlanPtr with_new_children(const std::vector<PlanPtr>& c) const override;
+    StreamPtr execute(int partition, const Exec& ex) const override;
+private:
+    SchemaPtr schema_;
+    bool one_row_;
+};
+
+class UnaryExec : public ExecutionPlan {
+public:
+    std::vector<PlanPtr> children() const override { return {input_}; }
+    Partitioning output_partitioning() const override { return input_->output_partitioning(); }
+    const PlanPtr& input() const { return input_; }
+protected:
+    PlanPtr input_;
+};
+
+class FilterExec : public UnaryExec {
+public:
+    FilterExec(ExprPtr predicate, PlanPtr input);
+    const char* name() const override { return "FilterExec"; }
+    SchemaPtr schema() const override { return input_->schema(); }
+    PlanPtr with_new_children(const std::vector<PlanPtr>& c) const override;
+    StreamPtr execute(int partition, const Exec& ex) const override;
+    std::string describe() const override { return "FilterExec: " + predicate_->to_string(); }
+    const ExprPtr& predicate() const { return predicate_; }
+private:
+    ExprPtr predicate_;
+};
+
+class ProjectionExec : public UnaryExec {
+public:
+    ProjectionExec(std::vector<std::pair<ExprPtr, std::string>> exprs, PlanPtr input);
+    const char* name() const override { return "ProjectionExec"; }
+    SchemaPtr schema() const override { return schema_; }
+    PlanPtr with_new_children(const std::vector<PlanPtr>& c) const override;
+    StreamPtr execute(int partition, const Exec& ex) const override;
+    std::string describe() const override;
+    const std::vector<std::pair<ExprPtr, std::string>>& exprs() const { return exprs_; }
+private:
+    std::vector<std::pair<ExprPtr, std::string>> exprs_;
+    SchemaPtr schema_;
+};
+
+class CoalesceBatchesExec : public UnaryExec {
+public:
+    CoalesceBatchesExec(PlanPtr input, int64_t target);
+    const char* name() const override { return "CoalesceBatchesExec"; }
+    SchemaPtr schema() const override { return input_->schema(); }
+    PlanPtr with_new_children(const std::vector<PlanPtr>& c) const override;
+    StreamPtr execute(int partition, const Exec& ex) const override;
+    std::string describe() const override { return "CoalesceBatchesExec: target_batch_size=" + std::to_string(target_); }
+private:
+    int64_t target_;
+};
+
+class MergeExec : public UnaryExec {
+public:
+    explicit MergeExec(PlanPtr input);
+    const char* name() const override { return "MergeExec"; }
+    SchemaPtr schema() const override { return input_->schema(); }
+    Partitioning output_partitioning() const override { return Partitioning{BHIP_PART_UNKNOWN, 1, {}}; }
+    PlanPtr with_new_children(const std::vector<PlanPtr>& c) const override;
+    StreamPtr execute(int partition, const Exec& ex) const override;
+};
+
+class LimitExec : public UnaryExec {     // GlobalLimitExec / LocalLimitExec
+public:
+    LimitExec(PlanPtr input, int64_t limit, bool global);
+    const char* name() const override { return global_ ? "GlobalLimitExec" : "LocalLimitExec"; }
+    SchemaPtr schema() const override { return input_->schema(); }
+    Partitioning output_partitioning() const override;
+    PlanPtr with_new_children(const std::vector<PlanPtr>& c) const override;
+    StreamPtr execute(int partition, const Exec& ex) const override;
+    std::string describe() const override { return std::string(name()) + ": limit=" + std::to_string(limit_); }
+private:
+    int64_t limit_;
+    bool global_;
+};
+
+class HashAggregateExec : public UnaryExec {
+public:
+    HashAggregateExec(int mode, std::vector<std::pair<ExprPtr, std::string>> group_exprs,
+                      std::vector<AggregateDesc> aggr, PlanPtr input);
+    const char* name() const override { return "HashAggregateExec"; }
+    SchemaPtr schema() const override { return schema_; }
+    PlanPtr with_new_children(const std::vector<PlanPtr>& c) const override;
+    StreamPtr execute(int partition, const Exec& ex) const override;
+    std::string describe() const override;
+private:
+    std::vector<BatchPtr> run(int partition, const Exec& ex) const;
+    int mode_;
+    std::vector<std::pair<ExprPtr, std::string>> group_;
+    std::vector<AggregateDesc> aggr_;
+    SchemaPtr schema_;
+    mutable std::atomic<int> path_hint_{0};    // 0 = unknown, 4/8 = register path with that many groups, -1 = hash path
+};
+
+struct JoinBuildSide;
+class HashJoinExec : public ExecutionPlan {
+public:
+    HashJoinExec(PlanPtr left, PlanPtr right, std::vector<std::pair<std::string, std::string>> on, int join_type);
+    const char* name() const override { return "HashJoinExec"; }
+    SchemaPtr schema() const override { return schema_; }
+    Partitioning output_partitioning() const override { return right_->output_partitioning(); }
+    std::vector<PlanPtr> children() const override { return {left_, right_}; }
+    PlanPtr with_new_children(const std::vector<PlanPtr>& c) const override;
+    StreamPtr execute(int partition, const Exec& ex) const override;
+    std::string describe() const override;
+private:
+    std::shared_ptr<const JoinBuildSide> build_side(const Exec& ex) const;
+    PlanPtr left_, right_;
+    std::vector<std::pair<std::string, std::string>> on_;
+    int join_type_;
+    SchemaPtr schema_;
+    std::vector<int> right_cols_;   // right columns kept in the output
+    // the build side (hash table over the whole left child) is built once and shared by every
+    // partition's task, like DataFusion's collect-left build future
+    struct BuildCache { std::mutex mu; std::shared_ptr<const JoinBuildSide> built; };
+    std::shared_ptr<BuildCache> cache_;
+};
+
+class SortExec : public UnaryExec {
+public:
+    SortExec(std::vector<SortDesc> exprs, PlanPtr input);
+    const char* name() const override { return "SortExec"; }
+    SchemaPtr schema() const override { return input_->schema(); }
+    Partitioning output_partitioning() const override { return Partitioning{BHIP_PART_UNKNOWN, 1, {}}; }
+    PlanPtr with_new_children(const std::vector<PlanPtr>& c) const override;
+    StreamPtr execute(int partition, const Exec& ex) const override;
+    std::string describe() const override;
+private:
+    std::vector<SortDesc> exprs_;
+};
+
+class RepartitionExec : public UnaryExec {
+public:
+    RepartitionExec(PlanPtr input, Partitioning part);
+    const char* name() const override { return "RepartitionExec"; }
+    SchemaPtr schema() const override { return input_->schema(); }
+    Partitioning output_partitioning() const override { return part_; }
+    PlanPtr with_new_children(const std::vector<PlanPtr>& c) const override;
+    StreamPtr execute(int partition, const Exec& ex) const override;
+    std::string describe() const override;
+private:
+    Partitioning part_;
+    // all output partitions are produced by the first execute() and handed out from here
+    struct SplitCache { std::mutex mu; bool done = false; std::vector<std::vector<BatchPtr>> parts; };
+    std::shared_ptr<SplitCache> cache_;
+};
+
+// shared helpers (ops_*.cpp)
+// evaluate `predicate` over `in` and return the surviving rows as ascending indices
+int64_t filter_indices(const Exec& ex, const Batch& in, const ExprPtr& predicate, BufferPtr& indices_out);
+// split a batch by hash(exprs) % n, keeping input order inside each part
+std::vector<BatchPtr> hash_partition_batch(const Exec& ex, const BatchPtr& in, const std::vector<ExprPtr>& exprs, int n);
+void check_scan_status(const Exec& ex, const ScanStatus* dev_status, ScanStatus* host_out = nullptr);
+// value of `e` over `in` as a column (a plain Column reference shares the input buffers)
+Column evaluate_column(const Exec& ex, const Batch& in, const ExprPtr& e);
+// gather of one column incl. its validity bitmap
+Column take_batch_column(const Exec& ex, const Column& c, const uint32_t* idx, int64_t n);
+// n NULLs of the given type
+Column null_column(const Exec& ex, int dtype, int64_t n);
+// gather where indices may hold 0xFFFFFFFF (= NULL row): always carries a validity bitmap
+Column take_column_nullable(const Exec& ex, const Column& c, const uint32_t* idx, int64_t n);
+// stable sort of (keys, perm) by the u64 keys; returns the buffers holding the sorted result
+void radix_sort_pairs(const Exec& ex, BufferPtr& keys, BufferPtr& perm, int64_t n);
+
+}  // namespace bhip
+
+struct bhip_plan { bhip::PlanPtr p; std::atomic<int> rc{1}; };
+struct bhip_stream {
+    bhip::StreamPtr s;
+    bhip::Exec ex;
+    std::vector<std::string> names;
+    ~bhip_stream() { if (ex.ctx && ex.stream) ex.ctx->release_stream(ex.stream); }
+};

@@ -1,0 +1,386 @@
+// kernels_agg.hip — fused scan + low-cardinality aggregate, and the merge of per-workgroup
+// partial states.
+//
+// Replaces the reference's FilterExec -> [CoalesceBatches] -> HashAggregateExec(Partial)
+// chain (operators built at rust/core/src/serde/physical_plan/from_proto.rs:81-92,122-128,
+// 173-252; executed from rust/executor/src/flight_service.rs:117-121) for group-bys with few
+// groups (TPC-H Q1: 4, Q6: 1, Q5: 5).  HBM traffic = each referenced input column read once
+// (coalesced, one row per lane) + a few KB of per-workgroup partial state => HBM-bound.
+//
+// Keys live in LDS, accumulators in registers (static indices; updates predicated on the
+// row's group id); lanes -> waves -> workgroup -> grid are reduced in a fixed order, so sums
+// are run-to-run deterministic.  A workgroup that meets more than GMAX groups raises
+// SCAN_OVERFLOW_GROUPS and the host re-runs the aggregate on the hash path.
+#include <hip/hip_runtime.h>
+#include "kernels.h"
+#include "vm_device.h"
+#include "reduce_device.h"
+#include "launch_common.h"
+
+namespace bhip {
+
+// =============================================================================================
+// Sink: low-cardinality aggregate
+// =============================================================================================
+template <int GMAX>
+struct AggLowCardArgs {
+    GroupRec* partials;      // [grid][GMAX]
+    uint32_t* partial_ng;    // [grid]
+    ScanStatus* status;
+};
+
+struct AggLds {
+    Key128 keys[AGG_GMAX];
+    uint32_t ng;
+    uint32_t winner;
+    uint32_t overflow;
+    uint32_t pad;
+    uint64_t red[4][AGG_GMAX * AGG_NACC];
+};
+
+template <int R, bool NULLS, int GMAX>
+__global__ void __launch_bounds__(BLOCK)
+scan_agg_lowcard_kernel(const ScanParams P, const AggLowCardArgs<GMAX> A) {
+    constexpr int TILE = BLOCK * R;
+    constexpr int NACC = AGG_NACC;
+    extern __shared__ __align__(16) uint8_t lds_raw[];
+    const TileLds L = carve_tile_lds<R, NULLS>(lds_raw, P.prog);
+    AggLds* S = reinterpret_cast<AggLds*>(lds_raw + tile_lds_bytes<R>(P.prog.n_vslots, P.prog.n_bslots, NULLS));
+    const int tid = threadIdx.x;
+
+    uint64_t acc[GMAX][NACC];
+    // without NULLS every accumulated input is known, so nvalid == rows
+    uint32_t nvalid[NULLS ? GMAX : 1][NULLS ? NACC : 1];
+    uint32_t rows[GMAX];
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g) {
+        rows[g] = 0;
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) {
+            acc[g][a] = (a < P.n_acc) ? acc_identity(P.acc[a].kind) : 0;
+            if (NULLS) nvalid[g][a] = 0;
+        }
+    }
+    if (tid == 0) { S->ng = 0; S->overflow = 0; S->winner = 0xFFFFFFFFu; }
+    __syncthreads();
+
+    uint32_t err = 0;
+    const int64_t n_tiles = (P.n_rows + TILE - 1) / TILE;
+    for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const int64_t base = t * TILE;
+        vm_load_tile<R, NULLS>(P, L, base);
+        vm_execute<R, NULLS>(P, L, base, err);
+
+        // ---- resolve each row's group among this workgroup's keys
+        int ng = S->ng;
+        Key128 gk[GMAX];
+#pragma unroll
+        for (int g = 0; g < GMAX; ++g) gk[g] = S->keys[g];
+        Key128 rk[R];
+        int lg[R];
+        bool pending = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int idx = r * BLOCK + tid;
+            bool live = (base + idx) < P.n_rows;
+            if (live && P.pred_slot >= 0) live = L.bvals[P.pred_slot * TILE + idx] & 1;
+            rk[r] = Key128{0, 0};
+            lg[r] = -1;
+            if (live) {
+                if (P.n_keyparts > 0) rk[r] = pack_key<R, NULLS>(P, L, base, r, err);
+                lg[r] = -2;   // live, group unknown
+#pragma unroll
+                for (int g = 0; g < GMAX; ++g)
+                    if (g < ng && rk[r] == gk[g]) lg[r] = g;
+                pending |= (lg[r] == -2);
+            }
+        }
+        // insertion rounds: rare (at most GMAX times per workgroup)
+        while (__syncthreads_or(pending ? 1 : 0)) {
+            if (pending) {
+                uint32_t mine = 0xFFFFFFFFu;
+#pragma unroll
+                for (int r = R - 1; r >= 0; --r)
+                    if (lg[r] == -2) mine = (uint32_t)(r * BLOCK + tid);
+                atomicMin(&S->winner, mine);
+            }
+            __syncthreads();
+            const uint32_t w = S->winner;
+            const int cur = S->ng;
+            __syncthreads();   // everyone has read (winner, ng) before the winner updates them
+            if (cur >= GMAX) {
+                if (tid == 0) S->overflow = 1;
+            } else if ((w % BLOCK) == (uint32_t)tid) {
+                Key128 wk{0, 0};
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if ((uint32_t)r == w / BLOCK) wk = rk[r];
+                S->keys[cur] = wk;
+                S->ng = cur + 1;
+            }
+            __syncthreads();
+            if (tid == 0) S->winner = 0xFFFFFFFFu;
+            if (S->overflow) break;
+            const Key128 nk = S->keys[cur];
+            pending = false;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (lg[r] == -2 && rk[r] == nk) lg[r] = cur;
+                pending |= (lg[r] == -2);
+            }
+        }
+        if (S->overflow) break;
+
+        // ---- accumulate (registers, static indices, predicated on the group id)
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int g = 0; g < GMAX; ++g)
+                if (lg[r] == g) rows[g] += 1;
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) {
+            if (a < P.n_acc) {
+                const AccSpec sp = P.acc[a];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (lg[r] < 0) continue;
+                    const int idx = r * BLOCK + tid;
+                    uint64_t v = 1;
+                    bool k = true;
+                    if (sp.kind == ACC_COUNT_VALID_B) {
+                        k = L.bvals[sp.slot * TILE + idx] >> 1;
+                    } else if (sp.kind != ACC_COUNT_ROWS) {
+                        v = L.vals[sp.slot * TILE + idx];
+                        if (NULLS) k = L.vvalid[sp.slot * TILE + idx];
+                    }
+                    if (sp.kind == ACC_COUNT_VALID || sp.kind == ACC_COUNT_VALID_B) { v = k ? 1 : 0; k = true; }
+                    if (!k) continue;
+#pragma unroll
+                    for (int g = 0; g < GMAX; ++g) {
+                        if (lg[r] == g) {
+                            acc[g][a] = acc_combine(acc[g][a], v, sp.kind);
+                            if (NULLS) nvalid[g][a] += 1;
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- workgroup reduction in a fixed order: lanes (xor-free shuffle tree) -> waves 0..3
+    const int wave = tid >> 6, lane = tid & 63;
+    __syncthreads();
+    const int ng = S->ng;
+    uint64_t tot_rows = 0, tot_acc = 0, tot_nv = 0;
+    // rows
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g) {
+        const uint64_t v = wave_reduce((uint64_t)rows[g], ACC_COUNT_ROWS);
+        if (lane == 0) S->red[wave][g] = v;
+    }
+    __syncthreads();
+    if (tid < GMAX) tot_rows = S->red[0][tid] + S->red[1][tid] + S->red[2][tid] + S->red[3][tid];
+    __syncthreads();
+    // accumulators
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g)
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) {
+            const int kind = (a < P.n_acc) ? P.acc[a].kind : ACC_COUNT_ROWS;
+            const uint64_t v = wave_reduce(acc[g][a], kind);
+            if (lane == 0) S->red[wave][g * NACC + a] = v;
+        }
+    __syncthreads();
+    if (tid < GMAX * NACC) {
+        const int a = tid % NACC;
+        const int kind = (a < P.n_acc) ? P.acc[a].kind : ACC_COUNT_ROWS;
+        tot_acc = S->red[0][tid];
+        tot_acc = acc_combine(tot_acc, S->red[1][tid], kind);
+        tot_acc = acc_combine(tot_acc, S->red[2][tid], kind);
+        tot_acc = acc_combine(tot_acc, S->red[3][tid], kind);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g)
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) {
+            const uint64_t v = wave_reduce(NULLS ? (uint64_t)nvalid[NULLS ? g : 0][NULLS ? a : 0] : (uint64_t)rows[g], ACC_COUNT_ROWS);
+            if (lane == 0) S->red[wave][g * NACC + a] = v;
+        }
+    __syncthreads();
+    if (tid < GMAX * NACC) tot_nv = S->red[0][tid] + S->red[1][tid] + S->red[2][tid] + S->red[3][tid];
+
+    GroupRec* out = A.partials + (size_t)blockIdx.x * GMAX;
+    if (tid < GMAX) {
+        out[tid].k0 = S->keys[tid].k0;
+        out[tid].k1 = S->keys[tid].k1;
+        out[tid].rows = tot_rows;
+    }
+    if (tid < GMAX * NACC) {
+        out[tid / NACC].acc[tid % NACC] = tot_acc;
+        out[tid / NACC].nvalid[tid % NACC] = tot_nv;
+    }
+    if (tid == 0) {
+        A.partial_ng[blockIdx.x] = (uint32_t)ng;
+        if (S->overflow) atomicOr(&A.status->flags, SCAN_OVERFLOW_GROUPS);
+    }
+    if (err) atomicOr(&A.status->flags, err);
+}
+
+// ---- merge of per-workgroup partials -------------------------------------------------------
+// Step 1 (one workgroup): give every partial record a group index in `table` (LDS hash of the
+// packed key; insertion in rounds separated by barriers, so compares only see finished keys).
+constexpr int MERGE_SLOTS = 2048;
+
+__global__ void __launch_bounds__(1024)
+merge_assign_kernel(const GroupRec* partials, const uint32_t* partial_ng, int n_part, int gmax,
+                    GroupRec* table, int cap, uint32_t* entry_group, ScanStatus* status) {
+    __shared__ Key128 skeys[MERGE_SLOTS];
+    __shared__ uint32_t sgroup[MERGE_SLOTS];   // 0 = empty, else group index + 1
+    __shared__ uint32_t s_ng, s_over;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < MERGE_SLOTS; i += blockDim.x) sgroup[i] = 0;
+    if (tid == 0) { s_ng = 0; s_over = 0; }
+    __syncthreads();
+    const int n_entries = n_part * gmax;
+    for (int e0 = 0; e0 < n_entries; e0 += blockDim.x) {
+        const int e = e0 + tid;
+        bool live = false;
+        Key128 k{0, 0};
+        if (e < n_entries) {
+            const int p = e / gmax, g = e % gmax;
+            live = (uint32_t)g < partial_ng[p];
+            if (live) k = Key128{partials[e].k0, partials[e].k1};
+            else entry_group[e] = 0xFFFFFFFFu;
+        }
+        uint32_t slot = (uint32_t)(hash_key(k) & (MERGE_SLOTS - 1));
+        bool pending = live;
+        // sgroup[slot]: 0 = empty, CLAIMED = being written this round, else group index + 1
+        constexpr uint32_t CLAIMED = 0xFFFFFFFFu;
+        while (__syncthreads_or(pending ? 1 : 0)) {
+            if (s_over) break;
+            if (pending) {
+                for (;;) {
+                    const uint32_t gidx = sgroup[slot];
+                    if (gidx == 0 || gidx == CLAIMED) break;   // CLAIMED: finished by the next round, look again then
+                    if (skeys[slot] == k) { entry_group[e] = gidx - 1; pending = false; break; }
+                    slot = (slot + 1) & (MERGE_SLOTS - 1);
+                }
+                if (pending && atomicCAS(&sgroup[slot], 0u, CLAIMED) == 0u) {
+                    const uint32_t gi = atomicAdd(&s_ng, 1u);
+                    if ((int)gi >= cap || gi >= MERGE_SLOTS / 2) {
+                        s_over = 1;
+                    } else {
+                        skeys[slot] = k;
+                        table[gi].k0 = k.k0;
+                        table[gi].k1 = k.k1;
+                        entry_group[e] = gi;
+                        __threadfence_block();
+                        sgroup[slot] = gi + 1;
+                    }
+                    pending = false;
+                }
+            }
+        }
+        if (s_over) break;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        status->n_groups = s_over ? 0 : s_ng;
+        if (s_over) atomicOr(&status->flags, SCAN_OVERFLOW_GROUPS);
+    }
+}
+
+// Step 2: one wave per (group, accumulator): lanes stride over the partial records in record
+// order, then a fixed shuffle tree => deterministic.
+struct MergeAccSpecs { AccSpec acc[VM_MAX_ACC]; int n_acc; };
+
+__global__ void __launch_bounds__(BLOCK)
+merge_reduce_kernel(const GroupRec* partials, const uint32_t* entry_group, int n_entries,
+                    MergeAccSpecs specs, GroupRec* table, const ScanStatus* status) {
+    const int n_groups = (int)status->n_groups;
+    const int per_group = specs.n_acc + 1;       // + rows
+    const int n_pairs = n_groups * per_group;
+    const int lane = threadIdx.x & 63;
+    const int wave_global = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    const int n_waves = gridDim.x * (BLOCK / 64);
+    for (int pair = wave_global; pair < n_pairs; pair += n_waves) {
+        const int g = pair / per_group, a = pair % per_group;
+        const bool is_rows = (a == specs.n_acc);
+        const int kind = is_rows ? (int)ACC_COUNT_ROWS : (int)specs.acc[a].kind;
+        uint64_t v = is_rows ? 0 : acc_identity(kind);
+        uint64_t nv = 0;
+        for (int e = lane; e < n_entries; e += 64) {
+            if (entry_group[e] == (uint32_t)g) {
+                if (is_rows) v += partials[e].rows;
+                else {
+                    v = acc_combine(v, partials[e].acc[a], kind);   // empty partials hold the identity
+                    nv += partials[e].nvalid[a];
+                }
+            }
+        }
+        v = wave_reduce(v, kind);
+        nv = wave_reduce(nv, ACC_COUNT_ROWS);
+        if (lane == 0) {
+            if (is_rows) table[g].rows = v;
+            else { table[g].acc[a] = v; table[g].nvalid[a] = nv; }
+        }
+    }
+}
+
+int scan_agg_lowcard_max_grid(const LaunchCfg& cfg) { return cfg.device_cus * 8; }
+
+template <int R, bool NULLS, int GMAX>
+static hipError_t launch_lowcard_t(const LaunchCfg& cfg, const ScanParams& P, GroupRec* partials, uint32_t* partial_ng,
+                                   int max_grid, ScanStatus* status, int* grid_out) {
+    constexpr int TILE = BLOCK * R;
+    const size_t lds = host_tile_bytes<R>(P.prog) + sizeof(AggLds);
+    const int64_t n_tiles = (P.n_rows + TILE - 1) / TILE;
+    int grid = pick_grid(cfg, n_tiles, lds, GMAX >= 8 ? 2 : 4);
+    if (grid > max_grid) grid = max_grid;
+    auto k = scan_agg_lowcard_kernel<R, NULLS, GMAX>;
+    hipError_t e = set_lds(k, lds);
+    if (e != hipSuccess) return e;
+    AggLowCardArgs<GMAX> A{partials, partial_ng, status};
+    hipLaunchKernelGGL(k, dim3(grid), dim3(BLOCK), lds, cfg.stream, P, A);
+    *grid_out = grid;
+    return hipGetLastError();
+}
+
+template <bool NULLS>
+static hipError_t launch_lowcard_n(const LaunchCfg& cfg, const ScanParams& P, int gmax, int r, GroupRec* partials,
+                                   uint32_t* partial_ng, int max_grid, ScanStatus* status, int* grid_out) {
+    // 8 groups x 8 accumulators take 128 VGPRs: that variant only exists with 2 rows per thread
+    if (gmax == 8) return launch_lowcard_t<2, NULLS, 8>(cfg, P, partials, partial_ng, max_grid, status, grid_out);
+    if (gmax == 4)
+        return r == 4 ? launch_lowcard_t<4, NULLS, 4>(cfg, P, partials, partial_ng, max_grid, status, grid_out)
+                      : launch_lowcard_t<2, NULLS, 4>(cfg, P, partials, partial_ng, max_grid, status, grid_out);
+    if (gmax == 1)
+        return r == 4 ? launch_lowcard_t<4, NULLS, 1>(cfg, P, partials, partial_ng, max_grid, status, grid_out)
+                      : launch_lowcard_t<2, NULLS, 1>(cfg, P, partials, partial_ng, max_grid, status, grid_out);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_scan_agg_lowcard(const LaunchCfg& cfg, const ScanParams& P, int gmax, GroupRec* partials,
+                                   uint32_t* partial_ng, int max_grid, ScanStatus* status, int* grid_out) {
+    const int r = choose_r(P.prog, sizeof(AggLds));
+    return P.prog.nullable ? launch_lowcard_n<true>(cfg, P, gmax, r, partials, partial_ng, max_grid, status, grid_out)
+                           : launch_lowcard_n<false>(cfg, P, gmax, r, partials, partial_ng, max_grid, status, grid_out);
+}
+
+hipError_t launch_merge_partials(const LaunchCfg& cfg, const GroupRec* partials, const uint32_t* partial_ng,
+                                 int n_part, int gmax, const AccSpec* acc_host, int n_acc, GroupRec* table, int cap,
+                                 uint32_t* entry_group, ScanStatus* status) {
+    hipLaunchKernelGGL(merge_assign_kernel, dim3(1), dim3(1024), 0, cfg.stream, partials, partial_ng, n_part, gmax,
+                       table, cap, entry_group, status);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    MergeAccSpecs specs;
+    specs.n_acc = n_acc;
+    for (int i = 0; i < VM_MAX_ACC; ++i) specs.acc[i] = i < n_acc ? acc_host[i] : AccSpec{ACC_COUNT_ROWS, 0, {0, 0}};
+    hipLaunchKernelGGL(merge_reduce_kernel, dim3(64), dim3(BLOCK), 0, cfg.stream, partials, entry_group,
+                       n_part * gmax, specs, table, status);
+    return hipGetLastError();
+}
+
+}  // namespace bhip

@@ -1,0 +1,286 @@
+// kernels_hash.hip — device-wide hash tables: high-cardinality HashAggregateExec and
+// HashJoinExec build / probe (rust/core/src/serde/physical_plan/from_proto.rs:173-276).
+//
+// Design (MI355X: 8 XCDs whose L2s are not coherent with each other, per-CU L1s never refreshed):
+// a slot is claimed by ONE 32-bit CAS that stores the claiming row's id; key equality is decided
+// by comparing against that row's packed key in a key array written by an EARLIER kernel
+// (scan_keys), so everything a prober reads besides the CAS word is immutable during the kernel —
+// no in-kernel release/acquire protocol, no stale-cache hazard.  Accumulators are only ever
+// touched by atomics (executed at the memory side).  Bound: random 16-B key reads + atomic traffic;
+// the algorithmic-bytes roofline deliberately does not credit it.
+#include <hip/hip_runtime.h>
+#include "host/hash_kernels.h"
+#include "launch_common.h"
+#include "reduce_device.h"
+#include "vm_device.h"
+
+namespace bhip {
+
+__device__ inline void atomic_acc(uint64_t* p, uint64_t v, int kind) {
+    switch (kind) {
+        case ACC_SUM_F64: unsafeAtomicAdd(reinterpret_cast<double*>(p), u2d(v)); break;
+        case ACC_MIN_F64: atomicMin(reinterpret_cast<double*>(p), u2d(v)); break;
+        case ACC_MAX_F64: atomicMax(reinterpret_cast<double*>(p), u2d(v)); break;
+        case ACC_MIN_I64: atomicMin(reinterpret_cast<long long*>(p), (long long)v); break;
+        case ACC_MAX_I64: atomicMax(reinterpret_cast<long long*>(p), (long long)v); break;
+        default: atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v); break;
+    }
+}
+
+// find (or claim) the slot of `key`; `row` = global id of the probing row (index into keys128)
+__device__ inline uint32_t table_upsert(uint32_t* owner, uint64_t mask, const uint64_t* keys128, const Key128& key,
+                                        uint32_t row) {
+    uint64_t slot = hash_key(key) & mask;
+    for (;;) {
+        uint32_t o = owner[slot];
+        if (o == 0) {
+            o = atomicCAS(&owner[slot], 0u, row + 1u);
+            if (o == 0) return (uint32_t)slot;       // claimed: this row's key defines the slot
+        }
+        const uint64_t* k = keys128 + 2ull * (o - 1u);
+        if (k[0] == key.k0 && k[1] == key.k1) return (uint32_t)slot;
+        slot = (slot + 1) & mask;
+    }
+}
+
+template <int R, bool NULLS>
+__global__ void __launch_bounds__(BLOCK)
+scan_agg_hash_kernel(const ScanParams P, const HashAggTable T, uint32_t row_base, ScanStatus* status) {
+    constexpr int TILE = BLOCK * R;
+    extern __shared__ __align__(16) uint8_t lds_raw[];
+    const TileLds L = carve_tile_lds<R, NULLS>(lds_raw, P.prog);
+    const int tid = threadIdx.x;
+    uint32_t err = 0;
+    const int64_t n_tiles = (P.n_rows + TILE - 1) / TILE;
+    for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const int64_t base = t * TILE;
+        vm_load_tile<R, NULLS>(P, L, base);
+        vm_execute<R, NULLS>(P, L, base, err);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int idx = r * BLOCK + tid;
+            const int64_t row = base + idx;
+            bool live = row < P.n_rows;
+            if (live && P.pred_slot >= 0) live = L.bvals[P.pred_slot * TILE + idx] & 1;
+            if (!live) continue;
+            const uint32_t grow = row_base + (uint32_t)row;
+            const Key128 key{T.keys128[2ull * grow], T.keys128[2ull * grow + 1]};
+            const uint32_t slot = table_upsert(T.owner, T.mask, T.keys128, key, grow);
+            atomicAdd(reinterpret_cast<unsigned long long*>(&T.rows[slot]), 1ull);
+            for (int a = 0; a < P.n_acc; ++a) {
+                const AccSpec sp = P.acc[a];
+                uint64_t v = 1;
+                bool k = true;
+                if (sp.kind == ACC_COUNT_VALID_B) k = L.bvals[sp.slot * TILE + idx] >> 1;
+                else if (sp.kind != ACC_COUNT_ROWS) {
+                    v = L.vals[sp.slot * TILE + idx];
+                    if (NULLS) k = L.vvalid[sp.slot * TILE + idx];
+                }
+                if (sp.kind == ACC_COUNT_VALID || sp.kind == ACC_COUNT_VALID_B) { v = k ? 1 : 0; k = true; }
+                if (!k) continue;
+                atomic_acc(&T.acc[(size_t)slot * T.n_acc + a], v, sp.kind);
+                if (NULLS) atomicAdd(reinterpret_cast<unsigned long long*>(&T.nvalid[(size_t)slot * T.n_acc + a]), 1ull);
+            }
+        }
+    }
+    if (err) atomicOr(&status->flags, err);
+}
+
+// accumulator identities (min/max) must be in place before the first atomic
+__global__ void __launch_bounds__(BLOCK)
+hash_agg_init_kernel(HashAggTable T, MergeAccKinds kinds) {
+    const size_t n = (size_t)(T.mask + 1) * T.n_acc;
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK)
+        T.acc[i] = acc_identity(kinds.kind[i % T.n_acc]);
+}
+
+// used slots -> flags (for the prefix sum), then dense GroupRec records
+__global__ void __launch_bounds__(BLOCK)
+hash_agg_flags_kernel(HashAggTable T, uint32_t* flags) {
+    const size_t n = (size_t)(T.mask + 1);
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK)
+        flags[i] = T.owner[i] != 0 ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(BLOCK)
+hash_agg_compact_kernel(HashAggTable T, const uint64_t* dense_index, int nulls, GroupRec* out) {
+    const size_t n = (size_t)(T.mask + 1);
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+        const uint32_t o = T.owner[i];
+        if (o == 0) continue;
+        GroupRec& g = out[dense_index[i]];
+        g.k0 = T.keys128[2ull * (o - 1u)];
+        g.k1 = T.keys128[2ull * (o - 1u) + 1];
+        g.rows = T.rows[i];
+        for (int a = 0; a < T.n_acc; ++a) {
+            g.acc[a] = T.acc[i * T.n_acc + a];
+            g.nvalid[a] = nulls ? T.nvalid[i * T.n_acc + a] : g.rows;
+        }
+    }
+}
+
+// =============================================================================================
+// HashJoinExec: build (left side) and probe (right side)
+// =============================================================================================
+__device__ inline bool bit_at(const uint64_t* bm, uint32_t i) { return bm == nullptr || ((bm[i >> 6] >> (i & 63)) & 1ull); }
+
+__global__ void __launch_bounds__(BLOCK)
+join_build_kernel(JoinTable T, const uint64_t* sel, uint32_t n_left) {
+    for (uint32_t row = blockIdx.x * BLOCK + threadIdx.x; row < n_left; row += gridDim.x * BLOCK) {
+        if (!bit_at(sel, row)) continue;                       // NULL keys never match
+        const Key128 key{T.keys128[2ull * row], T.keys128[2ull * row + 1]};
+        const uint32_t slot = table_upsert(T.owner, T.mask, T.keys128, key, row);
+        T.next[row] = atomicExch(&T.head[slot], row + 1u);     // push on the slot's chain
+    }
+}
+
+// slot holding `key`, or 0xFFFFFFFF (read-only: the table was finished by the build kernel)
+__device__ inline uint32_t table_find(const JoinTable& T, const Key128& key) {
+    uint64_t slot = hash_key(key) & T.mask;
+    for (;;) {
+        const uint32_t o = T.owner[slot];
+        if (o == 0) return 0xFFFFFFFFu;
+        const uint64_t* k = T.keys128 + 2ull * (o - 1u);
+        if (k[0] == key.k0 && k[1] == key.k1) return (uint32_t)slot;
+        slot = (slot + 1) & T.mask;
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK)
+join_probe_count_kernel(JoinTable T, const uint64_t* rkeys128, const uint64_t* rsel, uint32_t n_right, int right_outer,
+                        uint32_t* counts) {
+    for (uint32_t row = blockIdx.x * BLOCK + threadIdx.x; row < n_right; row += gridDim.x * BLOCK) {
+        uint32_t c = 0;
+        if (bit_at(rsel, row)) {
+            const Key128 key{rkeys128[2ull * row], rkeys128[2ull * row + 1]};
+            const uint32_t slot = table_find(T, key);
+            if (slot != 0xFFFFFFFFu)
+                for (uint32_t l = T.head[slot]; l != 0; l = T.next[l - 1u]) ++c;
+        }
+        counts[row] = (right_outer && c == 0) ? 1u : c;
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK)
+join_probe_emit_kernel(JoinTable T, const uint64_t* rkeys128, const uint64_t* rsel, uint32_t n_right, int right_outer,
+                       const uint64_t* offsets, uint32_t* left_idx, uint32_t* right_idx, uint32_t* matched) {
+    for (uint32_t row = blockIdx.x * BLOCK + threadIdx.x; row < n_right; row += gridDim.x * BLOCK) {
+        uint64_t pos = offsets[row];
+        uint32_t c = 0;
+        if (bit_at(rsel, row)) {
+            const Key128 key{rkeys128[2ull * row], rkeys128[2ull * row + 1]};
+            const uint32_t slot = table_find(T, key);
+            if (slot != 0xFFFFFFFFu)
+                for (uint32_t l = T.head[slot]; l != 0; l = T.next[l - 1u]) {
+                    left_idx[pos] = l - 1u;
+                    right_idx[pos] = row;
+                    if (matched) atomicOr(&matched[(l - 1u) >> 5], 1u << ((l - 1u) & 31));
+                    ++pos;
+                    ++c;
+                }
+        }
+        if (right_outer && c == 0) { left_idx[pos] = 0xFFFFFFFFu; right_idx[pos] = row; }
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK)
+join_unmatched_flags_kernel(const uint32_t* matched, uint32_t n_left, uint32_t* flags) {
+    for (uint32_t row = blockIdx.x * BLOCK + threadIdx.x; row < n_left; row += gridDim.x * BLOCK)
+        flags[row] = ((matched[row >> 5] >> (row & 31)) & 1u) ? 0u : 1u;
+}
+
+__global__ void __launch_bounds__(BLOCK)
+compact_flags_kernel(const uint32_t* flags, const uint64_t* offsets, uint32_t n, uint32_t* out) {
+    for (uint32_t row = blockIdx.x * BLOCK + threadIdx.x; row < n; row += gridDim.x * BLOCK)
+        if (flags[row]) out[offsets[row]] = row;
+}
+
+static int grid_rows(const LaunchCfg& cfg, size_t n) {
+    size_t g = (n + BLOCK - 1) / BLOCK;
+    const size_t cap = (size_t)cfg.device_cus * 16;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+hipError_t launch_join_build(const LaunchCfg& cfg, const JoinTable& T, const uint64_t* sel, uint32_t n_left) {
+    if (n_left == 0) return hipSuccess;
+    hipLaunchKernelGGL(join_build_kernel, dim3(grid_rows(cfg, n_left)), dim3(BLOCK), 0, cfg.stream, T, sel, n_left);
+    return hipGetLastError();
+}
+hipError_t launch_join_probe_count(const LaunchCfg& cfg, const JoinTable& T, const uint64_t* rkeys128, const uint64_t* rsel,
+                                   uint32_t n_right, bool right_outer, uint32_t* counts) {
+    if (n_right == 0) return hipSuccess;
+    hipLaunchKernelGGL(join_probe_count_kernel, dim3(grid_rows(cfg, n_right)), dim3(BLOCK), 0, cfg.stream, T, rkeys128, rsel,
+                       n_right, right_outer ? 1 : 0, counts);
+    return hipGetLastError();
+}
+hipError_t launch_join_probe_emit(const LaunchCfg& cfg, const JoinTable& T, const uint64_t* rkeys128, const uint64_t* rsel,
+                                  uint32_t n_right, bool right_outer, const uint64_t* offsets, uint32_t* left_idx,
+                                  uint32_t* right_idx, uint32_t* matched) {
+    if (n_right == 0) return hipSuccess;
+    hipLaunchKernelGGL(join_probe_emit_kernel, dim3(grid_rows(cfg, n_right)), dim3(BLOCK), 0, cfg.stream, T, rkeys128, rsel,
+                       n_right, right_outer ? 1 : 0, offsets, left_idx, right_idx, matched);
+    return hipGetLastError();
+}
+hipError_t launch_join_unmatched_flags(const LaunchCfg& cfg, const uint32_t* matched, uint32_t n_left, uint32_t* flags) {
+    if (n_left == 0) return hipSuccess;
+    hipLaunchKernelGGL(join_unmatched_flags_kernel, dim3(grid_rows(cfg, n_left)), dim3(BLOCK), 0, cfg.stream, matched, n_left, flags);
+    return hipGetLastError();
+}
+hipError_t launch_compact_flags(const LaunchCfg& cfg, const uint32_t* flags, const uint64_t* offsets, uint32_t n, uint32_t* out) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(compact_flags_kernel, dim3(grid_rows(cfg, n)), dim3(BLOCK), 0, cfg.stream, flags, offsets, n, out);
+    return hipGetLastError();
+}
+
+template <bool NULLS>
+static hipError_t launch_agg_hash_n(const LaunchCfg& cfg, const ScanParams& P, const HashAggTable& T, uint32_t row_base,
+                                    ScanStatus* status) {
+    const int r = choose_r(P.prog, 0);
+    const size_t lds = r == 4 ? host_tile_bytes<4>(P.prog) : host_tile_bytes<2>(P.prog);
+    const int64_t n_tiles = (P.n_rows + BLOCK * r - 1) / (BLOCK * r);
+    const int grid = pick_grid(cfg, n_tiles, lds, 4);
+    hipError_t e;
+    if (r == 4) {
+        auto k = scan_agg_hash_kernel<4, NULLS>;
+        if ((e = set_lds(k, lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(BLOCK), lds, cfg.stream, P, T, row_base, status);
+    } else {
+        auto k = scan_agg_hash_kernel<2, NULLS>;
+        if ((e = set_lds(k, lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(BLOCK), lds, cfg.stream, P, T, row_base, status);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_scan_agg_hash(const LaunchCfg& cfg, const ScanParams& P, const HashAggTable& T, uint32_t row_base,
+                                ScanStatus* status) {
+    return P.prog.nullable ? launch_agg_hash_n<true>(cfg, P, T, row_base, status)
+                           : launch_agg_hash_n<false>(cfg, P, T, row_base, status);
+}
+
+static int grid_n(const LaunchCfg& cfg, size_t n) {
+    size_t g = (n + BLOCK - 1) / BLOCK;
+    const size_t cap = (size_t)cfg.device_cus * 16;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+hipError_t launch_hash_agg_init(const LaunchCfg& cfg, const HashAggTable& T, const MergeAccKinds& kinds) {
+    hipLaunchKernelGGL(hash_agg_init_kernel, dim3(grid_n(cfg, (size_t)(T.mask + 1) * T.n_acc)), dim3(BLOCK), 0, cfg.stream, T, kinds);
+    return hipGetLastError();
+}
+hipError_t launch_hash_agg_flags(const LaunchCfg& cfg, const HashAggTable& T, uint32_t* flags) {
+    hipLaunchKernelGGL(hash_agg_flags_kernel, dim3(grid_n(cfg, (size_t)(T.mask + 1))), dim3(BLOCK), 0, cfg.stream, T, flags);
+    return hipGetLastError();
+}
+hipError_t launch_hash_agg_compact(const LaunchCfg& cfg, const HashAggTable& T, const uint64_t* dense_index, bool nulls,
+                                   GroupRec* out) {
+    hipLaunchKernelGGL(hash_agg_compact_kernel, dim3(grid_n(cfg, (size_t)(T.mask + 1))), dim3(BLOCK), 0, cfg.stream, T,
+                       dense_index, nulls ? 1 : 0, out);
+    return hipGetLastError();
+}
+
+}  // namespace bhip

@@ -1,0 +1,251 @@
+// kernels_sort.hip — stable LSD radix sort of (u64 key, u32 row id) pairs and the key
+// normalisation that turns SortExec's lexicographic multi-key order into unsigned integer order.
+//
+// SortExec (rust/core/src/serde/physical_plan/from_proto.rs:291-331) needs: all rows of the single
+// input partition, PhysicalSortExpr{expr, descending, nulls_first} per key.  The same stable pass
+// also implements RepartitionExec(Hash)'s split (key = partition id) and keeps input order inside
+// every partition.
+//
+// One 8-bit pass = histogram -> exclusive scan -> scatter.  Ranks inside a workgroup come from
+// wave64 ballots (8 ballots give the lanes holding the same digit), so the pass is stable without
+// any sorting network.  HBM traffic per pass: read keys+ids twice, write once (12 B x 3 per row);
+// passes whose byte is the same in every key are skipped (one OR-reduction per key tells).
+#include <hip/hip_runtime.h>
+#include "sort_kernels.h"
+#include "util_kernels.h"
+#include "vm_device.h"
+
+namespace bhip {
+
+constexpr int SORT_BLOCK = 256;
+constexpr int SORT_ITEMS = 16;                       // sub-tiles per chunk
+constexpr int SORT_CHUNK = SORT_BLOCK * SORT_ITEMS;  // 4096 rows per workgroup
+
+__global__ void __launch_bounds__(SORT_BLOCK)
+radix_hist_kernel(const uint64_t* keys, int64_t n, int shift, uint32_t* hist, int n_blocks) {
+    __shared__ uint32_t s_hist[256];
+    s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * SORT_CHUNK;
+#pragma unroll
+    for (int i = 0; i < SORT_ITEMS; ++i) {
+        const int64_t j = base + i * SORT_BLOCK + threadIdx.x;
+        if (j < n) atomicAdd(&s_hist[(keys[j] >> shift) & 0xFF], 1u);
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * n_blocks + blockIdx.x] = s_hist[threadIdx.x];   // digit-major
+}
+
+__global__ void __launch_bounds__(SORT_BLOCK)
+radix_scatter_kernel(const uint64_t* keys, const uint32_t* vals, int64_t n, int shift, const uint32_t* offsets,
+                     int n_blocks, uint64_t* keys_out, uint32_t* vals_out) {
+    __shared__ uint32_t s_base[256];            // next output position of each digit for this workgroup
+    __shared__ uint32_t s_wave[4][256];         // per-wave digit counts of the current sub-tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    s_base[tid] = offsets[(size_t)tid * n_blocks + blockIdx.x];
+    const int64_t base = (int64_t)blockIdx.x * SORT_CHUNK;
+    for (int i = 0; i < SORT_ITEMS; ++i) {
+        for (int w = 0; w < 4; ++w) s_wave[w][tid] = 0;
+        __syncthreads();
+        const int64_t j = base + i * SORT_BLOCK + tid;
+        const bool in = j < n;
+        uint64_t key = 0;
+        uint32_t val = 0;
+        uint32_t digit = 0;
+        if (in) { key = keys[j]; val = vals[j]; digit = (uint32_t)(key >> shift) & 0xFF; }
+        // lanes of this wave holding the same digit
+        uint64_t same = __ballot(in);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const uint64_t m = __ballot((digit >> b) & 1);
+            same &= ((digit >> b) & 1) ? m : ~m;
+        }
+        const uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        if (in && rank == 0) s_wave[wave][digit] = (uint32_t)__popcll(same);
+        __syncthreads();
+        if (in) {
+            uint32_t pos = s_base[digit] + rank;
+            for (int w = 0; w < wave; ++w) pos += s_wave[w][digit];
+            keys_out[pos] = key;
+            vals_out[pos] = val;
+        }
+        __syncthreads();
+        s_base[tid] += s_wave[0][tid] + s_wave[1][tid] + s_wave[2][tid] + s_wave[3][tid];
+        __syncthreads();
+    }
+}
+
+// OR over all keys of (key XOR first key): bits that differ somewhere
+__global__ void __launch_bounds__(SORT_BLOCK)
+key_diff_kernel(const uint64_t* keys, int64_t n, uint64_t* out) {
+    const uint64_t first = keys[0];
+    uint64_t acc = 0;
+    for (int64_t i = (int64_t)blockIdx.x * SORT_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * SORT_BLOCK)
+        acc |= keys[i] ^ first;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        uint32_t lo = __shfl_down((uint32_t)acc, d, 64), hi = __shfl_down((uint32_t)(acc >> 32), d, 64);
+        acc |= ((uint64_t)hi << 32) | lo;
+    }
+    if ((threadIdx.x & 63) == 0 && acc) atomicOr((unsigned long long*)out, (unsigned long long)acc);
+}
+
+size_t radix_sort_temp_bytes(int64_t n) {
+    const int64_t n_blocks = (n + SORT_CHUNK - 1) / SORT_CHUNK;
+    const size_t hist = (size_t)256 * (n_blocks > 0 ? n_blocks : 1) * 4;
+    return 2 * hist + exclusive_scan_temp_bytes(256 * n_blocks) + 64;
+}
+
+hipError_t radix_key_diff(const LaunchCfg& cfg, const uint64_t* keys, int64_t n, uint64_t* diff_out) {
+    hipError_t e = hipMemsetAsync(diff_out, 0, 8, cfg.stream);
+    if (e != hipSuccess || n == 0) return e;
+    int64_t g = (n + SORT_BLOCK - 1) / SORT_BLOCK;
+    if (g > (int64_t)cfg.device_cus * 8) g = (int64_t)cfg.device_cus * 8;
+    hipLaunchKernelGGL(key_diff_kernel, dim3((unsigned)g), dim3(SORT_BLOCK), 0, cfg.stream, keys, n, diff_out);
+    return hipGetLastError();
+}
+
+// one stable pass on byte `byte` of the keys: (keys, vals) -> (keys_out, vals_out)
+hipError_t radix_pass(const LaunchCfg& cfg, const uint64_t* keys, const uint32_t* vals, int64_t n, int byte,
+                      uint64_t* keys_out, uint32_t* vals_out, void* temp) {
+    if (n == 0) return hipSuccess;
+    const int n_blocks = (int)((n + SORT_CHUNK - 1) / SORT_CHUNK);
+    const size_t hist_elems = (size_t)256 * n_blocks;
+    uint32_t* hist = reinterpret_cast<uint32_t*>(temp);
+    uint32_t* offsets = hist + hist_elems;
+    void* scan_tmp = offsets + hist_elems + 4;
+    hipLaunchKernelGGL(radix_hist_kernel, dim3(n_blocks), dim3(SORT_BLOCK), 0, cfg.stream, keys, n, byte * 8, hist, n_blocks);
+    hipError_t e = exclusive_scan_u32_u32(cfg.stream, hist, (int64_t)hist_elems, offsets, false, nullptr, scan_tmp);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(radix_scatter_kernel, dim3(n_blocks), dim3(SORT_BLOCK), 0, cfg.stream, keys, vals, n, byte * 8,
+                       offsets, n_blocks, keys_out, vals_out);
+    return hipGetLastError();
+}
+
+// ---- key normalisation ---------------------------------------------------------------------------
+// out[i] = order-preserving u64 image of column value at row perm[i]
+__global__ void __launch_bounds__(SORT_BLOCK)
+sort_key_fixed_kernel(ColumnRef c, const uint32_t* perm, int64_t n, int descending, uint64_t* out) {
+    for (int64_t i = (int64_t)blockIdx.x * SORT_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * SORT_BLOCK) {
+        const uint32_t row = perm[i];
+        uint64_t k;
+        switch (c.dtype) {
+            case DT_INT32:
+            case DT_DATE32: k = (uint64_t)(int64_t) reinterpret_cast<const int32_t*>(c.data)[row] ^ 0x8000000000000000ull; break;
+            case DT_INT64: k = reinterpret_cast<const uint64_t*>(c.data)[row] ^ 0x8000000000000000ull; break;
+            case DT_UINT8: k = reinterpret_cast<const uint8_t*>(c.data)[row]; break;
+            case DT_UINT64: k = reinterpret_cast<const uint64_t*>(c.data)[row]; break;
+            case DT_BOOLEAN: k = (reinterpret_cast<const uint8_t*>(c.data)[row >> 3] >> (row & 7)) & 1u; break;
+            default: {   // Float64: total order by sign-magnitude flip
+                const uint64_t b = reinterpret_cast<const uint64_t*>(c.data)[row];
+                k = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+            } break;
+        }
+        if (c.validity != nullptr && !((c.validity[row >> 6] >> (row & 63)) & 1ull)) k = 0;   // ties among NULLs
+        out[i] = descending ? ~k : k;
+    }
+}
+
+// Utf8: chunk `chunk` = bytes [8*chunk, 8*chunk+8) big-endian, zero padded; chunk == -1: the length
+__global__ void __launch_bounds__(SORT_BLOCK)
+sort_key_utf8_kernel(ColumnRef c, const uint32_t* perm, int64_t n, int chunk, int descending, uint64_t* out) {
+    for (int64_t i = (int64_t)blockIdx.x * SORT_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * SORT_BLOCK) {
+        const uint32_t row = perm[i];
+        const int32_t o0 = c.offsets[row], len = c.offsets[row + 1] - o0;
+        uint64_t k = 0;
+        if (chunk < 0) k = (uint64_t)(uint32_t)len;
+        else {
+            const uint8_t* s = reinterpret_cast<const uint8_t*>(c.data) + o0;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const int p = chunk * 8 + b;
+                k = (k << 8) | (p < len ? s[p] : 0u);
+            }
+        }
+        if (c.validity != nullptr && !((c.validity[row >> 6] >> (row & 63)) & 1ull)) k = 0;
+        out[i] = descending ? ~k : k;
+    }
+}
+
+// null rank: nulls_first -> NULL = 0, valid = 1 ; nulls last -> NULL = 1, valid = 0
+__global__ void __launch_bounds__(SORT_BLOCK)
+sort_key_null_kernel(const uint64_t* validity, const uint32_t* perm, int64_t n, int nulls_first, uint64_t* out) {
+    for (int64_t i = (int64_t)blockIdx.x * SORT_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * SORT_BLOCK) {
+        const uint32_t row = perm[i];
+        const bool valid = (validity[row >> 6] >> (row & 63)) & 1ull;
+        out[i] = nulls_first ? (valid ? 1 : 0) : (valid ? 0 : 1);
+    }
+}
+
+__global__ void __launch_bounds__(SORT_BLOCK)
+utf8_max_len_kernel(const int32_t* offsets, int64_t n, uint32_t* out) {
+    uint32_t m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * SORT_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * SORT_BLOCK) {
+        const uint32_t len = (uint32_t)(offsets[i + 1] - offsets[i]);
+        m = len > m ? len : m;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_down(m, d, 64); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
+// partition id = hash % n  as a sort key
+__global__ void __launch_bounds__(SORT_BLOCK)
+hash_to_pid_kernel(const uint64_t* hashes, int64_t n, uint32_t n_parts, uint64_t* out) {
+    for (int64_t i = (int64_t)blockIdx.x * SORT_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * SORT_BLOCK)
+        out[i] = hashes[i] % n_parts;
+}
+
+// first[p] = first position whose (sorted) key is >= p, for p in [0, n_parts]
+__global__ void __launch_bounds__(SORT_BLOCK)
+partition_bounds_kernel(const uint64_t* sorted_keys, int64_t n, uint32_t n_parts, uint32_t* first) {
+    for (int64_t i = (int64_t)blockIdx.x * SORT_BLOCK + threadIdx.x; i <= n; i += (int64_t)gridDim.x * SORT_BLOCK) {
+        const uint64_t cur = i < n ? sorted_keys[i] : n_parts;
+        const uint64_t prev = i > 0 ? sorted_keys[i - 1] + 1 : 0;
+        for (uint64_t p = prev; p <= cur && p <= n_parts; ++p) first[p] = (uint32_t)i;
+    }
+}
+
+static int sgrid(const LaunchCfg& cfg, int64_t n) {
+    int64_t g = (n + SORT_BLOCK - 1) / SORT_BLOCK;
+    const int64_t cap = (int64_t)cfg.device_cus * 16;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+hipError_t launch_sort_key_fixed(const LaunchCfg& cfg, const ColumnRef& c, const uint32_t* perm, int64_t n, bool desc, uint64_t* out) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(sort_key_fixed_kernel, dim3(sgrid(cfg, n)), dim3(SORT_BLOCK), 0, cfg.stream, c, perm, n, desc ? 1 : 0, out);
+    return hipGetLastError();
+}
+hipError_t launch_sort_key_utf8(const LaunchCfg& cfg, const ColumnRef& c, const uint32_t* perm, int64_t n, int chunk, bool desc,
+                                uint64_t* out) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(sort_key_utf8_kernel, dim3(sgrid(cfg, n)), dim3(SORT_BLOCK), 0, cfg.stream, c, perm, n, chunk, desc ? 1 : 0, out);
+    return hipGetLastError();
+}
+hipError_t launch_sort_key_null(const LaunchCfg& cfg, const uint64_t* validity, const uint32_t* perm, int64_t n, bool nulls_first,
+                                uint64_t* out) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(sort_key_null_kernel, dim3(sgrid(cfg, n)), dim3(SORT_BLOCK), 0, cfg.stream, validity, perm, n,
+                       nulls_first ? 1 : 0, out);
+    return hipGetLastError();
+}
+hipError_t launch_utf8_max_len(const LaunchCfg& cfg, const int32_t* offsets, int64_t n, uint32_t* out) {
+    hipError_t e = hipMemsetAsync(out, 0, 4, cfg.stream);
+    if (e != hipSuccess || n == 0) return e;
+    hipLaunchKernelGGL(utf8_max_len_kernel, dim3(sgrid(cfg, n)), dim3(SORT_BLOCK), 0, cfg.stream, offsets, n, out);
+    return hipGetLastError();
+}
+hipError_t launch_hash_to_pid(const LaunchCfg& cfg, const uint64_t* hashes, int64_t n, uint32_t n_parts, uint64_t* out) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(hash_to_pid_kernel, dim3(sgrid(cfg, n)), dim3(SORT_BLOCK), 0, cfg.stream, hashes, n, n_parts, out);
+    return hipGetLastError();
+}
+hipError_t launch_partition_bounds(const LaunchCfg& cfg, const uint64_t* sorted_keys, int64_t n, uint32_t n_parts, uint32_t* first) {
+    hipLaunchKernelGGL(partition_bounds_kernel, dim3(sgrid(cfg, n + 1)), dim3(SORT_BLOCK), 0, cfg.stream, sorted_keys, n, n_parts, first);
+    return hipGetLastError();
+}
+
+}  // namespace bhip

@@ -1,0 +1,467 @@
+// kernels_util.hip — data-movement kernels around the scan kernels: prefix sums, selection
+// bitmap -> row indices, gathers ("take") for fixed-width / bitmap / Utf8 columns, group-table
+// emission, concatenation helpers.
+//
+// These are the MI355X bodies of arrow-rs `filter` / `take` / `concat`, which the reference
+// reaches through FilterExec, HashJoinExec, SortExec, RepartitionExec and CoalesceBatchesExec
+// (rust/core/src/serde/physical_plan/from_proto.rs:81-92,122-147,253-331).  All are HBM-bound:
+// sequential reads/writes are one element per lane (coalesced); gathers read at row
+// granularity and write coalesced.
+#include <hip/hip_runtime.h>
+#include "kernels.h"
+#include "util_kernels.h"
+#include "vm_device.h"
+
+namespace bhip {
+
+// =============================================================================================
+// exclusive prefix sum  out[i] = sum_{j<i} in[j]   (uint32 in, uint64/uint32/int32 out)
+// three phases: per-chunk sums -> one-workgroup scan of the sums -> per-chunk local scan
+// =============================================================================================
+constexpr int SCAN_BLOCK = 256;
+constexpr int SCAN_ITEMS = 16;
+constexpr int SCAN_CHUNK = SCAN_BLOCK * SCAN_ITEMS;   // 4096
+
+__device__ inline uint64_t block_exclusive_scan(uint64_t v, uint64_t* s_wave, uint64_t* total) {
+    // wave inclusive scan by shuffles, then 4 wave totals through LDS
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t lo = __shfl_up((uint32_t)x, d, 64), hi = __shfl_up((uint32_t)(x >> 32), d, 64);
+        const uint64_t y = ((uint64_t)hi << 32) | lo;
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) s_wave[wave] = x;
+    __syncthreads();
+    uint64_t wave_off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_BLOCK / 64; ++w) {
+        const uint64_t s = s_wave[w];
+        if (w < wave) wave_off += s;
+        tot += s;
+    }
+    __syncthreads();
+    if (total) *total = tot;
+    return wave_off + x - v;
+}
+
+__global__ void __launch_bounds__(SCAN_BLOCK)
+scan_chunk_sums_kernel(const uint32_t* in, int64_t n, uint64_t* chunk_sums) {
+    __shared__ uint64_t s_wave[4];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK;
+    uint64_t v = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        const int64_t j = base + i * SCAN_BLOCK + threadIdx.x;
+        if (j < n) v += in[j];
+    }
+    uint64_t tot;
+    block_exclusive_scan(v, s_wave, &tot);
+    if (threadIdx.x == 0) chunk_sums[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(SCAN_BLOCK)
+scan_sums_kernel(uint64_t* chunk_sums, int64_t n_chunks, uint64_t* total_out) {
+    __shared__ uint64_t s_wave[4];
+    uint64_t carry = 0;
+    for (int64_t b = 0; b < n_chunks; b += SCAN_BLOCK) {
+        const int64_t j = b + threadIdx.x;
+        const uint64_t v = j < n_chunks ? chunk_sums[j] : 0;
+        uint64_t tot;
+        const uint64_t ex = block_exclusive_scan(v, s_wave, &tot);
+        if (j < n_chunks) chunk_sums[j] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = carry;
+}
+
+template <class OutT>
+__global__ void __launch_bounds__(SCAN_BLOCK)
+scan_apply_kernel(const uint32_t* in, int64_t n, const uint64_t* chunk_offsets, OutT* out, int write_total) {
+    __shared__ uint64_t s_wave[4];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK;
+    // thread owns SCAN_ITEMS consecutive elements so the scan order is the element order
+    uint32_t x[SCAN_ITEMS];
+    uint64_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        const int64_t j = base + (int64_t)threadIdx.x * SCAN_ITEMS + i;
+        x[i] = j < n ? in[j] : 0;
+        sum += x[i];
+    }
+    uint64_t run = chunk_offsets[blockIdx.x] + block_exclusive_scan(sum, s_wave, nullptr);
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        const int64_t j = base + (int64_t)threadIdx.x * SCAN_ITEMS + i;
+        if (j < n) out[j] = (OutT)run;
+        run += x[i];
+        if (write_total && j == n - 1) out[n] = (OutT)run;
+    }
+}
+
+size_t exclusive_scan_temp_bytes(int64_t n) {
+    const int64_t n_chunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    return (size_t)(n_chunks > 0 ? n_chunks : 1) * sizeof(uint64_t);
+}
+
+template <class OutT>
+static hipError_t exclusive_scan_t(hipStream_t st, const uint32_t* in, int64_t n, OutT* out, bool write_total,
+                                   uint64_t* total_out, void* temp) {
+    uint64_t* sums = reinterpret_cast<uint64_t*>(temp);
+    const int64_t n_chunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    if (n_chunks == 0) {
+        hipError_t e = hipSuccess;
+        if (total_out) e = hipMemsetAsync(total_out, 0, sizeof(uint64_t), st);
+        if (e == hipSuccess && write_total) e = hipMemsetAsync(out, 0, sizeof(OutT), st);
+        return e;
+    }
+    hipLaunchKernelGGL(scan_chunk_sums_kernel, dim3((unsigned)n_chunks), dim3(SCAN_BLOCK), 0, st, in, n, sums);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, st, sums, n_chunks, total_out);
+    hipLaunchKernelGGL((scan_apply_kernel<OutT>), dim3((unsigned)n_chunks), dim3(SCAN_BLOCK), 0, st, in, n, sums, out,
+                       write_total ? 1 : 0);
+    return hipGetLastError();
+}
+
+hipError_t exclusive_scan_u32_u64(hipStream_t st, const uint32_t* in, int64_t n, uint64_t* out, bool write_total,
+                                  uint64_t* total_out, void* temp) {
+    return exclusive_scan_t<uint64_t>(st, in, n, out, write_total, total_out, temp);
+}
+hipError_t exclusive_scan_u32_i32(hipStream_t st, const uint32_t* in, int64_t n, int32_t* out, bool write_total,
+                                  uint64_t* total_out, void* temp) {
+    return exclusive_scan_t<int32_t>(st, in, n, out, write_total, total_out, temp);
+}
+hipError_t exclusive_scan_u32_u32(hipStream_t st, const uint32_t* in, int64_t n, uint32_t* out, bool write_total,
+                                  uint64_t* total_out, void* temp) {
+    return exclusive_scan_t<uint32_t>(st, in, n, out, write_total, total_out, temp);
+}
+
+// =============================================================================================
+// selection bitmap -> ascending row indices (FilterExec keeps row order)
+// =============================================================================================
+__global__ void __launch_bounds__(BLOCK)
+select_indices_kernel(const uint64_t* bitmap, const uint64_t* tile_offsets, int64_t n_rows, uint32_t* indices) {
+    __shared__ uint32_t s_word_off[SEL_TILE / 64 + 1];
+    const int tid = threadIdx.x;
+    const int64_t n_tiles = (n_rows + SEL_TILE - 1) / SEL_TILE;
+    for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const int64_t base = t * SEL_TILE;
+        const int64_t n_words = (n_rows + 63) / 64;
+        if (tid == 0) {
+            uint32_t run = 0;
+            for (int w = 0; w < SEL_TILE / 64; ++w) {
+                s_word_off[w] = run;
+                const int64_t wi = (base >> 6) + w;
+                run += wi < n_words ? (uint32_t)__popcll(bitmap[wi]) : 0u;
+            }
+        }
+        __syncthreads();
+        const uint64_t out_base = tile_offsets[t];
+#pragma unroll
+        for (int r = 0; r < SEL_TILE / BLOCK; ++r) {
+            const int64_t row = base + r * BLOCK + tid;
+            if (row < n_rows) {
+                const uint64_t word = bitmap[row >> 6];
+                const int lane = (int)(row & 63);
+                if ((word >> lane) & 1ull) {
+                    const uint32_t rank = (uint32_t)__popcll(word & ((1ull << lane) - 1ull));
+                    indices[out_base + s_word_off[(row - base) >> 6] + rank] = (uint32_t)row;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_select_indices(const LaunchCfg& cfg, const uint64_t* bitmap, const uint64_t* tile_offsets,
+                                 int64_t n_rows, uint32_t* indices) {
+    const int64_t n_tiles = (n_rows + SEL_TILE - 1) / SEL_TILE;
+    if (n_tiles == 0) return hipSuccess;
+    int64_t grid = (int64_t)cfg.device_cus * 8;
+    if (grid > n_tiles) grid = n_tiles;
+    hipLaunchKernelGGL(select_indices_kernel, dim3((unsigned)grid), dim3(BLOCK), 0, cfg.stream, bitmap, tile_offsets,
+                       n_rows, indices);
+    return hipGetLastError();
+}
+
+// =============================================================================================
+// take (gather by row index); index 0xFFFFFFFF = NULL row (outer joins)
+// =============================================================================================
+constexpr uint32_t NULL_INDEX = 0xFFFFFFFFu;
+
+template <class T>
+__global__ void __launch_bounds__(BLOCK)
+take_fixed_kernel(const T* src, const uint32_t* idx, int64_t n, T* dst) {
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+        const uint32_t j = idx[i];
+        dst[i] = j == NULL_INDEX ? T(0) : src[j];
+    }
+}
+
+// validity / Boolean bitmaps: out bit i = (idx != NULL) && src bit idx (src == nullptr: all set)
+__global__ void __launch_bounds__(BLOCK)
+take_bitmap_kernel(const uint64_t* src, const uint32_t* idx, int64_t n, uint64_t* dst) {
+    const int64_t n_round = (n + 63) & ~(int64_t)63;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n_round; i += (int64_t)gridDim.x * BLOCK) {
+        bool bit = false;
+        if (i < n) {
+            const uint32_t j = idx[i];
+            if (j != NULL_INDEX) bit = src == nullptr ? true : ((src[j >> 6] >> (j & 63)) & 1ull);
+        }
+        const uint64_t word = __ballot(bit);
+        if ((threadIdx.x & 63) == 0) dst[i >> 6] = word;
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK)
+take_utf8_lengths_kernel(const int32_t* offsets, const uint32_t* idx, int64_t n, uint32_t* lengths) {
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+        const uint32_t j = idx[i];
+        lengths[i] = j == NULL_INDEX ? 0u : (uint32_t)(offsets[j + 1] - offsets[j]);
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK)
+take_utf8_copy_kernel(const int32_t* src_off, const uint8_t* src, const uint32_t* idx, int64_t n,
+                      const int32_t* dst_off, uint8_t* dst) {
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+        const uint32_t j = idx[i];
+        if (j == NULL_INDEX) continue;
+        const int32_t s0 = src_off[j], len = src_off[j + 1] - s0, d0 = dst_off[i];
+        for (int32_t b = 0; b < len; ++b) dst[d0 + b] = src[s0 + b];
+    }
+}
+
+static int grid_for(const LaunchCfg& cfg, int64_t n, int per_thread = 1) {
+    int64_t g = (n + (int64_t)BLOCK * per_thread - 1) / ((int64_t)BLOCK * per_thread);
+    const int64_t cap = (int64_t)cfg.device_cus * 16;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+hipError_t launch_take_fixed(const LaunchCfg& cfg, const void* src, int width, const uint32_t* idx, int64_t n, void* dst) {
+    if (n == 0) return hipSuccess;
+    const int grid = grid_for(cfg, n);
+    switch (width) {
+        case 1: hipLaunchKernelGGL(take_fixed_kernel<uint8_t>, dim3(grid), dim3(BLOCK), 0, cfg.stream,
+                                   (const uint8_t*)src, idx, n, (uint8_t*)dst); break;
+        case 4: hipLaunchKernelGGL(take_fixed_kernel<uint32_t>, dim3(grid), dim3(BLOCK), 0, cfg.stream,
+                                   (const uint32_t*)src, idx, n, (uint32_t*)dst); break;
+        case 8: hipLaunchKernelGGL(take_fixed_kernel<uint64_t>, dim3(grid), dim3(BLOCK), 0, cfg.stream,
+                                   (const uint64_t*)src, idx, n, (uint64_t*)dst); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_take_bitmap(const LaunchCfg& cfg, const uint64_t* src, const uint32_t* idx, int64_t n, uint64_t* dst) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(take_bitmap_kernel, dim3(grid_for(cfg, n)), dim3(BLOCK), 0, cfg.stream, src, idx, n, dst);
+    return hipGetLastError();
+}
+
+hipError_t launch_take_utf8_lengths(const LaunchCfg& cfg, const int32_t* offsets, const uint32_t* idx, int64_t n,
+                                    uint32_t* lengths) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(take_utf8_lengths_kernel, dim3(grid_for(cfg, n)), dim3(BLOCK), 0, cfg.stream, offsets, idx, n, lengths);
+    return hipGetLastError();
+}
+
+hipError_t launch_take_utf8_copy(const LaunchCfg& cfg, const int32_t* src_off, const uint8_t* src, const uint32_t* idx,
+                                 int64_t n, const int32_t* dst_off, uint8_t* dst) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(take_utf8_copy_kernel, dim3(grid_for(cfg, n)), dim3(BLOCK), 0, cfg.stream, src_off, src, idx, n,
+                       dst_off, dst);
+    return hipGetLastError();
+}
+
+// =============================================================================================
+// small helpers
+// =============================================================================================
+__global__ void __launch_bounds__(BLOCK)
+iota_u32_kernel(uint32_t* out, int64_t n, uint32_t start) {
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK)
+        out[i] = start + (uint32_t)i;
+}
+hipError_t launch_iota_u32(const LaunchCfg& cfg, uint32_t* out, int64_t n, uint32_t start) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(iota_u32_kernel, dim3(grid_for(cfg, n)), dim3(BLOCK), 0, cfg.stream, out, n, start);
+    return hipGetLastError();
+}
+
+// dst_off[i] = src_off[i] - src_off[0] + add   (i in [0, n]) : Utf8 offsets of a concatenation part
+__global__ void __launch_bounds__(BLOCK)
+rebase_offsets_kernel(const int32_t* src_off, int64_t n_plus_1, int32_t add, int32_t* dst_off) {
+    const int32_t first = src_off[0];
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n_plus_1; i += (int64_t)gridDim.x * BLOCK)
+        dst_off[i] = src_off[i] - first + add;
+}
+hipError_t launch_rebase_offsets(const LaunchCfg& cfg, const int32_t* src_off, int64_t n_plus_1, int32_t add, int32_t* dst_off) {
+    hipLaunchKernelGGL(rebase_offsets_kernel, dim3(grid_for(cfg, n_plus_1)), dim3(BLOCK), 0, cfg.stream, src_off,
+                       n_plus_1, add, dst_off);
+    return hipGetLastError();
+}
+
+// copy `n_bits` bits from src (starting at bit src_bit0) to dst starting at bit dst_bit0.
+// One wave builds one 64-bit destination word; partial edge words are merged with atomics.
+__global__ void __launch_bounds__(BLOCK)
+copy_bits_kernel(const uint64_t* src, int64_t src_bit0, uint64_t* dst, int64_t dst_bit0, int64_t n_bits) {
+    const int64_t first_word = dst_bit0 >> 6, last_word = (dst_bit0 + n_bits - 1) >> 6;
+    const int64_t n_words = last_word - first_word + 1;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * BLOCK) >> 6;
+    for (int64_t w = wave; w < n_words; w += n_waves) {
+        const int64_t dbit = ((first_word + w) << 6) + lane;
+        const int64_t rel = dbit - dst_bit0;
+        bool in = rel >= 0 && rel < n_bits;
+        bool bit = false;
+        if (in) {
+            if (src == nullptr) bit = true;
+            else { const int64_t sbit = src_bit0 + rel; bit = (src[sbit >> 6] >> (sbit & 63)) & 1ull; }
+        }
+        const uint64_t val = __ballot(bit), mask = __ballot(in);
+        if (lane == 0) {
+            if (mask == ~0ull) dst[first_word + w] = val;
+            else {
+                atomicAnd((unsigned long long*)&dst[first_word + w], (unsigned long long)~mask);
+                atomicOr((unsigned long long*)&dst[first_word + w], (unsigned long long)val);
+            }
+        }
+    }
+}
+hipError_t launch_copy_bits(const LaunchCfg& cfg, const uint64_t* src, int64_t src_bit0, uint64_t* dst, int64_t dst_bit0,
+                            int64_t n_bits) {
+    if (n_bits == 0) return hipSuccess;
+    hipLaunchKernelGGL(copy_bits_kernel, dim3(grid_for(cfg, (n_bits + 63) / 64 * 64)), dim3(BLOCK), 0, cfg.stream, src,
+                       src_bit0, dst, dst_bit0, n_bits);
+    return hipGetLastError();
+}
+
+// =============================================================================================
+// group table -> Arrow columns
+// =============================================================================================
+__device__ inline uint64_t key_get(const GroupRec& g, int pos, int width) {
+    uint64_t v;
+    if (pos >= 8) v = g.k1 >> (8 * (pos - 8));
+    else {
+        v = g.k0 >> (8 * pos);
+        if (pos > 0 && pos + width > 8) v |= g.k1 << (8 * (8 - pos));
+    }
+    if (width < 8) v &= (1ull << (8 * width)) - 1ull;
+    return v;
+}
+
+// one group column; `pos` = byte position of the part inside the packed key
+__global__ void __launch_bounds__(BLOCK)
+emit_group_key_kernel(const GroupRec* table, int64_t n_groups, EmitKeySpec spec, void* data, uint64_t* validity,
+                      uint32_t* utf8_lengths) {
+    const int64_t n_round = (n_groups + 63) & ~(int64_t)63;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n_round; i += (int64_t)gridDim.x * BLOCK) {
+        bool valid = false;
+        if (i < n_groups) {
+            const GroupRec& g = table[i];
+            int pos = spec.pos, width = spec.width;
+            valid = true;
+            if (spec.nullable) { valid = key_get(g, pos, 1) != 0; pos += 1; width -= 1; }
+            if (spec.dtype == DT_UTF8) {
+                if (utf8_lengths) utf8_lengths[i] = valid ? (uint32_t)key_get(g, pos, 1) : 0u;
+            } else {
+                uint64_t v = valid ? key_get(g, pos, width) : 0;
+                switch (spec.dtype) {
+                    case DT_INT32:
+                    case DT_DATE32: reinterpret_cast<int32_t*>(data)[i] = (int32_t)(uint32_t)v; break;
+                    case DT_UINT8: reinterpret_cast<uint8_t*>(data)[i] = (uint8_t)v; break;
+                    case DT_BOOLEAN: break;   // written below as a ballot word
+                    default: reinterpret_cast<uint64_t*>(data)[i] = v; break;
+                }
+                if (spec.dtype == DT_BOOLEAN) {
+                    const uint64_t word = __ballot(v & 1);
+                    if ((threadIdx.x & 63) == 0) reinterpret_cast<uint64_t*>(data)[i >> 6] = word;
+                }
+            }
+        } else if (spec.dtype == DT_BOOLEAN) {
+            const uint64_t word = __ballot(false);
+            if ((threadIdx.x & 63) == 0) reinterpret_cast<uint64_t*>(data)[i >> 6] = word;
+        }
+        if (validity != nullptr) {
+            const uint64_t vw = __ballot(valid);
+            if ((threadIdx.x & 63) == 0) validity[i >> 6] = vw;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK)
+emit_group_utf8_kernel(const GroupRec* table, int64_t n_groups, EmitKeySpec spec, const int32_t* offsets, uint8_t* bytes) {
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n_groups; i += (int64_t)gridDim.x * BLOCK) {
+        const GroupRec& g = table[i];
+        int pos = spec.pos;
+        if (spec.nullable) { if (key_get(g, pos, 1) == 0) continue; pos += 1; }
+        const int len = (int)key_get(g, pos, 1);
+        const int32_t d0 = offsets[i];
+        for (int b = 0; b < len; ++b) bytes[d0 + b] = (uint8_t)key_get(g, pos + 1 + b, 1);
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK)
+emit_group_value_kernel(const GroupRec* table, int64_t n_groups, EmitValueSpec spec, void* data, uint64_t* validity) {
+    const int64_t n_round = (n_groups + 63) & ~(int64_t)63;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n_round; i += (int64_t)gridDim.x * BLOCK) {
+        bool valid = false;
+        if (i < n_groups) {
+            const GroupRec& g = table[i];
+            const uint64_t cnt_a = spec.count_is_rows ? g.rows : g.nvalid[spec.acc_a];
+            uint64_t v = 0;
+            valid = true;
+            switch (spec.kind) {
+                case EMIT_VALUE: v = g.acc[spec.acc_a]; valid = cnt_a > 0; break;
+                case EMIT_COUNT: v = cnt_a; break;
+                case EMIT_ROWS: v = g.rows; break;
+                case EMIT_RAW: v = g.acc[spec.acc_a]; break;
+                case EMIT_AVG: valid = cnt_a > 0; v = valid ? d2u(u2d(g.acc[spec.acc_a]) / (double)cnt_a) : 0; break;
+                case EMIT_AVG_ACC: {
+                    const uint64_t c = g.acc[spec.acc_b];
+                    valid = c > 0 && g.nvalid[spec.acc_a] > 0;
+                    v = valid ? d2u(u2d(g.acc[spec.acc_a]) / (double)c) : 0;
+                } break;
+                default: break;
+            }
+            if (!valid) v = 0;
+            switch (spec.dtype) {
+                case DT_INT32:
+                case DT_DATE32: reinterpret_cast<int32_t*>(data)[i] = (int32_t)(uint32_t)v; break;
+                case DT_UINT8: reinterpret_cast<uint8_t*>(data)[i] = (uint8_t)v; break;
+                default: reinterpret_cast<uint64_t*>(data)[i] = v; break;
+            }
+        }
+        if (validity != nullptr) {
+            const uint64_t vw = __ballot(valid);
+            if ((threadIdx.x & 63) == 0) validity[i >> 6] = vw;
+        }
+    }
+}
+
+hipError_t launch_emit_group_key(const LaunchCfg& cfg, const GroupRec* table, int64_t n_groups, const EmitKeySpec& spec,
+                                 void* data, uint64_t* validity, uint32_t* utf8_lengths) {
+    if (n_groups == 0) return hipSuccess;
+    hipLaunchKernelGGL(emit_group_key_kernel, dim3(grid_for(cfg, n_groups)), dim3(BLOCK), 0, cfg.stream, table, n_groups,
+                       spec, data, validity, utf8_lengths);
+    return hipGetLastError();
+}
+hipError_t launch_emit_group_utf8(const LaunchCfg& cfg, const GroupRec* table, int64_t n_groups, const EmitKeySpec& spec,
+                                  const int32_t* offsets, uint8_t* bytes) {
+    if (n_groups == 0) return hipSuccess;
+    hipLaunchKernelGGL(emit_group_utf8_kernel, dim3(grid_for(cfg, n_groups)), dim3(BLOCK), 0, cfg.stream, table, n_groups,
+                       spec, offsets, bytes);
+    return hipGetLastError();
+}
+hipError_t launch_emit_group_value(const LaunchCfg& cfg, const GroupRec* table, int64_t n_groups,
+                                   const EmitValueSpec& spec, void* data, uint64_t* validity) {
+    if (n_groups == 0) return hipSuccess;
+    hipLaunchKernelGGL(emit_group_value_kernel, dim3(grid_for(cfg, n_groups)), dim3(BLOCK), 0, cfg.stream, table,
+                       n_groups, spec, data, validity);
+    return hipGetLastError();
+}
+
+}  // namespace bhip

@@ -1,0 +1,25 @@
+// sort_kernels.h — launchers of kernels_sort.hip (internal C++ interface).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kernels.h"
+
+namespace bhip {
+
+size_t radix_sort_temp_bytes(int64_t n);
+// bits that differ between any two keys (device u64)
+hipError_t radix_key_diff(const LaunchCfg& cfg, const uint64_t* keys, int64_t n, uint64_t* diff_out);
+// one stable 8-bit pass on byte `byte` (0 = least significant)
+hipError_t radix_pass(const LaunchCfg& cfg, const uint64_t* keys, const uint32_t* vals, int64_t n, int byte,
+                      uint64_t* keys_out, uint32_t* vals_out, void* temp);
+
+hipError_t launch_sort_key_fixed(const LaunchCfg& cfg, const ColumnRef& c, const uint32_t* perm, int64_t n, bool desc, uint64_t* out);
+hipError_t launch_sort_key_utf8(const LaunchCfg& cfg, const ColumnRef& c, const uint32_t* perm, int64_t n, int chunk, bool desc,
+                                uint64_t* out);
+hipError_t launch_sort_key_null(const LaunchCfg& cfg, const uint64_t* validity, const uint32_t* perm, int64_t n, bool nulls_first,
+                                uint64_t* out);
+hipError_t launch_utf8_max_len(const LaunchCfg& cfg, const int32_t* offsets, int64_t n, uint32_t* out);
+hipError_t launch_hash_to_pid(const LaunchCfg& cfg, const uint64_t* hashes, int64_t n, uint32_t n_parts, uint64_t* out);
+hipError_t launch_partition_bounds(const LaunchCfg& cfg, const uint64_t* sorted_keys, int64_t n, uint32_t n_parts, uint32_t* first);
+
+}  // namespace bhip

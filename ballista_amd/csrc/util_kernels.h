@@ -1,0 +1,80 @@
+// util_kernels.h — launchers of kernels_util.hip / kernels_gen.hip / kernels_hash.hip /
+// kernels_sort.hip (internal C++ interface).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kernels.h"
+
+namespace bhip {
+
+// ---- prefix sums ------------------------------------------------------------------------
+size_t exclusive_scan_temp_bytes(int64_t n);
+// out[i] = sum in[0..i) ; write_total: also out[n] = grand total ; total_out (device u64) optional
+hipError_t exclusive_scan_u32_u64(hipStream_t st, const uint32_t* in, int64_t n, uint64_t* out, bool write_total,
+                                  uint64_t* total_out, void* temp);
+hipError_t exclusive_scan_u32_i32(hipStream_t st, const uint32_t* in, int64_t n, int32_t* out, bool write_total,
+                                  uint64_t* total_out, void* temp);
+hipError_t exclusive_scan_u32_u32(hipStream_t st, const uint32_t* in, int64_t n, uint32_t* out, bool write_total,
+                                  uint64_t* total_out, void* temp);
+
+// ---- selection ---------------------------------------------------------------------------
+hipError_t launch_select_indices(const LaunchCfg& cfg, const uint64_t* bitmap, const uint64_t* tile_offsets,
+                                 int64_t n_rows, uint32_t* indices);
+
+// ---- take ----------------------------------------------------------------------------------
+hipError_t launch_take_fixed(const LaunchCfg& cfg, const void* src, int width, const uint32_t* idx, int64_t n, void* dst);
+hipError_t launch_take_bitmap(const LaunchCfg& cfg, const uint64_t* src, const uint32_t* idx, int64_t n, uint64_t* dst);
+hipError_t launch_take_utf8_lengths(const LaunchCfg& cfg, const int32_t* offsets, const uint32_t* idx, int64_t n,
+                                    uint32_t* lengths);
+hipError_t launch_take_utf8_copy(const LaunchCfg& cfg, const int32_t* src_off, const uint8_t* src, const uint32_t* idx,
+                                 int64_t n, const int32_t* dst_off, uint8_t* dst);
+
+hipError_t launch_iota_u32(const LaunchCfg& cfg, uint32_t* out, int64_t n, uint32_t start);
+hipError_t launch_rebase_offsets(const LaunchCfg& cfg, const int32_t* src_off, int64_t n_plus_1, int32_t add, int32_t* dst_off);
+hipError_t launch_copy_bits(const LaunchCfg& cfg, const uint64_t* src, int64_t src_bit0, uint64_t* dst, int64_t dst_bit0,
+                            int64_t n_bits);
+
+// ---- group table -> columns ----------------------------------------------------------------
+struct EmitKeySpec {
+    int32_t pos;        // byte position of the part in the packed key
+    int32_t width;      // bytes (incl. null byte / length byte)
+    int32_t nullable;
+    int32_t dtype;
+};
+enum EmitValueKind : int32_t {
+    EMIT_VALUE = 0,     // acc[a], NULL when no input reached it (SUM / MIN / MAX)
+    EMIT_COUNT = 1,     // number of non-NULL inputs of acc[a] (COUNT(x), AVG count)
+    EMIT_ROWS = 2,      // rows of the group (COUNT(*))
+    EMIT_RAW = 3,       // acc[a] as is (merged counts in Final mode)
+    EMIT_AVG = 4,       // acc[a] / count(a)
+    EMIT_AVG_ACC = 5    // acc[a] / acc[b]   (Final mode: merged sum / merged count)
+};
+struct EmitValueSpec {
+    int32_t kind;
+    int32_t acc_a, acc_b;
+    int32_t count_is_rows;   // program has no NULLs: count(a) == rows
+    int32_t dtype;
+};
+hipError_t launch_emit_group_key(const LaunchCfg& cfg, const GroupRec* table, int64_t n_groups, const EmitKeySpec& spec,
+                                 void* data, uint64_t* validity, uint32_t* utf8_lengths);
+hipError_t launch_emit_group_utf8(const LaunchCfg& cfg, const GroupRec* table, int64_t n_groups, const EmitKeySpec& spec,
+                                  const int32_t* offsets, uint8_t* bytes);
+hipError_t launch_emit_group_value(const LaunchCfg& cfg, const GroupRec* table, int64_t n_groups,
+                                   const EmitValueSpec& spec, void* data, uint64_t* validity);
+
+// ---- synthetic TPC-H generator (kernels_gen.hip) -------------------------------------------
+struct GenLineitemOut {
+    int32_t* l_orderkey; int64_t* l_orderkey_i64; int32_t* l_suppkey;
+    double* l_quantity; double* l_extendedprice; double* l_discount; double* l_tax;
+    int32_t* l_shipdate; int32_t* l_commitdate; int32_t* l_receiptdate;
+    int32_t* flag_off; uint8_t* flag_data; int32_t* status_off; uint8_t* status_data;
+};
+hipError_t launch_gen_lineitem(const LaunchCfg& cfg, uint64_t seed, uint64_t row0, uint64_t n, uint64_t n_orders,
+                               uint64_t n_parts, uint64_t n_supp, const GenLineitemOut& out);
+struct GenOrdersOut {
+    int32_t* o_orderkey; int64_t* o_orderkey_i64; int32_t* o_custkey; int32_t* o_orderdate; int32_t* o_shippriority;
+};
+hipError_t launch_gen_orders(const LaunchCfg& cfg, uint64_t seed, uint64_t row0, uint64_t n, uint64_t n_cust,
+                             const GenOrdersOut& out);
+
+}  // namespace bhip

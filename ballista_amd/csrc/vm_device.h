@@ -1,0 +1,449 @@
+// vm_device.h — device side of the expression VM (see vm_isa.h for the design).
+//
+// Geometry: a workgroup is 256 threads (4 wave64); a tile is 256*R rows; thread `tid`
+// owns rows  tile_base + r*256 + tid  (r < R), so consecutive lanes touch consecutive
+// rows: global loads coalesce (a wave reads 64 consecutive values) and LDS slot accesses
+// are bank-conflict free (lane stride = element size).  Every slot element is read and
+// written only by its owning thread, so the interpreter needs no barriers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "vm_isa.h"
+
+namespace bhip {
+
+constexpr int BLOCK = 256;
+
+struct TileLds {
+    uint64_t* vals;     // [n_vslots][TILE]
+    uint8_t* vvalid;    // [n_vslots][TILE]   (only when NULLS)
+    uint8_t* bvals;     // [n_bslots][TILE]   bit0 = value, bit1 = known (not NULL)
+};
+
+template <int R>
+__device__ inline size_t tile_lds_bytes(int n_vslots, int n_bslots, bool nulls) {
+    constexpr int TILE = BLOCK * R;
+    size_t b = (size_t)n_vslots * TILE * 8;
+    if (nulls) b += (size_t)n_vslots * TILE;
+    b += (size_t)n_bslots * TILE;
+    return (b + 15) & ~(size_t)15;
+}
+
+template <int R, bool NULLS>
+__device__ inline TileLds carve_tile_lds(uint8_t* base, const VmProgram& G) {
+    constexpr int TILE = BLOCK * R;
+    TileLds L;
+    L.vals = reinterpret_cast<uint64_t*>(base);
+    uint8_t* p = base + (size_t)G.n_vslots * TILE * 8;
+    L.vvalid = p;
+    if (NULLS) p += (size_t)G.n_vslots * TILE;
+    L.bvals = p;
+    return L;
+}
+
+__device__ inline double u2d(uint64_t u) { return __longlong_as_double((long long)u); }
+__device__ inline uint64_t d2u(double d) { return (uint64_t)__double_as_longlong(d); }
+
+__device__ inline bool column_valid_bit(const ColumnRef& c, int64_t row) {
+    if (c.validity == nullptr) return true;
+    return (c.validity[row >> 6] >> (row & 63)) & 1ull;
+}
+
+// ---- hoisted column loads: all global loads of a tile are issued before any is consumed
+template <int R, bool NULLS>
+__device__ inline void vm_load_tile(const ScanParams& P, const TileLds& L, int64_t tile_base) {
+    constexpr int TILE = BLOCK * R;
+    constexpr int GROUP = 6;
+    const VmProgram& G = P.prog;
+    const int tid = threadIdx.x;
+    for (int g0 = 0; g0 < G.n_loads; g0 += GROUP) {
+        uint64_t x[GROUP][R];
+        uint8_t ok[NULLS ? GROUP : 1][NULLS ? R : 1];   // without NULLS every loaded value is known
+#pragma unroll
+        for (int j = 0; j < GROUP; ++j) {
+            if (g0 + j < G.n_loads) {
+                const VmLoad ld = G.loads[g0 + j];
+                const ColumnRef& c = P.cols[ld.col];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int64_t row = tile_base + r * BLOCK + tid;
+                    uint64_t v = 0;
+                    uint8_t k = 0;
+                    if (row < P.n_rows) {
+                        switch (ld.dtype) {
+                            case DT_FLOAT64:
+                            case DT_INT64:
+                            case DT_UINT64: v = reinterpret_cast<const uint64_t*>(c.data)[row]; break;
+                            case DT_INT32:
+                            case DT_DATE32: v = (uint64_t)(int64_t) reinterpret_cast<const int32_t*>(c.data)[row]; break;
+                            case DT_UINT8: v = reinterpret_cast<const uint8_t*>(c.data)[row]; break;
+                            case DT_BOOLEAN: v = (reinterpret_cast<const uint8_t*>(c.data)[row >> 3] >> (row & 7)) & 1u; break;
+                            default: break;
+                        }
+                        k = NULLS ? (uint8_t)column_valid_bit(c, row) : 1;
+                    }
+                    x[j][r] = v;
+                    if (NULLS) ok[j][r] = k;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < GROUP; ++j) {
+            if (g0 + j < G.n_loads) {
+                const VmLoad ld = G.loads[g0 + j];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int idx = r * BLOCK + tid;
+                    const uint8_t k = NULLS ? ok[NULLS ? j : 0][NULLS ? r : 0] : (uint8_t)1;
+                    if (ld.to_bool) {
+                        L.bvals[ld.dst * TILE + idx] = (uint8_t)((x[j][r] & k) | (k << 1));
+                    } else {
+                        L.vals[ld.dst * TILE + idx] = x[j][r];
+                        if (NULLS) L.vvalid[ld.dst * TILE + idx] = k;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- Utf8 helpers --------------------------------------------------------------------
+// three-way compare of a row's string with `lit[0..litlen)` (bytes; UTF-8 byte order)
+__device__ inline int str_cmp3(const uint8_t* s, int len, const uint8_t* t, int tlen) {
+    const int m = len < tlen ? len : tlen;
+    for (int i = 0; i < m; ++i) {
+        const int d = (int)s[i] - (int)t[i];
+        if (d != 0) return d < 0 ? -1 : 1;
+    }
+    return len < tlen ? -1 : (len > tlen ? 1 : 0);
+}
+
+__device__ inline bool cmp3_to_bool(int c, int kind) {
+    switch (kind) {
+        case CMP_EQ: return c == 0;
+        case CMP_NE: return c != 0;
+        case CMP_LT: return c < 0;
+        case CMP_LE: return c <= 0;
+        case CMP_GT: return c > 0;
+        default: return c >= 0;
+    }
+}
+
+__device__ inline bool str_like(const uint8_t* s, int len, const uint8_t* p, int plen, int kind) {
+    if (kind == LIKE_EXACT) return len == plen && str_cmp3(s, len, p, plen) == 0;
+    if (len < plen) return false;
+    if (kind == LIKE_PREFIX) return str_cmp3(s, plen, p, plen) == 0;
+    if (kind == LIKE_SUFFIX) return str_cmp3(s + (len - plen), plen, p, plen) == 0;
+    for (int i = 0; i + plen <= len; ++i)
+        if (str_cmp3(s + i, plen, p, plen) == 0) return true;
+    return false;
+}
+
+template <class T>
+__device__ inline bool cmp_vals(T a, T b, int kind) {
+    switch (kind) {
+        case CMP_EQ: return a == b;
+        case CMP_NE: return a != b;
+        case CMP_LT: return a < b;
+        case CMP_LE: return a <= b;
+        case CMP_GT: return a > b;
+        default: return a >= b;
+    }
+}
+
+__device__ inline double math_f64(double x, int fn) {
+    switch (fn) {
+        case FN_SQRT: return sqrt(x);
+        case FN_ABS: return fabs(x);
+        case FN_FLOOR: return floor(x);
+        case FN_CEIL: return ceil(x);
+        case FN_ROUND: return round(x);
+        case FN_TRUNC: return trunc(x);
+        case FN_SIGNUM: return isnan(x) ? x : copysign(1.0, x);
+        case FN_EXP: return exp(x);
+        case FN_LN: return log(x);
+        case FN_LOG2: return log2(x);
+        case FN_LOG10: return log10(x);
+        case FN_SIN: return sin(x);
+        case FN_COS: return cos(x);
+        case FN_TAN: return tan(x);
+        case FN_ASIN: return asin(x);
+        case FN_ACOS: return acos(x);
+        default: return atan(x);
+    }
+}
+
+__device__ inline bool int_in_range(int64_t v, int dtype) {
+    switch (dtype) {
+        case DT_INT32:
+        case DT_DATE32: return v >= -2147483648ll && v <= 2147483647ll;
+        case DT_UINT8: return v >= 0 && v <= 255;
+        case DT_UINT64: return v >= 0;
+        default: return true;
+    }
+}
+
+// ---- the interpreter -----------------------------------------------------------------
+// `err` accumulates SCAN_ERR_* bits for this thread (caller ORs them into global status).
+template <int R, bool NULLS>
+__device__ inline void vm_execute(const ScanParams& P, const TileLds& L, int64_t tile_base, uint32_t& err) {
+    constexpr int TILE = BLOCK * R;
+    const VmProgram& G = P.prog;
+    const int tid = threadIdx.x;
+
+#define BHIP_FOR_R _Pragma("unroll") for (int r = 0; r < R; ++r)
+#define IDX (r * BLOCK + tid)
+#define VA ((I.flags & VF_A_LIT) ? lit_a : L.vals[I.a * TILE + IDX])
+#define VB ((I.flags & VF_B_LIT) ? lit_b : L.vals[I.b * TILE + IDX])
+#define KA ((!NULLS || (I.flags & VF_A_LIT)) ? (uint8_t)1 : L.vvalid[I.a * TILE + IDX])
+#define KB ((!NULLS || (I.flags & VF_B_LIT)) ? (uint8_t)1 : L.vvalid[I.b * TILE + IDX])
+#define PUT_V(val, known)                                   \
+    do {                                                    \
+        L.vals[I.dst * TILE + IDX] = (val);                 \
+        if (NULLS) L.vvalid[I.dst * TILE + IDX] = (known);  \
+    } while (0)
+#define PUT_B(val, known)                                                            \
+    do {                                                                             \
+        const uint8_t k_ = (known) ? 1 : 0;                                          \
+        const uint8_t v_ = ((val) ? 1 : 0) & k_;                                     \
+        L.bvals[I.dst * TILE + IDX] = (uint8_t)(v_ | (k_ << 1));                     \
+    } while (0)
+
+    for (int pc = 0; pc < G.n_instr; ++pc) {
+        const VmInstr I = G.instr[pc];
+        const uint64_t lit_a = (I.flags & VF_A_LIT) ? G.lits[I.a] : 0;
+        const uint64_t lit_b = (I.flags & VF_B_LIT) ? G.lits[I.b] : 0;
+        switch (I.op) {
+            case OP_ADD_F64: BHIP_FOR_R { const uint8_t k = KA & KB; PUT_V(d2u(u2d(VA) + u2d(VB)), k); } break;
+            case OP_SUB_F64: BHIP_FOR_R { const uint8_t k = KA & KB; PUT_V(d2u(u2d(VA) - u2d(VB)), k); } break;
+            case OP_MUL_F64: BHIP_FOR_R { const uint8_t k = KA & KB; PUT_V(d2u(u2d(VA) * u2d(VB)), k); } break;
+            case OP_DIV_F64: BHIP_FOR_R { const uint8_t k = KA & KB; PUT_V(d2u(u2d(VA) / u2d(VB)), k); } break;
+            case OP_ADD_I64: BHIP_FOR_R { const uint8_t k = KA & KB; PUT_V(VA + VB, k); } break;
+            case OP_SUB_I64: BHIP_FOR_R { const uint8_t k = KA & KB; PUT_V(VA - VB, k); } break;
+            case OP_MUL_I64: BHIP_FOR_R { const uint8_t k = KA & KB; PUT_V(VA * VB, k); } break;
+            case OP_DIV_I64:
+                BHIP_FOR_R {
+                    const uint8_t k = KA & KB;
+                    const int64_t a = (int64_t)VA, b = (int64_t)VB;
+                    // a row the fused predicate (slot c) rejects was never evaluated by the reference
+                    const bool live = (tile_base + IDX < P.n_rows) && k &&
+                                      (I.c == 0xFF || (L.bvals[I.c * TILE + IDX] & 1));
+                    if (b == 0 && live) err |= SCAN_ERR_DIV_ZERO;
+                    const int64_t q = (b == 0 || (a == INT64_MIN && b == -1)) ? 0 : a / b;
+                    PUT_V((uint64_t)q, k);
+                }
+                break;
+            case OP_NEG_F64: BHIP_FOR_R { PUT_V(d2u(-u2d(VA)), KA); } break;
+            case OP_NEG_I64: BHIP_FOR_R { PUT_V((uint64_t)0 - VA, KA); } break;
+            case OP_CMP_F64: BHIP_FOR_R { const uint8_t k = KA & KB; PUT_B(cmp_vals<double>(u2d(VA), u2d(VB), I.aux), k); } break;
+            case OP_CMP_I64: BHIP_FOR_R { const uint8_t k = KA & KB; PUT_B(cmp_vals<int64_t>((int64_t)VA, (int64_t)VB, I.aux), k); } break;
+            case OP_CMP_U64: BHIP_FOR_R { const uint8_t k = KA & KB; PUT_B(cmp_vals<uint64_t>(VA, VB, I.aux), k); } break;
+            case OP_AND:
+                BHIP_FOR_R {
+                    const uint8_t a = L.bvals[I.a * TILE + IDX], b = L.bvals[I.b * TILE + IDX];
+                    const uint8_t va = a & 1, ka = a >> 1, vb = b & 1, kb = b >> 1;
+                    const uint8_t v = va & vb;
+                    const uint8_t k = (ka & kb) | (ka & (va ^ 1)) | (kb & (vb ^ 1));
+                    L.bvals[I.dst * TILE + IDX] = (uint8_t)(v | (k << 1));
+                }
+                break;
+            case OP_OR:
+                BHIP_FOR_R {
+                    const uint8_t a = L.bvals[I.a * TILE + IDX], b = L.bvals[I.b * TILE + IDX];
+                    const uint8_t va = a & 1, ka = a >> 1, vb = b & 1, kb = b >> 1;
+                    const uint8_t v = va | vb;
+                    const uint8_t k = (ka & kb) | va | vb;
+                    L.bvals[I.dst * TILE + IDX] = (uint8_t)(v | (k << 1));
+                }
+                break;
+            case OP_NOT:
+                BHIP_FOR_R {
+                    const uint8_t a = L.bvals[I.a * TILE + IDX];
+                    const uint8_t k = a >> 1;
+                    L.bvals[I.dst * TILE + IDX] = (uint8_t)((((a & 1) ^ 1) & k) | (k << 1));
+                }
+                break;
+            case OP_IS_NULL_V: BHIP_FOR_R { const uint8_t k = KA; PUT_B(I.aux ? k : (k ^ 1), 1); } break;
+            case OP_IS_NULL_B:
+                BHIP_FOR_R { const uint8_t k = L.bvals[I.a * TILE + IDX] >> 1; PUT_B(I.aux ? k : (k ^ 1), 1); }
+                break;
+            case OP_I64_TO_F64: BHIP_FOR_R { PUT_V(d2u((double)(int64_t)VA), KA); } break;
+            case OP_U64_TO_F64: BHIP_FOR_R { PUT_V(d2u((double)VA), KA); } break;
+            case OP_F64_TO_I64:
+                BHIP_FOR_R {
+                    const double d = u2d(VA);
+                    const double t = trunc(d);
+                    bool ok;
+                    uint64_t out = 0;
+                    if (I.aux == DT_UINT64) {
+                        ok = (t >= 0.0) && (t < 18446744073709551616.0);
+                        if (ok) out = (uint64_t)t;
+                    } else {
+                        ok = (t >= -9223372036854775808.0) && (t < 9223372036854775808.0);
+                        if (ok) { const int64_t v = (int64_t)t; ok = int_in_range(v, I.aux); out = ok ? (uint64_t)v : 0; }
+                    }
+                    PUT_V(out, (uint8_t)(KA & (ok ? 1 : 0)));
+                }
+                break;
+            case OP_I64_NARROW:
+                BHIP_FOR_R {
+                    const int64_t v = (int64_t)VA;
+                    const bool ok = int_in_range(v, I.aux);
+                    PUT_V(ok ? (uint64_t)v : 0, (uint8_t)(KA & (ok ? 1 : 0)));
+                }
+                break;
+            case OP_WRAP_I64:
+                BHIP_FOR_R {
+                    const uint64_t v = VA;
+                    uint64_t w = v;
+                    if (I.aux == DT_INT32 || I.aux == DT_DATE32) w = (uint64_t)(int64_t)(int32_t)(uint32_t)v;
+                    else if (I.aux == DT_UINT8) w = v & 0xFFull;
+                    PUT_V(w, KA);
+                }
+                break;
+            case OP_B_TO_I64:
+                BHIP_FOR_R { const uint8_t a = L.bvals[I.a * TILE + IDX]; PUT_V((uint64_t)(a & 1), (uint8_t)(a >> 1)); }
+                break;
+            case OP_I64_TO_B: BHIP_FOR_R { PUT_B(VA != 0, KA); } break;
+            case OP_SELECT_V:
+                BHIP_FOR_R {
+                    const bool c = L.bvals[I.c * TILE + IDX] & 1;
+                    const uint64_t v = c ? VA : VB;
+                    const uint8_t k = c ? KA : KB;
+                    PUT_V(v, k);
+                }
+                break;
+            case OP_SELECT_B:
+                BHIP_FOR_R {
+                    const bool c = L.bvals[I.c * TILE + IDX] & 1;
+                    L.bvals[I.dst * TILE + IDX] = c ? L.bvals[I.a * TILE + IDX] : L.bvals[I.b * TILE + IDX];
+                }
+                break;
+            case OP_MOV_V: BHIP_FOR_R { PUT_V(VA, (uint8_t)(I.aux ? 0 : KA)); } break;   // aux=1: typed NULL
+            case OP_MOV_B: BHIP_FOR_R { L.bvals[I.dst * TILE + IDX] = L.bvals[I.a * TILE + IDX]; } break;
+            case OP_LIT_B: BHIP_FOR_R { L.bvals[I.dst * TILE + IDX] = (uint8_t)(I.aux & 3); } break;
+            case OP_STR_CMP_LIT:
+            case OP_STR_LIKE_LIT: {
+                const ColumnRef& c = P.cols[I.c];
+                const uint8_t* lit = G.strlits + I.a;
+                BHIP_FOR_R {
+                    const int64_t row = tile_base + IDX;
+                    bool v = false, k = false;
+                    if (row < P.n_rows) {
+                        k = !NULLS || column_valid_bit(c, row);
+                        const int32_t o0 = c.offsets[row], o1 = c.offsets[row + 1];
+                        const uint8_t* s = reinterpret_cast<const uint8_t*>(c.data) + o0;
+                        if (I.op == OP_STR_CMP_LIT) v = cmp3_to_bool(str_cmp3(s, o1 - o0, lit, I.b), I.aux);
+                        else v = str_like(s, o1 - o0, lit, I.b, I.aux);
+                        if (I.flags & VF_NEGATE) v = !v;
+                    }
+                    PUT_B(v, k);
+                }
+            } break;
+            case OP_STR_CMP_COL: {
+                const ColumnRef& ca = P.cols[I.a];
+                const ColumnRef& cb = P.cols[I.b];
+                BHIP_FOR_R {
+                    const int64_t row = tile_base + IDX;
+                    bool v = false, k = false;
+                    if (row < P.n_rows) {
+                        k = !NULLS || (column_valid_bit(ca, row) && column_valid_bit(cb, row));
+                        const int32_t a0 = ca.offsets[row], a1 = ca.offsets[row + 1];
+                        const int32_t b0 = cb.offsets[row], b1 = cb.offsets[row + 1];
+                        v = cmp3_to_bool(str_cmp3(reinterpret_cast<const uint8_t*>(ca.data) + a0, a1 - a0,
+                                                  reinterpret_cast<const uint8_t*>(cb.data) + b0, b1 - b0), I.aux);
+                    }
+                    PUT_B(v, k);
+                }
+            } break;
+            case OP_STR_IS_NULL: {
+                const ColumnRef& c = P.cols[I.c];
+                BHIP_FOR_R {
+                    const int64_t row = tile_base + IDX;
+                    const bool k = row < P.n_rows ? column_valid_bit(c, row) : true;
+                    PUT_B(I.aux ? k : !k, 1);
+                }
+            } break;
+            case OP_MATH_F64: BHIP_FOR_R { PUT_V(d2u(math_f64(u2d(VA), I.aux)), KA); } break;
+            default: break;
+        }
+    }
+#undef BHIP_FOR_R
+#undef IDX
+#undef VA
+#undef VB
+#undef KA
+#undef KB
+#undef PUT_V
+#undef PUT_B
+}
+
+// ---- packed keys ------------------------------------------------------------------------
+// A key tuple packs into 16 bytes (k0 = bytes 0-7, k1 = bytes 8-15, little-endian).
+// Parts are laid out in order; a nullable part is preceded by one byte (0 = NULL, 1 = valid,
+// value bytes zeroed when NULL); a Utf8 part is [len][bytes...] padded with zeros.
+struct Key128 {
+    uint64_t k0, k1;
+    __device__ bool operator==(const Key128& o) const { return k0 == o.k0 && k1 == o.k1; }
+};
+
+__device__ inline void key_put(Key128& k, int pos, uint64_t v, int width) {
+    // little-endian insert of the low `width` bytes of v at byte position pos
+    if (width < 8) v &= ((1ull << (8 * width)) - 1ull);
+    if (pos < 8) {
+        k.k0 |= v << (8 * pos);
+        if (pos + width > 8) k.k1 |= v >> (8 * (8 - pos));
+    } else {
+        k.k1 |= v << (8 * (pos - 8));
+    }
+}
+
+template <int R, bool NULLS>
+__device__ inline Key128 pack_key(const ScanParams& P, const TileLds& L, int64_t tile_base, int r, uint32_t& err) {
+    constexpr int TILE = BLOCK * R;
+    const int idx = r * BLOCK + threadIdx.x;
+    const int64_t row = tile_base + idx;
+    Key128 k{0, 0};
+    int pos = 0;
+    for (int i = 0; i < P.n_keyparts; ++i) {
+        const KeyPart kp = P.keyparts[i];
+        int width = kp.width;
+        bool valid = true;
+        if (kp.kind == KP_VSLOT || kp.kind == KP_VSLOT_F64) {
+            if (NULLS) valid = L.vvalid[kp.src * TILE + idx];
+            if (kp.nullable) { key_put(k, pos, valid ? 1 : 0, 1); pos += 1; width -= 1; }
+            if (valid) key_put(k, pos, L.vals[kp.src * TILE + idx], width);
+        } else if (kp.kind == KP_BSLOT) {
+            const uint8_t b = L.bvals[kp.src * TILE + idx];
+            valid = b >> 1;
+            if (kp.nullable) { key_put(k, pos, valid ? 1 : 0, 1); pos += 1; width -= 1; }
+            if (valid) key_put(k, pos, b & 1, width);
+        } else {  // KP_UTF8_COL
+            const ColumnRef& c = P.cols[kp.src];
+            if (row < P.n_rows) {
+                if (NULLS) valid = column_valid_bit(c, row);
+                if (kp.nullable) { key_put(k, pos, valid ? 1 : 0, 1); pos += 1; width -= 1; }
+                if (valid) {
+                    const int32_t o0 = c.offsets[row], o1 = c.offsets[row + 1];
+                    int len = o1 - o0;
+                    if (len > width - 1) { err |= SCAN_ERR_KEY_TOO_LONG; len = width - 1; }
+                    key_put(k, pos, (uint64_t)len, 1);
+                    const uint8_t* s = reinterpret_cast<const uint8_t*>(c.data) + o0;
+                    for (int j = 0; j < len; ++j) key_put(k, pos + 1 + j, s[j], 1);
+                }
+            } else if (kp.nullable) { pos += 1; width -= 1; }
+        }
+        pos += width;
+    }
+    return k;
+}
+
+__device__ inline uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__device__ inline uint64_t hash_key(const Key128& k) { return mix64(mix64(k.k0) ^ k.k1); }
+
+}  // namespace bhip

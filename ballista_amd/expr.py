@@ -1,0 +1,272 @@
+"""Physical expressions — the host-side mirror of the expression kinds a Ballista executor
+can receive.
+
+The set is exactly what the reference's physical-plan serde accepts
+(rust/core/src/serde/physical_plan/to_proto.rs:380-511; rebuilt by `compile_expr`,
+from_proto.rs:348-364): Column, Literal, BinaryExpr, CastExpr, CaseExpr, NotExpr,
+IsNullExpr, IsNotNullExpr, InListExpr, NegativeExpr, ScalarFunctionExpr — and the
+aggregate kinds of to_proto.rs:348-378 (Sum, Avg, Count; Min/Max exist in the proto but
+are not serialisable there, we accept them anyway).  Binary operator names are the wire
+strings of rust/core/src/serde/logical_plan/from_proto.rs:937-957.
+
+These classes are plain descriptions; `ballista_amd.plan` lowers them to the flat VM
+program the C-ABI takes (include/ballista_hip.h, `bhip_expr_*`).  As in DataFusion's
+*physical* plans both sides of a BinaryExpr must already have equal types — use
+`coerce()` to insert the casts DataFusion's planner would.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple, Union
+
+# Arrow type names as in rust/benchmarks/tpch/src/main.rs:267-360 / SURVEY §8(b)
+INT32, INT64, UINT8, UINT64 = "Int32", "Int64", "UInt8", "UInt64"
+FLOAT64, DATE32, BOOLEAN, UTF8 = "Float64", "Date32", "Boolean", "Utf8"
+ALL_TYPES = (INT32, INT64, UINT8, UINT64, FLOAT64, DATE32, BOOLEAN, UTF8)
+
+BINARY_OPS = ("And", "Or", "Eq", "NotEq", "LtEq", "Lt", "Gt", "GtEq",
+              "Plus", "Minus", "Multiply", "Divide", "Like", "NotLike")
+COMPARE_OPS = ("Eq", "NotEq", "LtEq", "Lt", "Gt", "GtEq")
+ARITH_OPS = ("Plus", "Minus", "Multiply", "Divide")
+
+SCALAR_FUNCTIONS = ("sqrt", "abs", "floor", "ceil", "round", "trunc", "signum",
+                    "exp", "ln", "log2", "log10", "sin", "cos", "tan", "asin", "acos", "atan")
+
+
+class PhysicalExpr:
+    """Base class (DataFusion `PhysicalExpr`)."""
+
+    # small builder sugar used by tests / tpch plans
+    def _bin(self, op, other):
+        return BinaryExpr(self, op, other if isinstance(other, PhysicalExpr) else lit(other))
+
+    def __add__(self, o): return self._bin("Plus", o)
+    def __sub__(self, o): return self._bin("Minus", o)
+    def __mul__(self, o): return self._bin("Multiply", o)
+    def __truediv__(self, o): return self._bin("Divide", o)
+    def __lt__(self, o): return self._bin("Lt", o)
+    def __le__(self, o): return self._bin("LtEq", o)
+    def __gt__(self, o): return self._bin("Gt", o)
+    def __ge__(self, o): return self._bin("GtEq", o)
+    def eq(self, o): return self._bin("Eq", o)
+    def ne(self, o): return self._bin("NotEq", o)
+    def and_(self, o): return self._bin("And", o)
+    def or_(self, o): return self._bin("Or", o)
+    def __neg__(self): return NegativeExpr(self)
+
+
+@dataclass(eq=False)
+class Column(PhysicalExpr):
+    name: str
+
+
+@dataclass(eq=False)
+class Literal(PhysicalExpr):
+    """ScalarValue (rust/core/proto/ballista.proto:685-709). value None = typed NULL."""
+    value: object
+    dtype: str
+
+
+@dataclass(eq=False)
+class BinaryExpr(PhysicalExpr):
+    left: PhysicalExpr
+    op: str
+    right: PhysicalExpr
+
+    def __post_init__(self):
+        if self.op not in BINARY_OPS:
+            raise ValueError(f"Unsupported binary operator '{self.op}'")
+
+
+@dataclass(eq=False)
+class CastExpr(PhysicalExpr):
+    expr: PhysicalExpr
+    dtype: str
+
+
+@dataclass(eq=False)
+class CaseExpr(PhysicalExpr):
+    """CASE [expr] WHEN w THEN t ... [ELSE e] END."""
+    expr: Optional[PhysicalExpr]
+    when_then: Sequence[Tuple[PhysicalExpr, PhysicalExpr]]
+    else_expr: Optional[PhysicalExpr] = None
+
+
+@dataclass(eq=False)
+class NotExpr(PhysicalExpr):
+    expr: PhysicalExpr
+
+
+@dataclass(eq=False)
+class IsNullExpr(PhysicalExpr):
+    expr: PhysicalExpr
+
+
+@dataclass(eq=False)
+class IsNotNullExpr(PhysicalExpr):
+    expr: PhysicalExpr
+
+
+@dataclass(eq=False)
+class InListExpr(PhysicalExpr):
+    expr: PhysicalExpr
+    list: Sequence[PhysicalExpr]
+    negated: bool = False
+
+
+@dataclass(eq=False)
+class NegativeExpr(PhysicalExpr):
+    expr: PhysicalExpr
+
+
+@dataclass(eq=False)
+class ScalarFunctionExpr(PhysicalExpr):
+    fun: str
+    args: Sequence[PhysicalExpr]
+
+    def __post_init__(self):
+        if self.fun not in SCALAR_FUNCTIONS:
+            raise NotImplementedError(f"scalar function '{self.fun}' is not supported")
+
+
+# ---- aggregates (DataFusion `AggregateExpr`) -----------------------------------------
+
+@dataclass(eq=False)
+class AggregateExpr:
+    fun: str            # "SUM" | "AVG" | "COUNT" | "MIN" | "MAX"
+    expr: PhysicalExpr
+    name: str
+
+    def __post_init__(self):
+        if self.fun not in ("SUM", "AVG", "COUNT", "MIN", "MAX"):
+            raise NotImplementedError(f"aggregate function '{self.fun}' is not supported")
+
+
+def Sum(expr, name): return AggregateExpr("SUM", expr, name)
+def Avg(expr, name): return AggregateExpr("AVG", expr, name)
+def Count(expr, name): return AggregateExpr("COUNT", expr, name)
+def Min(expr, name): return AggregateExpr("MIN", expr, name)
+def Max(expr, name): return AggregateExpr("MAX", expr, name)
+
+
+@dataclass(eq=False)
+class PhysicalSortExpr:
+    """ballista.proto PhysicalSortExprNode; SQL default ASC NULLS FIRST (Appendix A)."""
+    expr: PhysicalExpr
+    descending: bool = False
+    nulls_first: bool = True
+
+
+# ---- helpers -------------------------------------------------------------------------
+
+def col(name: str) -> Column:
+    return Column(name)
+
+
+def lit(v, dtype: Optional[str] = None) -> Literal:
+    if isinstance(v, Literal):
+        return v
+    if dtype is None:
+        if isinstance(v, bool):
+            dtype = BOOLEAN
+        elif isinstance(v, int):
+            dtype = INT64
+        elif isinstance(v, float):
+            dtype = FLOAT64
+        elif isinstance(v, str):
+            dtype = UTF8
+        else:
+            raise TypeError(f"cannot infer literal type of {v!r}")
+    return Literal(v, dtype)
+
+
+def date32(s: str) -> Literal:
+    """`date 'YYYY-MM-DD'` literal as days since 1970-01-01 (Appendix A)."""
+    import datetime
+    d = datetime.date.fromisoformat(s)
+    return Literal((d - datetime.date(1970, 1, 1)).days, DATE32)
+
+
+_NUMERIC_RANK = {UINT8: 1, INT32: 2, DATE32: 2, INT64: 3, UINT64: 4, FLOAT64: 5}
+
+
+def expr_type(e: PhysicalExpr, schema: dict) -> str:
+    """Result type of `e` over `schema` (name -> Arrow type name)."""
+    if isinstance(e, Column):
+        if e.name not in schema:
+            raise KeyError(f"No field named '{e.name}'")
+        return schema[e.name]
+    if isinstance(e, Literal):
+        return e.dtype
+    if isinstance(e, BinaryExpr):
+        if e.op in ARITH_OPS:
+            return expr_type(e.left, schema)
+        return BOOLEAN
+    if isinstance(e, CastExpr):
+        return e.dtype
+    if isinstance(e, CaseExpr):
+        return expr_type(e.when_then[0][1], schema)
+    if isinstance(e, (NotExpr, IsNullExpr, IsNotNullExpr, InListExpr)):
+        return BOOLEAN
+    if isinstance(e, NegativeExpr):
+        return expr_type(e.expr, schema)
+    if isinstance(e, ScalarFunctionExpr):
+        return FLOAT64
+    raise TypeError(f"not a PhysicalExpr: {e!r}")
+
+
+def coerce(e: PhysicalExpr, schema: dict) -> PhysicalExpr:
+    """Insert the casts DataFusion's physical planner inserts so that both sides of every
+    BinaryExpr / InList / Case branch have one type (numeric literals and columns are
+    widened towards the higher-ranked side; e.g. Int64 literal 1 -> Float64)."""
+    def cast_to(x, t):
+        if expr_type(x, schema) == t:
+            return x
+        if isinstance(x, Literal) and x.value is not None and t in _NUMERIC_RANK:
+            v = float(x.value) if t == FLOAT64 else int(x.value)
+            return Literal(v, t)
+        return CastExpr(x, t)
+
+    def common(a, b):
+        if a == b:
+            return a
+        if a in _NUMERIC_RANK and b in _NUMERIC_RANK:
+            if DATE32 in (a, b):
+                return DATE32
+            return a if _NUMERIC_RANK[a] >= _NUMERIC_RANK[b] else b
+        raise TypeError(f"cannot coerce {a} and {b}")
+
+    if isinstance(e, BinaryExpr):
+        l, r = coerce(e.left, schema), coerce(e.right, schema)
+        if e.op in ARITH_OPS or e.op in COMPARE_OPS:
+            t = common(expr_type(l, schema), expr_type(r, schema))
+            l, r = cast_to(l, t), cast_to(r, t)
+        return BinaryExpr(l, e.op, r)
+    if isinstance(e, CastExpr):
+        return CastExpr(coerce(e.expr, schema), e.dtype)
+    if isinstance(e, NotExpr):
+        return NotExpr(coerce(e.expr, schema))
+    if isinstance(e, IsNullExpr):
+        return IsNullExpr(coerce(e.expr, schema))
+    if isinstance(e, IsNotNullExpr):
+        return IsNotNullExpr(coerce(e.expr, schema))
+    if isinstance(e, NegativeExpr):
+        return NegativeExpr(coerce(e.expr, schema))
+    if isinstance(e, InListExpr):
+        x = coerce(e.expr, schema)
+        t = expr_type(x, schema)
+        return InListExpr(x, [cast_to(coerce(v, schema), t) for v in e.list], e.negated)
+    if isinstance(e, CaseExpr):
+        base = coerce(e.expr, schema) if e.expr is not None else None
+        wt = [(coerce(w, schema), coerce(t, schema)) for w, t in e.when_then]
+        el = coerce(e.else_expr, schema) if e.else_expr is not None else None
+        t = expr_type(wt[0][1], schema)
+        for _, th in wt[1:]:
+            t = common(t, expr_type(th, schema))
+        if el is not None:
+            t = common(t, expr_type(el, schema))
+        wt = [(w if base is None else cast_to(w, expr_type(base, schema)), cast_to(th, t)) for w, th in wt]
+        return CaseExpr(base, wt, cast_to(el, t) if el is not None else None)
+    if isinstance(e, ScalarFunctionExpr):
+        return ScalarFunctionExpr(e.fun, [cast_to(coerce(a, schema), FLOAT64) for a in e.args])
+    return e

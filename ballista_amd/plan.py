@@ -1,0 +1,632 @@
+"""Host-side mirror of the operator interface a Ballista executor drives.
+
+`ExecutionPlan` here has the same five methods as DataFusion's trait as the reference uses it
+(rust/core/src/execution_plans/query_stage.rs:49-85): `schema()`, `output_partitioning()`,
+`children()`, `with_new_children()`, `execute(partition)` -> `RecordBatchStream`
+(rust/core/src/memory_stream.rs:57-92).  Operator constructors take their arguments in the
+order the physical-plan serde passes them (rust/core/src/serde/physical_plan/from_proto.rs:
+58-346).  All compute happens in libballista_hip.so through the C ABI; these classes only
+describe plans and move batches across the boundary.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterator, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib as L
+from . import expr as E
+
+DTYPE_ID = {E.INT32: 1, E.INT64: 2, E.UINT8: 3, E.UINT64: 4, E.FLOAT64: 5, E.DATE32: 6, E.BOOLEAN: 7, E.UTF8: 8}
+DTYPE_NAME = {v: k for k, v in DTYPE_ID.items()}
+NP_DTYPE = {E.INT32: np.int32, E.INT64: np.int64, E.UINT8: np.uint8, E.UINT64: np.uint64,
+            E.FLOAT64: np.float64, E.DATE32: np.int32}
+
+PARTIAL, FINAL = "Partial", "Final"
+INNER, LEFT, RIGHT = "Inner", "Left", "Right"
+
+
+class Partitioning:
+    """datafusion Partitioning::{UnknownPartitioning(n), RoundRobinBatch(n), Hash(exprs, n)}
+    (from_proto.rs:143-158)."""
+    UNKNOWN, ROUND_ROBIN, HASH = 0, 1, 2
+
+    def __init__(self, scheme, count, exprs=()):
+        self.scheme, self.count, self.exprs = scheme, count, list(exprs)
+
+    @staticmethod
+    def Hash(exprs, n): return Partitioning(Partitioning.HASH, n, exprs)
+    @staticmethod
+    def RoundRobinBatch(n): return Partitioning(Partitioning.ROUND_ROBIN, n)
+    @staticmethod
+    def UnknownPartitioning(n): return Partitioning(Partitioning.UNKNOWN, n)
+
+    def partition_count(self): return self.count
+
+    def __repr__(self):
+        return {0: "UnknownPartitioning", 1: "RoundRobinBatch", 2: "Hash"}[self.scheme] + f"({self.count})"
+
+
+class Context:
+    """One GPU (bhip_ctx)."""
+
+    def __init__(self, device: int = 0):
+        h = C.c_void_p()
+        L.check(L.lib().bhip_ctx_create(device, C.byref(h)))
+        self._h = h
+
+    def synchronize(self):
+        L.check(L.lib().bhip_ctx_synchronize(self._h))
+
+    def memory(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        L.check(L.lib().bhip_ctx_memory(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def kernel_time(self, reset=False):
+        ms, n = C.c_double(), C.c_uint64()
+        L.check(L.lib().bhip_ctx_kernel_time(self._h, 1 if reset else 0, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                L.lib().bhip_ctx_release(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+# ---- expression lowering: tree -> postfix bhip_expr_node[] -------------------------------------
+
+_EXPR_KIND = dict(COLUMN=1, LITERAL=2, BINARY=3, CAST=4, NOT=5, IS_NULL=6, IS_NOT_NULL=7, NEGATIVE=8,
+                  IN_LIST=9, CASE=10, SCALAR_FN=11)
+
+
+class _Lowered:
+    """owns the ctypes storage of lowered expressions until the C call returned"""
+
+    def __init__(self):
+        self.keep = []
+
+    def expr(self, e) -> L.Expr:
+        nodes = []
+        self._walk(e, nodes)
+        arr = (L.ExprNode * len(nodes))(*nodes)
+        self.keep.append(arr)
+        return L.Expr(C.cast(arr, C.POINTER(L.ExprNode)), len(nodes))
+
+    def exprs(self, es):
+        arr = (L.Expr * max(1, len(es)))(*[self.expr(e) for e in es])
+        self.keep.append(arr)
+        return arr
+
+    def strings(self, ss):
+        arr = (C.c_char_p * max(1, len(ss)))(*[s.encode() for s in ss])
+        self.keep.append(arr)
+        return arr
+
+    def _node(self, kind, dtype=0, n_args=0, flags=0, name=None, i64=0, f64=0.0):
+        b = name.encode() if name is not None else None
+        self.keep.append(b)
+        return L.ExprNode(_EXPR_KIND[kind], dtype, n_args, flags, b, i64, f64)
+
+    def _walk(self, e, out):
+        if isinstance(e, E.Column):
+            out.append(self._node("COLUMN", name=e.name))
+        elif isinstance(e, E.Literal):
+            dt = DTYPE_ID[e.dtype]
+            if e.value is None:
+                out.append(self._node("LITERAL", dtype=dt, flags=1))
+            elif e.dtype == E.UTF8:
+                out.append(self._node("LITERAL", dtype=dt, name=e.value))
+            elif e.dtype == E.FLOAT64:
+                out.append(self._node("LITERAL", dtype=dt, f64=float(e.value)))
+            elif e.dtype == E.UINT64:
+                v = int(e.value)
+                out.append(self._node("LITERAL", dtype=dt, i64=v - (1 << 64) if v >= (1 << 63) else v))
+            else:
+                out.append(self._node("LITERAL", dtype=dt, i64=int(e.value)))
+        elif isinstance(e, E.BinaryExpr):
+            self._walk(e.left, out)
+            self._walk(e.right, out)
+            out.append(self._node("BINARY", name=e.op))
+        elif isinstance(e, E.CastExpr):
+            self._walk(e.expr, out)
+            out.append(self._node("CAST", dtype=DTYPE_ID[e.dtype]))
+        elif isinstance(e, E.NotExpr):
+            self._walk(e.expr, out)
+            out.append(self._node("NOT"))
+        elif isinstance(e, E.IsNullExpr):
+            self._walk(e.expr, out)
+            out.append(self._node("IS_NULL"))
+        elif isinstance(e, E.IsNotNullExpr):
+            self._walk(e.expr, out)
+            out.append(self._node("IS_NOT_NULL"))
+        elif isinstance(e, E.NegativeExpr):
+            self._walk(e.expr, out)
+            out.append(self._node("NEGATIVE"))
+        elif isinstance(e, E.InListExpr):
+            self._walk(e.expr, out)
+            for item in e.list:
+                self._walk(item, out)
+            out.append(self._node("IN_LIST", n_args=len(e.list), flags=1 if e.negated else 0))
+        elif isinstance(e, E.CaseExpr):
+            flags = 0
+            if e.expr is not None:
+                self._walk(e.expr, out)
+                flags |= 1
+            for w, t in e.when_then:
+                self._walk(w, out)
+                self._walk(t, out)
+            if e.else_expr is not None:
+                self._walk(e.else_expr, out)
+                flags |= 2
+            out.append(self._node("CASE", n_args=len(e.when_then), flags=flags))
+        elif isinstance(e, E.ScalarFunctionExpr):
+            for a in e.args:
+                self._walk(a, out)
+            out.append(self._node("SCALAR_FN", n_args=len(e.args), name=e.fun))
+        else:
+            raise TypeError(f"not a PhysicalExpr: {e!r}")
+
+
+# ---- record batches ---------------------------------------------------------------------------------
+
+class RecordBatch:
+    """A device-resident Arrow RecordBatch (bhip_batch)."""
+
+    def __init__(self, handle, ctx: Context):
+        self._h = handle
+        self.ctx = ctx
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                L.lib().bhip_batch_release(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # -- constructors
+    @staticmethod
+    def from_columns(ctx: Context, columns) -> "RecordBatch":
+        """columns: list of (name, dtype, values, validity) — values: numpy array, or for Utf8 a list
+        of str / None-free str list; Boolean: bool array; validity: bool array or None."""
+        descs, keep, n_rows = [], [], None
+        for name, dtype, values, validity in columns:
+            d = L.ColumnDesc()
+            nb = name.encode()
+            keep.append(nb)
+            d.name = nb
+            d.dtype = DTYPE_ID[dtype]
+            d.nullable = 1 if validity is not None else 0
+            n = len(values)
+            n_rows = n if n_rows is None else n_rows
+            if n != n_rows:
+                raise ValueError("columns of different lengths")
+            if dtype == E.UTF8:
+                enc = [("" if s is None else s).encode() for s in values]
+                off = np.zeros(n + 1, np.int32)
+                if n:
+                    off[1:] = np.cumsum([len(b) for b in enc])
+                data = np.frombuffer(b"".join(enc) + b"\0", dtype=np.uint8).copy()
+                keep += [off, data]
+                d.offsets = off.ctypes.data
+                d.data = data.ctypes.data
+                d.data_bytes = int(off[-1])
+            elif dtype == E.BOOLEAN:
+                bits = np.packbits(np.asarray(values, np.bool_), bitorder="little")
+                bits = np.concatenate([bits, np.zeros(8, np.uint8)])
+                keep.append(bits)
+                d.data = bits.ctypes.data
+            else:
+                arr = np.ascontiguousarray(values, NP_DTYPE[dtype])
+                if arr.size == 0:
+                    arr = np.zeros(1, NP_DTYPE[dtype])
+                keep.append(arr)
+                d.data = arr.ctypes.data
+            if validity is not None:
+                vb = np.packbits(np.asarray(validity, np.bool_), bitorder="little")
+                vb = np.concatenate([vb, np.zeros(8, np.uint8)])
+                keep.append(vb)
+                d.validity = vb.ctypes.data
+            descs.append(d)
+        arr = (L.ColumnDesc * max(1, len(descs)))(*descs)
+        h = C.c_void_p()
+        L.check(L.lib().bhip_batch_from_host(ctx._h, len(descs), arr, n_rows or 0, C.byref(h)))
+        return RecordBatch(h, ctx)
+
+    @staticmethod
+    def from_pyarrow(ctx: Context, batch) -> "RecordBatch":
+        """through the Arrow C Data Interface (bhip_batch_import_arrow)"""
+        import pyarrow as pa
+        from pyarrow.cffi import ffi
+        if isinstance(batch, pa.Table):
+            batch = batch.combine_chunks().to_batches()[0] if batch.num_rows else pa.RecordBatch.from_pylist([], schema=batch.schema)
+        c_arr = ffi.new("struct ArrowArray*")
+        c_sch = ffi.new("struct ArrowSchema*")
+        batch._export_to_c(int(ffi.cast("uintptr_t", c_arr)), int(ffi.cast("uintptr_t", c_sch)))
+        h = C.c_void_p()
+        try:
+            L.check(L.lib().bhip_batch_import_arrow(ctx._h, int(ffi.cast("uintptr_t", c_arr)),
+                                                    int(ffi.cast("uintptr_t", c_sch)), C.byref(h)))
+        finally:
+            if c_arr.release != ffi.NULL:
+                c_arr.release(c_arr)
+            if c_sch.release != ffi.NULL:
+                c_sch.release(c_sch)
+        return RecordBatch(h, ctx)
+
+    # -- accessors
+    @property
+    def num_rows(self):
+        return L.lib().bhip_batch_num_rows(self._h)
+
+    @property
+    def num_columns(self):
+        return L.lib().bhip_batch_num_columns(self._h)
+
+    def memory_size(self):
+        return L.lib().bhip_batch_memory_size(self._h)
+
+    def column_info(self, i):
+        name, dt, nul, nbytes, hv = C.c_char_p(), C.c_int32(), C.c_int32(), C.c_int64(), C.c_int32()
+        L.check(L.lib().bhip_batch_column_info(self._h, i, C.byref(name), C.byref(dt), C.byref(nul), C.byref(nbytes), C.byref(hv)))
+        return name.value.decode(), DTYPE_NAME[dt.value], bool(nul.value), nbytes.value, bool(hv.value)
+
+    def schema(self):
+        return [(self.column_info(i)[0], self.column_info(i)[1]) for i in range(self.num_columns)]
+
+    def column_device(self, i):
+        d, o, v = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        L.check(L.lib().bhip_batch_column_device(self._h, i, C.byref(d), C.byref(o), C.byref(v)))
+        return d.value, o.value, v.value
+
+    def column(self, i):
+        """-> (dtype, values, validity): numpy values (Utf8: list of str), validity bool array or None"""
+        name, dtype, _, nbytes, has_valid = self.column_info(i)
+        n = self.num_rows
+        valid = None
+        vbuf = np.zeros((n + 7) // 8 + 8, np.uint8) if has_valid else None
+        if dtype == E.UTF8:
+            off = np.zeros(n + 1, np.int32)
+            data = np.zeros(max(1, nbytes), np.uint8)
+            L.check(L.lib().bhip_batch_column_to_host(self._h, i, data.ctypes.data, off.ctypes.data,
+                                                      vbuf.ctypes.data if has_valid else None))
+            raw = data.tobytes()
+            values = [raw[off[k]:off[k + 1]].decode() for k in range(n)]
+        elif dtype == E.BOOLEAN:
+            data = np.zeros((n + 7) // 8 + 8, np.uint8)
+            L.check(L.lib().bhip_batch_column_to_host(self._h, i, data.ctypes.data, None, vbuf.ctypes.data if has_valid else None))
+            values = np.unpackbits(data, bitorder="little")[:n].astype(np.bool_)
+        else:
+            values = np.zeros(max(1, n), NP_DTYPE[dtype])
+            L.check(L.lib().bhip_batch_column_to_host(self._h, i, values.ctypes.data, None, vbuf.ctypes.data if has_valid else None))
+            values = values[:n]
+        if has_valid:
+            valid = np.unpackbits(vbuf, bitorder="little")[:n].astype(np.bool_)
+        return dtype, values, valid
+
+    def to_pydict(self):
+        out = {}
+        for i in range(self.num_columns):
+            name = self.column_info(i)[0]
+            _, values, valid = self.column(i)
+            vals = [v.item() if hasattr(v, "item") else v for v in values]
+            if valid is not None:
+                vals = [v if ok else None for v, ok in zip(vals, valid)]
+            out[name] = vals
+        return out
+
+    def to_pyarrow(self):
+        """through the Arrow C Data Interface (bhip_batch_export_arrow)"""
+        import pyarrow as pa
+        from pyarrow.cffi import ffi
+        c_arr = ffi.new("struct ArrowArray*")
+        c_sch = ffi.new("struct ArrowSchema*")
+        L.check(L.lib().bhip_batch_export_arrow(self._h, int(ffi.cast("uintptr_t", c_arr)), int(ffi.cast("uintptr_t", c_sch))))
+        return pa.RecordBatch._import_from_c(int(ffi.cast("uintptr_t", c_arr)), int(ffi.cast("uintptr_t", c_sch)))
+
+
+class RecordBatchStream:
+    """bhip_stream: single-consumer iterator of RecordBatch."""
+
+    def __init__(self, handle, ctx):
+        self._h = handle
+        self.ctx = ctx
+
+    def schema(self):
+        return _read_schema(L.lib().bhip_stream_schema, self._h)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self) -> RecordBatch:
+        if not self._h:
+            raise StopIteration
+        b = C.c_void_p()
+        L.check(L.lib().bhip_stream_next(self._h, C.byref(b)))
+        if not b.value:
+            raise StopIteration
+        return RecordBatch(b, self.ctx)
+
+    def drain(self):
+        """utils::write_stream_to_disk's accounting (rust/core/src/utils.rs:49-84) -> PartitionStats"""
+        r, n, by = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        L.check(L.lib().bhip_stream_drain(self._h, None, None, C.byref(r), C.byref(n), C.byref(by)))
+        return dict(num_rows=r.value, num_batches=n.value, num_bytes=by.value)
+
+    def to_arrow_reader(self):
+        """hand the stream to pyarrow through the Arrow C Stream Interface (consumes it)"""
+        import pyarrow as pa
+        from pyarrow.cffi import ffi
+        c_stream = ffi.new("struct ArrowArrayStream*")
+        L.check(L.lib().bhip_stream_export_arrow(self._h, int(ffi.cast("uintptr_t", c_stream))))
+        self._h = None
+        return pa.RecordBatchReader._import_from_c(int(ffi.cast("uintptr_t", c_stream)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                L.lib().bhip_stream_release(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def _read_schema(fn, handle):
+    n = C.c_int32()
+    L.check(fn(handle, 0, None, None, None, C.byref(n)))
+    names = (C.c_char_p * max(1, n.value))()
+    dts = (C.c_int32 * max(1, n.value))()
+    nul = (C.c_int32 * max(1, n.value))()
+    L.check(fn(handle, n.value, names, dts, nul, C.byref(n)))
+    return [(names[i].decode(), DTYPE_NAME[dts[i]], bool(nul[i])) for i in range(n.value)]
+
+
+# ---- plans ---------------------------------------------------------------------------------------------
+
+class ExecutionPlan:
+    """datafusion::physical_plan::ExecutionPlan"""
+
+    def __init__(self, handle, ctx, children=()):
+        self._h = handle
+        self.ctx = ctx
+        self._children = list(children)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                L.lib().bhip_plan_release(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def as_any(self) -> str:
+        return L.lib().bhip_plan_name(self._h).decode()
+
+    def schema(self):
+        return _read_schema(L.lib().bhip_plan_schema, self._h)
+
+    def output_partitioning(self) -> Partitioning:
+        s, n = C.c_int32(), C.c_int32()
+        L.check(L.lib().bhip_plan_output_partitioning(self._h, C.byref(s), C.byref(n)))
+        return Partitioning(s.value, n.value)
+
+    def children(self) -> List["ExecutionPlan"]:
+        return list(self._children)
+
+    def with_new_children(self, children: Sequence["ExecutionPlan"]) -> "ExecutionPlan":
+        arr = (C.c_void_p * max(1, len(children)))(*[c._h for c in children])
+        h = C.c_void_p()
+        L.check(L.lib().bhip_plan_with_new_children(self._h, len(children), arr, C.byref(h)))
+        new = object.__new__(type(self))
+        new.__dict__.update(self.__dict__)
+        ExecutionPlan.__init__(new, h, self.ctx, children)
+        if len(children) == 1 and hasattr(self, "input"):
+            new.input = children[0]
+        if len(children) == 2 and hasattr(self, "left"):
+            new.left, new.right = children
+        return new
+
+    def execute(self, partition: int) -> RecordBatchStream:
+        h = C.c_void_p()
+        L.check(L.lib().bhip_plan_execute(self._h, partition, C.byref(h)))
+        return RecordBatchStream(h, self.ctx)
+
+    def collect(self) -> List[RecordBatch]:
+        out = []
+        for p in range(self.output_partitioning().partition_count()):
+            out.extend(self.execute(p))
+        return out
+
+    def display(self) -> str:
+        buf = C.create_string_buffer(16384)
+        L.check(L.lib().bhip_plan_display(self._h, buf, len(buf)))
+        return buf.value.decode()
+
+    def __repr__(self):
+        return self.display()
+
+
+class MemoryExec(ExecutionPlan):
+    """datafusion MemoryExec::try_new(partitions, schema, projection): partitions = list of lists of
+    RecordBatch.  Leaf standing in for CsvExec/ParquetExec/ShuffleReaderExec (from_proto.rs:93-121,
+    277-286), whose file / Flight decoding stays on the host."""
+
+    def __init__(self, partitions: Sequence[Sequence[RecordBatch]], ctx: Optional[Context] = None):
+        flat, offs = [], [0]
+        for p in partitions:
+            flat.extend(p)
+            offs.append(len(flat))
+        if not flat:
+            raise L.PlanError(L.EINVAL, "MemoryExec needs at least one batch")
+        ctx = ctx or flat[0].ctx
+        arr = (C.c_void_p * len(flat))(*[b._h for b in flat])
+        o = (C.c_int32 * len(offs))(*offs)
+        h = C.c_void_p()
+        L.check(L.lib().bhip_plan_memory(ctx._h, len(partitions), o, arr, C.byref(h)))
+        super().__init__(h, ctx)
+        self.partitions = [list(p) for p in partitions]
+
+
+class FilterExec(ExecutionPlan):
+    """FilterExec::try_new(predicate, input)  (from_proto.rs:81-92)"""
+
+    def __init__(self, predicate: E.PhysicalExpr, input: ExecutionPlan):
+        lw = _Lowered()
+        ex = lw.expr(predicate)
+        h = C.c_void_p()
+        L.check(L.lib().bhip_plan_filter(input._h, C.byref(ex), C.byref(h)))
+        super().__init__(h, input.ctx, [input])
+        self.predicate, self.input = predicate, input
+
+
+class ProjectionExec(ExecutionPlan):
+    """ProjectionExec::try_new(exprs: Vec<(expr, name)>, input)  (from_proto.rs:69-80)"""
+
+    def __init__(self, exprs: Sequence[Tuple[E.PhysicalExpr, str]], input: ExecutionPlan):
+        lw = _Lowered()
+        h = C.c_void_p()
+        L.check(L.lib().bhip_plan_projection(input._h, len(exprs), lw.exprs([e for e, _ in exprs]),
+                                             lw.strings([n for _, n in exprs]), C.byref(h)))
+        super().__init__(h, input.ctx, [input])
+        self.exprs, self.input = list(exprs), input
+
+
+class HashAggregateExec(ExecutionPlan):
+    """HashAggregateExec::try_new(mode, group_expr: Vec<(expr, name)>, aggr_expr, input)
+    (from_proto.rs:173-252)"""
+
+    _FN = {"SUM": 1, "AVG": 2, "COUNT": 3, "MIN": 4, "MAX": 5}
+
+    def __init__(self, mode: str, group_expr: Sequence[Tuple[E.PhysicalExpr, str]],
+                 aggr_expr: Sequence[E.AggregateExpr], input: ExecutionPlan):
+        if mode not in (PARTIAL, FINAL):
+            raise L.PlanError(L.EINVAL, f"Unsupported aggregate mode {mode}")
+        lw = _Lowered()
+        aggs = (L.Aggregate * max(1, len(aggr_expr)))()
+        for i, a in enumerate(aggr_expr):
+            nb = a.name.encode()
+            lw.keep.append(nb)
+            aggs[i] = L.Aggregate(self._FN[a.fun], lw.expr(a.expr), nb)
+        h = C.c_void_p()
+        L.check(L.lib().bhip_plan_hash_aggregate(input._h, 0 if mode == PARTIAL else 1, len(group_expr),
+                                                 lw.exprs([e for e, _ in group_expr]),
+                                                 lw.strings([n for _, n in group_expr]),
+                                                 len(aggr_expr), aggs, C.byref(h)))
+        super().__init__(h, input.ctx, [input])
+        self.mode, self.group_expr, self.aggr_expr, self.input = mode, list(group_expr), list(aggr_expr), input
+
+
+class HashJoinExec(ExecutionPlan):
+    """HashJoinExec::try_new(left, right, on: &[(String, String)], join_type)  (from_proto.rs:253-276);
+    left is the build side."""
+
+    _JT = {INNER: 0, LEFT: 1, RIGHT: 2}
+
+    def __init__(self, left: ExecutionPlan, right: ExecutionPlan, on: Sequence[Tuple[str, str]], join_type: str = INNER):
+        if join_type not in self._JT:
+            raise L.PlanError(L.EINVAL, f"Unsupported join type {join_type}")
+        lw = _Lowered()
+        h = C.c_void_p()
+        L.check(L.lib().bhip_plan_hash_join(left._h, right._h, len(on), lw.strings([a for a, _ in on]),
+                                            lw.strings([b for _, b in on]), self._JT[join_type], C.byref(h)))
+        super().__init__(h, left.ctx, [left, right])
+        self.left, self.right, self.on, self.join_type = left, right, list(on), join_type
+
+
+class SortExec(ExecutionPlan):
+    """SortExec::try_new(expr: Vec<PhysicalSortExpr>, input)  (from_proto.rs:291-331)"""
+
+    def __init__(self, expr: Sequence[E.PhysicalSortExpr], input: ExecutionPlan):
+        lw = _Lowered()
+        arr = (L.SortExprC * max(1, len(expr)))()
+        for i, s in enumerate(expr):
+            arr[i] = L.SortExprC(lw.expr(s.expr), 1 if s.descending else 0, 1 if s.nulls_first else 0)
+        h = C.c_void_p()
+        L.check(L.lib().bhip_plan_sort(input._h, len(expr), arr, C.byref(h)))
+        super().__init__(h, input.ctx, [input])
+        self.expr, self.input = list(expr), input
+
+
+class RepartitionExec(ExecutionPlan):
+    """RepartitionExec::try_new(input, partitioning)  (from_proto.rs:133-164)"""
+
+    def __init__(self, input: ExecutionPlan, partitioning: Partitioning):
+        lw = _Lowered()
+        h = C.c_void_p()
+        L.check(L.lib().bhip_plan_repartition(input._h, partitioning.scheme, len(partitioning.exprs),
+                                              lw.exprs(partitioning.exprs), partitioning.count, C.byref(h)))
+        super().__init__(h, input.ctx, [input])
+        self.input, self.partitioning = input, partitioning
+
+
+class CoalesceBatchesExec(ExecutionPlan):
+    """CoalesceBatchesExec::new(input, target_batch_size)  (from_proto.rs:122-128)"""
+
+    def __init__(self, input: ExecutionPlan, target_batch_size: int):
+        h = C.c_void_p()
+        L.check(L.lib().bhip_plan_coalesce_batches(input._h, target_batch_size, C.byref(h)))
+        super().__init__(h, input.ctx, [input])
+        self.input, self.target_batch_size = input, target_batch_size
+
+
+class MergeExec(ExecutionPlan):
+    """MergeExec::new(input)  (from_proto.rs:129-132)"""
+
+    def __init__(self, input: ExecutionPlan):
+        h = C.c_void_p()
+        L.check(L.lib().bhip_plan_merge(input._h, C.byref(h)))
+        super().__init__(h, input.ctx, [input])
+        self.input = input
+
+
+class GlobalLimitExec(ExecutionPlan):
+    """GlobalLimitExec::new(input, limit, concurrency)  (from_proto.rs:165-168)"""
+
+    def __init__(self, input: ExecutionPlan, limit: int):
+        h = C.c_void_p()
+        L.check(L.lib().bhip_plan_global_limit(input._h, limit, C.byref(h)))
+        super().__init__(h, input.ctx, [input])
+        self.input, self.limit = input, limit
+
+
+class LocalLimitExec(ExecutionPlan):
+    """LocalLimitExec::new(input, limit)  (from_proto.rs:169-172)"""
+
+    def __init__(self, input: ExecutionPlan, limit: int):
+        h = C.c_void_p()
+        L.check(L.lib().bhip_plan_local_limit(input._h, limit, C.byref(h)))
+        super().__init__(h, input.ctx, [input])
+        self.input, self.limit = input, limit
+
+
+# ---- batch-level helpers used by the multi-GPU exchange ---------------------------------------------------
+
+def hash_partition(batch: RecordBatch, exprs: Sequence[E.PhysicalExpr], n: int) -> List[RecordBatch]:
+    lw = _Lowered()
+    out = (C.c_void_p * n)()
+    L.check(L.lib().bhip_batch_hash_partition(batch._h, len(exprs), lw.exprs(exprs), n, out))
+    return [RecordBatch(C.c_void_p(out[i]), batch.ctx) for i in range(n)]
+
+
+def concat(ctx: Context, batches: Sequence[RecordBatch]) -> RecordBatch:
+    arr = (C.c_void_p * len(batches))(*[b._h for b in batches])
+    h = C.c_void_p()
+    L.check(L.lib().bhip_batch_concat(ctx._h, len(batches), arr, C.byref(h)))
+    return RecordBatch(h, ctx)
+
+
+def tpch_lineitem(ctx: Context, sf: float, seed: int, row0: int, n: int, key64=False, with_dates=False) -> RecordBatch:
+    h = C.c_void_p()
+    L.check(L.lib().bhip_tpch_lineitem(ctx._h, sf, seed, row0, n, 1 if key64 else 0, 1 if with_dates else 0, C.byref(h)))
+    return RecordBatch(h, ctx)
+
+
+def tpch_orders(ctx: Context, sf: float, seed: int, row0: int, n: int, key64=False) -> RecordBatch:
+    h = C.c_void_p()
+    L.check(L.lib().bhip_tpch_orders(ctx._h, sf, seed, row0, n, 1 if key64 else 0, C.byref(h)))
+    return RecordBatch(h, ctx)

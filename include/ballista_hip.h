@@ -1,0 +1,300 @@
+/*
+ * ballista_hip.h — C ABI of libballista_hip.so, the MI355X-native physical execution layer
+ * that drops in underneath a Ballista executor.
+ *
+ * What it replaces.  A Ballista executor runs one call per task,
+ *     partition.plan.execute(part)          rust/executor/src/flight_service.rs:117-121
+ * on a tree of DataFusion operators rebuilt from the wire plan
+ *     rust/core/src/serde/physical_plan/from_proto.rs:58-346  (operators)
+ *     rust/core/src/serde/physical_plan/from_proto.rs:348-364 (compile_expr)
+ * and drains the resulting RecordBatchStream (rust/core/src/utils.rs:49-84).  The trait it
+ * calls through is DataFusion's `ExecutionPlan` as visible in the reference's own
+ * implementations (rust/core/src/execution_plans/query_stage.rs:49-85):
+ *     schema(), output_partitioning(), children(), with_new_children(), execute(partition)
+ * and `RecordBatchStream` (rust/core/src/memory_stream.rs:57-92).  Every entry point below
+ * names the reference interface it stands in for.  A Rust `GpuExec: ExecutionPlan` shim binds
+ * these with `extern "C"` (INTEGRATION.md shows the binding).
+ *
+ * Conventions:
+ *   - every function returns a bhip_status; 0 = OK.  Nothing aborts or throws across the ABI;
+ *     the message of the last failure on the calling thread is bhip_last_error().
+ *   - BHIP_ENOTIMPL means "this plan/expression/type is outside the GPU path": the caller keeps
+ *     its CPU operator for that subtree (there is NO CPU fallback inside this library).
+ *   - handles are reference counted and immutable after creation; plans may be shared between
+ *     threads and executed concurrently (the executor runs `concurrent_tasks` tasks at once,
+ *     rust/executor/executor_config_spec.toml:57-62); a stream is single-consumer.
+ *   - batches cross the boundary as Arrow C Data Interface structs (host memory) or stay
+ *     device-resident (bhip_batch) between chained GPU operators.
+ *   - strings are UTF-8, NUL terminated, and are copied; arrays are copied.
+ */
+#ifndef BALLISTA_HIP_H
+#define BALLISTA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- Arrow C Data / C Stream interface (https://arrow.apache.org/docs/format/CDataInterface.html) */
+#ifndef ARROW_C_DATA_INTERFACE
+#define ARROW_C_DATA_INTERFACE
+#define ARROW_FLAG_DICTIONARY_ORDERED 1
+#define ARROW_FLAG_NULLABLE 2
+#define ARROW_FLAG_MAP_KEYS_SORTED 4
+struct ArrowSchema {
+    const char* format;
+    const char* name;
+    const char* metadata;
+    int64_t flags;
+    int64_t n_children;
+    struct ArrowSchema** children;
+    struct ArrowSchema* dictionary;
+    void (*release)(struct ArrowSchema*);
+    void* private_data;
+};
+struct ArrowArray {
+    int64_t length;
+    int64_t null_count;
+    int64_t offset;
+    int64_t n_buffers;
+    int64_t n_children;
+    const void** buffers;
+    struct ArrowArray** children;
+    struct ArrowArray* dictionary;
+    void (*release)(struct ArrowArray*);
+    void* private_data;
+};
+#endif
+#ifndef ARROW_C_STREAM_INTERFACE
+#define ARROW_C_STREAM_INTERFACE
+struct ArrowArrayStream {
+    int (*get_schema)(struct ArrowArrayStream*, struct ArrowSchema* out);
+    int (*get_next)(struct ArrowArrayStream*, struct ArrowArray* out);
+    const char* (*get_last_error)(struct ArrowArrayStream*);
+    void (*release)(struct ArrowArrayStream*);
+    void* private_data;
+};
+#endif
+
+/* ---- status ---------------------------------------------------------------------------
+ * mirrors the error kinds the executor maps to tonic::Status::internal
+ * (rust/executor/src/flight_service.rs:344-354; rust/core/src/error.rs:30-163) */
+typedef int32_t bhip_status;
+enum {
+    BHIP_OK = 0,
+    BHIP_EINVAL = 1,     /* DataFusionError::Plan / Internal: malformed plan, unknown column, type mismatch */
+    BHIP_ENOTIMPL = 2,   /* DataFusionError::NotImplemented: keep the CPU operator */
+    BHIP_EEXEC = 3,      /* DataFusionError::Execution / ArrowError: e.g. "Divide by zero error" */
+    BHIP_EHIP = 4,       /* a HIP runtime call failed (message carries hipGetErrorString) */
+    BHIP_EOOM = 5        /* device allocation failed */
+};
+const char* bhip_last_error(void);
+const char* bhip_version(void);
+
+/* ---- types (Arrow types of the TPC-H schemas, rust/benchmarks/tpch/src/main.rs:267-360) */
+typedef enum {
+    BHIP_INT32 = 1, BHIP_INT64 = 2, BHIP_UINT8 = 3, BHIP_UINT64 = 4, BHIP_FLOAT64 = 5,
+    BHIP_DATE32 = 6, BHIP_BOOLEAN = 7, BHIP_UTF8 = 8
+} bhip_dtype;
+
+typedef struct bhip_ctx bhip_ctx;        /* one GPU: allocator, stream pool */
+typedef struct bhip_batch bhip_batch;    /* device-resident RecordBatch */
+typedef struct bhip_plan bhip_plan;      /* Arc<dyn ExecutionPlan> */
+typedef struct bhip_stream bhip_stream;  /* Pin<Box<dyn RecordBatchStream>> */
+
+/* ---- context ------------------------------------------------------------------------------ */
+bhip_status bhip_ctx_create(int device, bhip_ctx** out);
+void bhip_ctx_release(bhip_ctx* ctx);
+bhip_status bhip_ctx_synchronize(bhip_ctx* ctx);
+/* bytes currently held / high-water mark of the context's device allocator */
+bhip_status bhip_ctx_memory(bhip_ctx* ctx, uint64_t* in_use, uint64_t* peak);
+
+/* ---- batches ------------------------------------------------------------------------------
+ * RecordBatch (columns are immutable, shared buffers).  Host constructors copy to the device;
+ * bhip_batch_from_device adopts device pointers without copying (caller keeps them alive and
+ * unchanged until the batch is released).  Layout per column = Arrow: fixed-width values, or
+ * Utf8 int32 offsets (length+1) + bytes, Boolean = bitmap; validity bitmap optional (NULL =
+ * no nulls); offset must be 0 for device columns. */
+typedef struct {
+    const char* name;
+    int32_t dtype;            /* bhip_dtype */
+    int32_t nullable;         /* schema nullability */
+    const void* data;         /* values | Utf8 bytes | Boolean bitmap */
+    const int32_t* offsets;   /* Utf8 only */
+    const uint8_t* validity;  /* Arrow validity bitmap or NULL */
+    int64_t data_bytes;       /* Utf8: number of value bytes; else ignored */
+} bhip_column_desc;
+
+bhip_status bhip_batch_from_host(bhip_ctx* ctx, int32_t n_cols, const bhip_column_desc* cols, int64_t n_rows,
+                                 bhip_batch** out);
+bhip_status bhip_batch_from_device(bhip_ctx* ctx, int32_t n_cols, const bhip_column_desc* cols, int64_t n_rows,
+                                   bhip_batch** out);
+/* Arrow C Data Interface: `array` is a struct array (one child per column) as produced by
+ * RecordBatch export; it is consumed (released) on success. */
+bhip_status bhip_batch_import_arrow(bhip_ctx* ctx, struct ArrowArray* array, struct ArrowSchema* schema,
+                                    bhip_batch** out);
+/* copies the batch to host memory and exports it; the caller releases out_array/out_schema. */
+bhip_status bhip_batch_export_arrow(bhip_batch* batch, struct ArrowArray* out_array, struct ArrowSchema* out_schema);
+void bhip_batch_retain(bhip_batch* batch);
+void bhip_batch_release(bhip_batch* batch);
+int64_t bhip_batch_num_rows(const bhip_batch* batch);
+int32_t bhip_batch_num_columns(const bhip_batch* batch);
+/* column metadata; `name` stays valid while the batch lives */
+bhip_status bhip_batch_column_info(const bhip_batch* batch, int32_t i, const char** name, int32_t* dtype,
+                                   int32_t* nullable, int64_t* data_bytes, int32_t* has_validity);
+/* raw device pointers of column i (for zero-copy consumers, e.g. an RCCL exchange) */
+bhip_status bhip_batch_column_device(const bhip_batch* batch, int32_t i, const void** data, const int32_t** offsets,
+                                     const uint8_t** validity);
+/* copy column i to caller-provided host buffers (any of the three may be NULL) */
+bhip_status bhip_batch_column_to_host(const bhip_batch* batch, int32_t i, void* data, int32_t* offsets, uint8_t* validity);
+/* ArrayRef::get_array_memory_size summed over columns — the num_bytes of PartitionStats
+ * (rust/core/src/utils.rs:60-83) */
+int64_t bhip_batch_memory_size(const bhip_batch* batch);
+
+/* ---- physical expressions ---------------------------------------------------------------
+ * A flat POSTFIX program of nodes mirroring the expression kinds the physical-plan serde can
+ * ship (rust/core/src/serde/physical_plan/to_proto.rs:380-511; LogicalExprNode,
+ * rust/core/proto/ballista.proto:14-45).  Binary operators are named by the wire strings of
+ * rust/core/src/serde/logical_plan/from_proto.rs:937-957 ("And" "Or" "Eq" "NotEq" "LtEq" "Lt"
+ * "Gt" "GtEq" "Plus" "Minus" "Multiply" "Divide" "Like" "NotLike"). */
+typedef enum {
+    BHIP_EXPR_COLUMN = 1,      /* name                                  pushes 1            */
+    BHIP_EXPR_LITERAL = 2,     /* dtype + value (is_null: typed NULL)   pushes 1            */
+    BHIP_EXPR_BINARY = 3,      /* op ; pops right, left                                     */
+    BHIP_EXPR_CAST = 4,        /* dtype ; pops 1                                            */
+    BHIP_EXPR_NOT = 5,
+    BHIP_EXPR_IS_NULL = 6,
+    BHIP_EXPR_IS_NOT_NULL = 7,
+    BHIP_EXPR_NEGATIVE = 8,
+    BHIP_EXPR_IN_LIST = 9,     /* n_args list items + 1 ; negated       pops n_args+1       */
+    BHIP_EXPR_CASE = 10,       /* n_args = #when/then pairs; flags bit0: has base expr,
+                                  bit1: has else.  Stack order: [base] w1 t1 ... wn tn [else] */
+    BHIP_EXPR_SCALAR_FN = 11   /* name = function ("sqrt", "abs", ...) ; n_args             */
+} bhip_expr_kind;
+
+typedef struct {
+    int32_t kind;            /* bhip_expr_kind */
+    int32_t dtype;           /* LITERAL / CAST */
+    int32_t n_args;
+    int32_t flags;           /* LITERAL: bit0 = is_null ; IN_LIST: bit0 = negated ; CASE: see above */
+    const char* name;        /* COLUMN name / BINARY operator / SCALAR_FN name / Utf8 literal */
+    int64_t i64;             /* integer, Date32, Boolean literal */
+    double f64;              /* Float64 literal */
+} bhip_expr_node;
+
+typedef struct {
+    const bhip_expr_node* nodes;
+    int32_t n_nodes;
+} bhip_expr;
+
+/* AggregateExpr (to_proto.rs:348-378: Sum / Avg / Count are what the serde ships; Min / Max are
+ * accepted too) */
+typedef enum { BHIP_AGG_SUM = 1, BHIP_AGG_AVG = 2, BHIP_AGG_COUNT = 3, BHIP_AGG_MIN = 4, BHIP_AGG_MAX = 5 } bhip_agg_fn;
+typedef struct {
+    int32_t fn;              /* bhip_agg_fn */
+    bhip_expr arg;
+    const char* name;        /* output field name */
+} bhip_aggregate;
+
+/* PhysicalSortExpr (ballista.proto PhysicalSortExprNode) */
+typedef struct {
+    bhip_expr expr;
+    int32_t descending;
+    int32_t nulls_first;
+} bhip_sort_expr;
+
+typedef enum { BHIP_AGG_PARTIAL = 0, BHIP_AGG_FINAL = 1 } bhip_agg_mode;       /* from_proto.rs:181-184 */
+typedef enum { BHIP_JOIN_INNER = 0, BHIP_JOIN_LEFT = 1, BHIP_JOIN_RIGHT = 2 } bhip_join_type; /* :268-272 */
+typedef enum {                                                                /* from_proto.rs:143-158 */
+    BHIP_PART_UNKNOWN = 0, BHIP_PART_ROUND_ROBIN = 1, BHIP_PART_HASH = 2
+} bhip_partitioning;
+
+/* ---- plans: one constructor per operator the serde can build (from_proto.rs line cited) ----
+ * Constructors take a reference on their inputs; the caller still releases its own. */
+/* leaf: in-memory partitions (datafusion MemoryExec; stands in for CsvExec/ParquetExec
+ * :93-121 and ShuffleReaderExec :277-286 whose decoding stays on the host side).
+ * batches[offsets[p] .. offsets[p+1]) are the batches of partition p. */
+bhip_status bhip_plan_memory(bhip_ctx* ctx, int32_t n_partitions, const int32_t* offsets, bhip_batch* const* batches,
+                             bhip_plan** out);
+/* EmptyExec :287-290 — schema given as column descs with NULL data */
+bhip_status bhip_plan_empty(bhip_ctx* ctx, int32_t n_cols, const bhip_column_desc* schema, int32_t produce_one_row,
+                            bhip_plan** out);
+bhip_status bhip_plan_filter(bhip_plan* input, const bhip_expr* predicate, bhip_plan** out);          /* :81-92  */
+bhip_status bhip_plan_projection(bhip_plan* input, int32_t n, const bhip_expr* exprs, const char* const* names,
+                                 bhip_plan** out);                                                   /* :69-80  */
+bhip_status bhip_plan_hash_aggregate(bhip_plan* input, int32_t mode, int32_t n_group, const bhip_expr* group_exprs,
+                                     const char* const* group_names, int32_t n_aggr, const bhip_aggregate* aggr,
+                                     bhip_plan** out);                                               /* :173-252 */
+bhip_status bhip_plan_hash_join(bhip_plan* left, bhip_plan* right, int32_t n_on, const char* const* left_keys,
+                                const char* const* right_keys, int32_t join_type, bhip_plan** out);  /* :253-276 */
+bhip_status bhip_plan_sort(bhip_plan* input, int32_t n, const bhip_sort_expr* exprs, bhip_plan** out); /* :291-331 */
+bhip_status bhip_plan_repartition(bhip_plan* input, int32_t scheme, int32_t n_exprs, const bhip_expr* hash_exprs,
+                                  int32_t partition_count, bhip_plan** out);                         /* :133-164 */
+bhip_status bhip_plan_coalesce_batches(bhip_plan* input, int64_t target_batch_size, bhip_plan** out);  /* :122-128 */
+bhip_status bhip_plan_merge(bhip_plan* input, bhip_plan** out);                                       /* :129-132 */
+bhip_status bhip_plan_global_limit(bhip_plan* input, int64_t limit, bhip_plan** out);                 /* :165-168 */
+bhip_status bhip_plan_local_limit(bhip_plan* input, int64_t limit, bhip_plan** out);                  /* :169-172 */
+
+void bhip_plan_retain(bhip_plan* plan);
+void bhip_plan_release(bhip_plan* plan);
+
+/* ---- ExecutionPlan trait (query_stage.rs:49-85) ---------------------------------------------- */
+/* as_any(): the operator's type name, e.g. "HashAggregateExec" */
+const char* bhip_plan_name(const bhip_plan* plan);
+/* schema(): fills up to `cap` entries, *n_cols = total number */
+bhip_status bhip_plan_schema(const bhip_plan* plan, int32_t cap, const char** names, int32_t* dtypes,
+                             int32_t* nullable, int32_t* n_cols);
+/* output_partitioning() */
+bhip_status bhip_plan_output_partitioning(const bhip_plan* plan, int32_t* scheme, int32_t* partition_count);
+/* children(): borrowed handles */
+bhip_status bhip_plan_children(const bhip_plan* plan, int32_t cap, bhip_plan** children, int32_t* n_children);
+/* with_new_children() */
+bhip_status bhip_plan_with_new_children(const bhip_plan* plan, int32_t n, bhip_plan* const* children, bhip_plan** out);
+/* async execute(partition) -> stream.  Blocking (wrap in spawn_blocking); re-entrant. */
+bhip_status bhip_plan_execute(bhip_plan* plan, int32_t partition, bhip_stream** out);
+/* Debug-style one-line-per-operator rendering (utils.rs:96-188 pretty printer) */
+bhip_status bhip_plan_display(const bhip_plan* plan, char* buf, size_t cap);
+
+/* ---- RecordBatchStream (memory_stream.rs:57-92) ------------------------------------------- */
+/* stream.next(): *out = NULL at end of stream */
+bhip_status bhip_stream_next(bhip_stream* stream, bhip_batch** out);
+bhip_status bhip_stream_schema(const bhip_stream* stream, int32_t cap, const char** names, int32_t* dtypes,
+                               int32_t* nullable, int32_t* n_cols);
+void bhip_stream_release(bhip_stream* stream);
+/* hands the stream to an Arrow C Stream consumer (batches are copied to host as they are pulled);
+ * the bhip_stream is consumed. */
+bhip_status bhip_stream_export_arrow(bhip_stream* stream, struct ArrowArrayStream* out);
+/* drains a stream like utils::write_stream_to_disk (rust/core/src/utils.rs:49-84) and reports
+ * PartitionStats{num_rows,num_batches,num_bytes}; batches are handed to `sink` (may be NULL). */
+typedef bhip_status (*bhip_batch_sink)(void* user, bhip_batch* batch);
+bhip_status bhip_stream_drain(bhip_stream* stream, bhip_batch_sink sink, void* user, uint64_t* num_rows,
+                              uint64_t* num_batches, uint64_t* num_bytes);
+
+/* ---- hash repartition exchange support (RepartitionExec(Hash) across GPUs) -----------------
+ * The per-row partition id is  bhip_row_hash(key columns) % n  (DESIGN.md "Row hash").  These
+ * two calls split a device batch into n device batches (partition p = rows whose id is p, input
+ * order kept) so the caller can exchange them (RCCL all-to-all) — used by the multi-GPU path. */
+bhip_status bhip_batch_hash_partition(bhip_batch* batch, int32_t n_exprs, const bhip_expr* hash_exprs, int32_t n,
+                                      bhip_batch** out /* n handles */);
+bhip_status bhip_batch_concat(bhip_ctx* ctx, int32_t n, bhip_batch* const* batches, bhip_batch** out);
+
+/* ---- synthetic TPC-H data (bench / tests) -------------------------------------------------- */
+/* lineitem rows [row0,row0+n) at scale factor `sf` generated on the device; key64: Int64 order keys
+ * (SF1000).  Columns: l_orderkey l_suppkey l_quantity l_extendedprice l_discount l_tax
+ * l_returnflag l_linestatus l_shipdate [l_commitdate l_receiptdate when with_dates]. */
+bhip_status bhip_tpch_lineitem(bhip_ctx* ctx, double sf, uint64_t seed, uint64_t row0, uint64_t n, int32_t key64,
+                               int32_t with_dates, bhip_batch** out);
+bhip_status bhip_tpch_orders(bhip_ctx* ctx, double sf, uint64_t seed, uint64_t row0, uint64_t n, int32_t key64,
+                             bhip_batch** out);
+
+/* ---- measurement hooks --------------------------------------------------------------------- */
+/* time (ms, HIP events on the stream the kernels ran on) and launch count of the dominant scan
+ * kernel accumulated on this context since the last reset */
+bhip_status bhip_ctx_kernel_time(bhip_ctx* ctx, int32_t reset, double* ms, uint64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BALLISTA_HIP_H */

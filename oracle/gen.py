@@ -1,0 +1,225 @@
+"""TEST INFRASTRUCTURE — ctypes front-end for oracle/tpch_gen.c (CPU twin of the HIP
+synthetic TPC-H generator) and for the threaded Q1/Q6 stage-1 port in oracle_ops.c
+(bench.py's cpu_baseline, kind "port").  See oracle/__init__.py."""
+from __future__ import annotations
+
+import ctypes
+from collections import OrderedDict
+
+import numpy as np
+
+from .engine import OCol, lib
+
+SEED = 0x7C4A_0BA1_1157_A001
+
+# TPC-H cardinalities; lineitem counts are dbgen's for SF1 / SF100
+_LINEITEM_ROWS = {1: 6_001_215, 100: 600_037_902}
+
+
+def cardinalities(sf: float):
+    n_orders = max(7, int(round(1_500_000 * sf)))
+    return {
+        "orders": n_orders,
+        "lineitem": _LINEITEM_ROWS.get(sf, 4 * n_orders),
+        "customer": max(3, int(round(150_000 * sf))),
+        "supplier": max(1, int(round(10_000 * sf))),
+        "part": max(1, int(round(200_000 * sf))),
+    }
+
+
+def _p(a, ct):
+    return a.ctypes.data_as(ctypes.POINTER(ct)) if a is not None else None
+
+
+def lineitem_arrays(sf=0.001, row0=0, n=None, seed=SEED, key64=False, dates=False):
+    """raw numpy arrays of lineitem rows [row0, row0+n)"""
+    card = cardinalities(sf)
+    if n is None:
+        n = card["lineitem"] - row0
+    a = OrderedDict()
+    a["l_orderkey"] = np.empty(n, np.int64 if key64 else np.int32)
+    a["l_suppkey"] = np.empty(n, np.int32)
+    for k in ("l_quantity", "l_extendedprice", "l_discount", "l_tax"):
+        a[k] = np.empty(n, np.float64)
+    a["l_shipdate"] = np.empty(n, np.int32)
+    commit = np.empty(n, np.int32) if dates else None
+    receipt = np.empty(n, np.int32) if dates else None
+    a["l_returnflag.off"] = np.empty(n + 1, np.int32)
+    a["l_returnflag.data"] = np.empty(n, np.uint8)
+    a["l_linestatus.off"] = np.empty(n + 1, np.int32)
+    a["l_linestatus.data"] = np.empty(n, np.uint8)
+    lib().tpch_gen_lineitem(
+        ctypes.c_uint64(seed), ctypes.c_uint64(row0), ctypes.c_uint64(n),
+        ctypes.c_uint64(card["orders"]), ctypes.c_uint64(card["part"]), ctypes.c_uint64(card["supplier"]),
+        None if key64 else _p(a["l_orderkey"], ctypes.c_int32),
+        _p(a["l_orderkey"], ctypes.c_int64) if key64 else None,
+        _p(a["l_suppkey"], ctypes.c_int32),
+        _p(a["l_quantity"], ctypes.c_double), _p(a["l_extendedprice"], ctypes.c_double),
+        _p(a["l_discount"], ctypes.c_double), _p(a["l_tax"], ctypes.c_double),
+        _p(a["l_shipdate"], ctypes.c_int32), _p(commit, ctypes.c_int32), _p(receipt, ctypes.c_int32),
+        _p(a["l_returnflag.off"], ctypes.c_int32), _p(a["l_returnflag.data"], ctypes.c_uint8),
+        _p(a["l_linestatus.off"], ctypes.c_int32), _p(a["l_linestatus.data"], ctypes.c_uint8))
+    if dates:
+        a["l_commitdate"] = commit
+        a["l_receiptdate"] = receipt
+    return a
+
+
+def _utf8_from(off, data):
+    b = data.tobytes()
+    return [b[off[i]:off[i + 1]].decode() for i in range(len(off) - 1)]
+
+
+def lineitem(sf=0.001, row0=0, n=None, seed=SEED, key64=False):
+    a = lineitem_arrays(sf, row0, n, seed, key64)
+    out = OrderedDict()
+    out["l_orderkey"] = OCol("Int64" if key64 else "Int32", a["l_orderkey"])
+    out["l_suppkey"] = OCol("Int32", a["l_suppkey"])
+    for k in ("l_quantity", "l_extendedprice", "l_discount", "l_tax"):
+        out[k] = OCol("Float64", a[k])
+    out["l_returnflag"] = OCol("Utf8", _utf8_from(a["l_returnflag.off"], a["l_returnflag.data"]))
+    out["l_linestatus"] = OCol("Utf8", _utf8_from(a["l_linestatus.off"], a["l_linestatus.data"]))
+    out["l_shipdate"] = OCol("Date32", a["l_shipdate"])
+    return out
+
+
+def orders_arrays(sf=0.001, row0=0, n=None, seed=SEED, key64=False):
+    card = cardinalities(sf)
+    if n is None:
+        n = card["orders"] - row0
+    a = OrderedDict()
+    a["o_orderkey"] = np.empty(n, np.int64 if key64 else np.int32)
+    a["o_custkey"] = np.empty(n, np.int32)
+    a["o_orderdate"] = np.empty(n, np.int32)
+    a["o_shippriority"] = np.empty(n, np.int32)
+    lib().tpch_gen_orders(ctypes.c_uint64(seed), ctypes.c_uint64(row0), ctypes.c_uint64(n),
+                          ctypes.c_uint64(card["customer"]),
+                          None if key64 else _p(a["o_orderkey"], ctypes.c_int32),
+                          _p(a["o_orderkey"], ctypes.c_int64) if key64 else None,
+                          _p(a["o_custkey"], ctypes.c_int32), _p(a["o_orderdate"], ctypes.c_int32),
+                          _p(a["o_shippriority"], ctypes.c_int32))
+    return a
+
+
+def orders(sf=0.001, seed=SEED, key64=False):
+    a = orders_arrays(sf, seed=seed, key64=key64)
+    return OrderedDict([
+        ("o_orderkey", OCol("Int64" if key64 else "Int32", a["o_orderkey"])),
+        ("o_custkey", OCol("Int32", a["o_custkey"])),
+        ("o_orderdate", OCol("Date32", a["o_orderdate"])),
+        ("o_shippriority", OCol("Int32", a["o_shippriority"]))])
+
+
+def customer_arrays(sf=0.001, seed=SEED):
+    n = cardinalities(sf)["customer"]
+    a = OrderedDict()
+    a["c_custkey"] = np.empty(n, np.int32)
+    a["c_nationkey"] = np.empty(n, np.int32)
+    a["c_mktsegment.off"] = np.empty(n + 1, np.int32)
+    data = np.empty(10 * n, np.uint8)
+    L = lib()
+    L.tpch_gen_customer.restype = ctypes.c_uint64
+    used = L.tpch_gen_customer(ctypes.c_uint64(seed), ctypes.c_uint64(n),
+                               _p(a["c_custkey"], ctypes.c_int32), _p(a["c_nationkey"], ctypes.c_int32),
+                               _p(a["c_mktsegment.off"], ctypes.c_int32), _p(data, ctypes.c_uint8))
+    a["c_mktsegment.data"] = data[:used].copy()
+    return a
+
+
+def customer(sf=0.001, seed=SEED):
+    a = customer_arrays(sf, seed)
+    return OrderedDict([
+        ("c_custkey", OCol("Int32", a["c_custkey"])),
+        ("c_nationkey", OCol("Int32", a["c_nationkey"])),
+        ("c_mktsegment", OCol("Utf8", _utf8_from(a["c_mktsegment.off"], a["c_mktsegment.data"])))])
+
+
+def supplier_arrays(sf=0.001, seed=SEED):
+    n = cardinalities(sf)["supplier"]
+    a = OrderedDict([("s_suppkey", np.empty(n, np.int32)), ("s_nationkey", np.empty(n, np.int32))])
+    lib().tpch_gen_supplier(ctypes.c_uint64(seed), ctypes.c_uint64(n),
+                            _p(a["s_suppkey"], ctypes.c_int32), _p(a["s_nationkey"], ctypes.c_int32))
+    return a
+
+
+def supplier(sf=0.001, seed=SEED):
+    a = supplier_arrays(sf, seed)
+    return OrderedDict([("s_suppkey", OCol("Int32", a["s_suppkey"])),
+                        ("s_nationkey", OCol("Int32", a["s_nationkey"]))])
+
+
+# the 25 nations / 5 regions of the TPC-H spec, in the format of the reference's fixtures
+# (rust/scheduler/testdata/nation/nation.tbl, region/region.tbl)
+NATIONS = [("ALGERIA", 0), ("ARGENTINA", 1), ("BRAZIL", 1), ("CANADA", 1), ("EGYPT", 4), ("ETHIOPIA", 0),
+           ("FRANCE", 3), ("GERMANY", 3), ("INDIA", 2), ("INDONESIA", 2), ("IRAN", 4), ("IRAQ", 4),
+           ("JAPAN", 2), ("JORDAN", 4), ("KENYA", 0), ("MOROCCO", 0), ("MOZAMBIQUE", 0), ("PERU", 1),
+           ("CHINA", 2), ("ROMANIA", 3), ("SAUDI ARABIA", 4), ("VIETNAM", 2), ("RUSSIA", 3),
+           ("UNITED KINGDOM", 3), ("UNITED STATES", 1)]
+REGIONS = ["AFRICA", "AMERICA", "ASIA", "EUROPE", "MIDDLE EAST"]
+
+
+def nation():
+    return OrderedDict([("n_nationkey", OCol("Int32", np.arange(25))),
+                        ("n_name", OCol("Utf8", [n for n, _ in NATIONS])),
+                        ("n_regionkey", OCol("Int32", [r for _, r in NATIONS]))])
+
+
+def region():
+    return OrderedDict([("r_regionkey", OCol("Int32", np.arange(5))), ("r_name", OCol("Utf8", REGIONS))])
+
+
+# ---- threaded stage-1 ports (cpu_baseline) --------------------------------------------
+
+def q1_partial_port(a, n_partitions, n_threads, date_lit=10471):
+    """a = lineitem_arrays(...).  Returns (keys u16[P*4], state f64[P*4*8], count u64[P*4])."""
+    n = len(a["l_quantity"])
+    keys = np.zeros(4 * n_partitions, np.uint16)
+    state = np.zeros(32 * n_partitions, np.float64)
+    count = np.zeros(4 * n_partitions, np.uint64)
+    lib().oracle_q1_partial(
+        _p(a["l_quantity"], ctypes.c_double), _p(a["l_extendedprice"], ctypes.c_double),
+        _p(a["l_discount"], ctypes.c_double), _p(a["l_tax"], ctypes.c_double),
+        _p(a["l_shipdate"], ctypes.c_int32),
+        _p(a["l_returnflag.off"], ctypes.c_int32), _p(a["l_returnflag.data"], ctypes.c_uint8),
+        _p(a["l_linestatus.off"], ctypes.c_int32), _p(a["l_linestatus.data"], ctypes.c_uint8),
+        ctypes.c_int64(n), ctypes.c_int32(date_lit), ctypes.c_int32(n_partitions), ctypes.c_int32(n_threads),
+        _p(keys, ctypes.c_uint16), _p(state, ctypes.c_double), _p(count, ctypes.c_uint64))
+    return keys, state, count
+
+
+def q1_final_from_port(keys, state, count):
+    """merge the port's per-partition states like HashAggregateExec(Final) and evaluate.
+    Returns {(flag, status): dict(sum_qty, ..., count_order)}"""
+    groups = OrderedDict()
+    for slot in range(len(keys)):
+        k = int(keys[slot])
+        if k == 0 or count[slot] == 0:
+            continue
+        key = (chr(k & 0xFF), chr(k >> 8))
+        s = state[slot * 8: slot * 8 + 8]
+        g = groups.get(key)
+        if g is None:
+            groups[key] = [s.copy(), int(count[slot])]
+        else:
+            g[0] = g[0] + s
+            g[1] += int(count[slot])
+    out = OrderedDict()
+    for key, (s, c) in groups.items():
+        out[key] = dict(sum_qty=s[0], sum_base_price=s[1], sum_disc_price=s[2], sum_charge=s[3],
+                        avg_qty=s[4] / float(c), avg_price=s[5] / float(c), avg_disc=s[6] / float(c),
+                        count_order=c)
+    return out
+
+
+def q6_partial_port(a, n_partitions, n_threads):
+    n = len(a["l_quantity"])
+    s = np.zeros(n_partitions, np.float64)
+    c = np.zeros(n_partitions, np.uint64)
+    lib().oracle_q6_partial(
+        _p(a["l_quantity"], ctypes.c_double), _p(a["l_extendedprice"], ctypes.c_double),
+        _p(a["l_discount"], ctypes.c_double), _p(a["l_shipdate"], ctypes.c_int32),
+        ctypes.c_int64(n), ctypes.c_int32(8766), ctypes.c_int32(9131),
+        ctypes.c_double(0.06 - 0.01), ctypes.c_double(0.06 + 0.01), ctypes.c_double(24.0),
+        ctypes.c_int32(n_partitions), ctypes.c_int32(n_threads),
+        _p(s, ctypes.c_double), _p(c, ctypes.c_uint64))
+    return s, c
