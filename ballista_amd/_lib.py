@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libballista_hip.so")
+LIB_PATH = os.environ.get("BHIP_LIB_PATH") or os.path.join(_HERE, "lib", "libballista_hip.so")
 
 OK, EINVAL, ENOTIMPL, EEXEC, EHIP, EOOM = 0, 1, 2, 3, 4, 5
 

@@ -143,7 +143,7 @@ struct Column {
         r.offsets = offsets ? offsets->as<int32_t>() : nullptr;
         r.validity = validity ? validity->as<uint64_t>() : nullptr;
         r.dtype = dtype;
-        r.pad = 0;
+        r.data_bytes = (int32_t)data_bytes;
         return r;
     }
     int64_t memory_size() const;

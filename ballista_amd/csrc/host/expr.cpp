@@ -307,6 +307,7 @@ Operand ProgramBuilder::load_column(int schema_idx) {
         o.index = new_vreg(is_b);
         o.vclass = is_b ? VC_BOOL : (f.dtype == DT_FLOAT64 ? VC_F64 : VC_I64);
         VmLoad ld;
+        memset(&ld, 0, sizeof(ld));
         ld.col = (uint8_t)o.col;
         ld.dst = 0;
         ld.dtype = (uint8_t)f.dtype;
@@ -714,6 +715,36 @@ void ProgramBuilder::add_output(const ExprPtr& e) {
 // ---- register allocation + emission ------------------------------------------------------------
 void ProgramBuilder::finish(ScanParams& P) {
     memset(&P, 0, sizeof(P));
+    // key layout: fixed-width parts take their width, Utf8 parts share what is left of 16 bytes
+    int fixed = 0, n_utf8 = 0;
+    for (auto& k : keys_) {
+        if (k.kind == KP_UTF8_COL) ++n_utf8;
+        else fixed += k.width;
+    }
+    if (!hash_only_ && (fixed > 16 || (n_utf8 > 0 && (16 - fixed) / n_utf8 < 2)))
+        fail(BHIP_ENOTIMPL, "key columns do not fit the 16-byte packed key");
+    const int utf8_width = n_utf8 ? (16 - fixed) / n_utf8 : 0;
+    bool has_utf8_loads = false;
+    for (auto& k : keys_) {
+        if (k.kind != KP_UTF8_COL) continue;
+        k.width = utf8_width;
+        // short strings (<= 7 chars + length byte) are packed by the hoisted load stage into one V
+        // register; wider parts are read by the sink itself (slower: loads are not hoisted)
+        if (!hash_only_ && utf8_width <= 8 && (int)loads_.size() < VM_MAX_LOADS) {
+            VmLoad ld;
+            memset(&ld, 0, sizeof(ld));
+            ld.col = (uint8_t)k.src;
+            ld.dtype = (uint8_t)DT_UTF8;
+            ld.width = (uint8_t)utf8_width;
+            const int vreg = new_vreg(false);
+            loads_.push_back(ld);
+            load_dst_is_b_.push_back(false);
+            load_vregs_.push_back(vreg);
+            k.kind = KP_VSLOT;
+            k.src = vreg;
+            has_utf8_loads = true;
+        }
+    }
     const int n_v = (int)vreg_is_b_.size();
     const int INF = 1 << 30;
     std::vector<int> last_use(n_v, -1);
@@ -772,6 +803,7 @@ void ProgramBuilder::finish(ScanParams& P) {
     }
     VmProgram& G = P.prog;
     G.n_loads = (int)loads_.size();
+    G.has_utf8_loads = has_utf8_loads ? 1 : 0;
     for (size_t i = 0; i < loads_.size(); ++i) {
         G.loads[i] = loads_[i];
         G.loads[i].dst = (uint8_t)phys[load_vregs_[i]];
@@ -785,20 +817,10 @@ void ProgramBuilder::finish(ScanParams& P) {
     P.pred_slot = pred_vreg_ >= 0 ? phys[pred_vreg_] : -1;
     P.n_cols = (int)col_map_.size();
 
-    // key layout: fixed-width parts take their width, Utf8 parts share what is left of 16 bytes
-    int fixed = 0, n_utf8 = 0;
-    for (auto& k : keys_) {
-        if (k.kind == KP_UTF8_COL) ++n_utf8;
-        else fixed += k.width;
-    }
-    if (!hash_only_ && (fixed > 16 || (n_utf8 > 0 && (16 - fixed) / n_utf8 < 2)))
-        fail(BHIP_ENOTIMPL, "key columns do not fit the 16-byte packed key");
-    const int utf8_width = n_utf8 ? (16 - fixed) / n_utf8 : 0;
     int pos = 0;
     P.n_keyparts = (int)keys_.size();
     for (size_t i = 0; i < keys_.size(); ++i) {
         KeyV& k = keys_[i];
-        if (k.kind == KP_UTF8_COL) k.width = utf8_width;
         KeyPart kp;
         kp.kind = (uint8_t)k.kind;
         kp.src = (uint8_t)(k.kind == KP_UTF8_COL ? k.src : phys[k.src]);

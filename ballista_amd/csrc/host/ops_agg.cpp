@@ -13,6 +13,7 @@
 #include "../util_kernels.h"
 #include "hash_kernels.h"
 #include "plan.hpp"
+#include "sop.hpp"
 
 namespace bhip {
 
@@ -163,7 +164,7 @@ struct TimedLaunches {
 // high-cardinality path (device-wide hash table); filled in by ops_agg_hash.cpp
 GroupRec* hash_aggregate(const Exec& ex, Temp& tmp, const ScanParams& P0, const ProgramBuilder& pb,
                          const std::vector<BatchPtr>& inputs, bool nullable, int64_t* n_groups, ScanStatus* status,
-                         TimedLaunches& timer) {
+                         TimedLaunches& /*timer: only the register-path scan kernel is the timed (dominant) kernel*/) {
     const LaunchCfg cfg = ex.cfg();
     int64_t total_rows = 0;
     for (auto& b : inputs) total_rows += b->n_rows;
@@ -194,13 +195,10 @@ GroupRec* hash_aggregate(const Exec& ex, Temp& tmp, const ScanParams& P0, const 
         ScanParams P = P0;
         ProgramBuilder::bind(P, pb.columns(), *b, nullable);
         HIP_CHECK(launch_scan_keys(cfg, P, keys + 2ull * row_base, nullptr, nullptr, status));
-        timer.begin();
         HIP_CHECK(launch_scan_agg_hash(cfg, P, T, row_base, status));
-        timer.end();
         row_base += (uint32_t)b->n_rows;
     }
     check_scan_status(ex, status);
-    timer.collect();
     // used slots -> dense records (slot order: deterministic for a given input)
     uint32_t* flags = tmp.get<uint32_t>(cap);
     uint64_t* dense = tmp.get<uint64_t>(cap + 1);
@@ -239,6 +237,12 @@ std::vector<BatchPtr> HashAggregateExec::run(int partition, const Exec& ex) cons
     if (f.predicate) pb.set_predicate(f.predicate);
     for (auto& g : f.group) pb.add_key(g);
 
+    std::vector<SopAccExpr> acc_exprs;  // accumulator index -> (kind, input expression)
+    auto add_acc = [&](int kind, const ExprPtr& e) {
+        const int idx = pb.add_acc(kind, pb.compile(e));
+        if (idx == (int)acc_exprs.size()) acc_exprs.push_back(SopAccExpr{kind, e});
+        return idx;
+    };
     std::vector<EmitValueSpec> emits;   // one per output state/value column
     auto emit = [&](int kind, int a, int b, int dtype) { emits.push_back(EmitValueSpec{kind, a, b, 0, dtype}); };
     size_t ai = 0;
@@ -249,8 +253,7 @@ std::vector<BatchPtr> HashAggregateExec::run(int partition, const Exec& ex) cons
             const bool lit_nonnull = arg->kind == BHIP_EXPR_LITERAL && !arg->is_null;
             switch (a.fn) {
                 case BHIP_AGG_SUM: {
-                    Operand x = pb.compile(arg);
-                    const int acc = pb.add_acc(t == DT_FLOAT64 ? ACC_SUM_F64 : ACC_SUM_I64, x);
+                    const int acc = add_acc(t == DT_FLOAT64 ? ACC_SUM_F64 : ACC_SUM_I64, arg);
                     emit(EMIT_VALUE, acc, 0, sum_type(t));
                 } break;
                 case BHIP_AGG_AVG: {
@@ -262,8 +265,7 @@ std::vector<BatchPtr> HashAggregateExec::run(int partition, const Exec& ex) cons
                         c->args = {arg};
                         farg = c;
                     }
-                    Operand x = pb.compile(farg);
-                    const int acc = pb.add_acc(ACC_SUM_F64, x);
+                    const int acc = add_acc(ACC_SUM_F64, farg);
                     emit(EMIT_COUNT, acc, 0, DT_UINT64);
                     emit(EMIT_VALUE, acc, 0, DT_FLOAT64);
                 } break;
@@ -271,15 +273,14 @@ std::vector<BatchPtr> HashAggregateExec::run(int partition, const Exec& ex) cons
                     if (lit_nonnull || !expr_nullable(arg, src_schema)) { emit(EMIT_ROWS, 0, 0, DT_UINT64); break; }
                     Operand x = pb.compile(arg);
                     if (x.is_utf8_col) fail(BHIP_ENOTIMPL, "COUNT over a nullable Utf8 column");
-                    const int acc = pb.add_acc(x.vclass == VC_BOOL ? ACC_COUNT_VALID_B : ACC_COUNT_VALID, x);
+                    const int acc = add_acc(x.vclass == VC_BOOL ? ACC_COUNT_VALID_B : ACC_COUNT_VALID, arg);
                     emit(EMIT_RAW, acc, 0, DT_UINT64);
                 } break;
                 default: {
                     if (t == DT_UTF8 || t == DT_BOOLEAN) fail(BHIP_ENOTIMPL, "MIN/MAX over Utf8 or Boolean");
-                    Operand x = pb.compile(arg);
                     const bool is_min = a.fn == BHIP_AGG_MIN;
                     const int kind = t == DT_FLOAT64 ? (is_min ? ACC_MIN_F64 : ACC_MAX_F64) : (is_min ? ACC_MIN_I64 : ACC_MAX_I64);
-                    emit(EMIT_VALUE, pb.add_acc(kind, x), 0, t);
+                    emit(EMIT_VALUE, add_acc(kind, arg), 0, t);
                 } break;
             }
         } else {
@@ -287,20 +288,20 @@ std::vector<BatchPtr> HashAggregateExec::run(int partition, const Exec& ex) cons
             const int t = expr_type(st0, src_schema);
             switch (a.fn) {
                 case BHIP_AGG_SUM: {
-                    const int acc = pb.add_acc(t == DT_FLOAT64 ? ACC_SUM_F64 : ACC_SUM_I64, pb.compile(st0));
+                    const int acc = add_acc(t == DT_FLOAT64 ? ACC_SUM_F64 : ACC_SUM_I64, st0);
                     emit(EMIT_VALUE, acc, 0, t);
                 } break;
                 case BHIP_AGG_AVG: {
                     const ExprPtr& st1 = f.args[ai++];
-                    const int acc_c = pb.add_acc(ACC_SUM_I64, pb.compile(st0));
-                    const int acc_s = pb.add_acc(ACC_SUM_F64, pb.compile(st1));
+                    const int acc_c = add_acc(ACC_SUM_I64, st0);
+                    const int acc_s = add_acc(ACC_SUM_F64, st1);
                     emit(EMIT_AVG_ACC, acc_s, acc_c, DT_FLOAT64);
                 } break;
-                case BHIP_AGG_COUNT: emit(EMIT_RAW, pb.add_acc(ACC_SUM_I64, pb.compile(st0)), 0, DT_UINT64); break;
+                case BHIP_AGG_COUNT: emit(EMIT_RAW, add_acc(ACC_SUM_I64, st0), 0, DT_UINT64); break;
                 default: {
                     const bool is_min = a.fn == BHIP_AGG_MIN;
                     const int kind = t == DT_FLOAT64 ? (is_min ? ACC_MIN_F64 : ACC_MAX_F64) : (is_min ? ACC_MIN_I64 : ACC_MAX_I64);
-                    emit(EMIT_VALUE, pb.add_acc(kind, pb.compile(st0)), 0, t);
+                    emit(EMIT_VALUE, add_acc(kind, st0), 0, t);
                 } break;
             }
         }
@@ -308,6 +309,11 @@ std::vector<BatchPtr> HashAggregateExec::run(int partition, const Exec& ex) cons
     ScanParams P0;
     pb.finish(P0);
     const int n_acc = P0.n_acc;
+    // register-resident fast path when the plan has the chain-of-products shape (kernels_sop.hip)
+    SopPlan sop;
+    static const bool sop_disabled = [] { const char* v = getenv("BHIP_NO_SOP"); return v && atoi(v) != 0; }();
+    const bool sop_ok = !sop_disabled && !pb.creates_nulls() && (int)acc_exprs.size() == n_acc && n_acc <= SOP_NSTEP &&
+                        build_sop(src_schema, f.predicate, f.group, pb.key_info(), pb.key_bytes(), acc_exprs, sop);
 
     // ---- input ------------------------------------------------------------------------------------
     std::vector<BatchPtr> inputs;
@@ -351,8 +357,12 @@ std::vector<BatchPtr> HashAggregateExec::run(int partition, const Exec& ex) cons
             ProgramBuilder::bind(P, pb.columns(), *b, nullable);
             int grid = 0;
             timer.begin();
-            HIP_CHECK(launch_scan_agg_lowcard(cfg, P, gmax, partials + (size_t)n_part * gmax, partial_ng + n_part,
-                                              max_grid, status, &grid));
+            if (sop_ok && !nullable && bind_sop(sop, *b))
+                HIP_CHECK(launch_scan_agg_sop(cfg, sop.prog, tmp.get<SopProgram>(1), gmax, partials + (size_t)n_part * gmax,
+                                              partial_ng + n_part, max_grid, status, &grid));
+            else
+                HIP_CHECK(launch_scan_agg_lowcard(cfg, P, tmp.get<ScanParams>(1), gmax, partials + (size_t)n_part * gmax,
+                                                  partial_ng + n_part, max_grid, status, &grid));
             timer.end();
             n_part += grid;
         }

@@ -31,7 +31,8 @@ struct LaunchCfg {
 
 // low-cardinality fused scan+aggregate; gmax in {1,4,8}.  partials: grid*gmax GroupRec,
 // partial_ng: grid uint32.  Returns the grid size used in *grid_out.
-hipError_t launch_scan_agg_lowcard(const LaunchCfg& cfg, const ScanParams& P, int gmax,
+// dparams: device scratch for the per-launch copy of P (sizeof(ScanParams)), must outlive the kernel.
+hipError_t launch_scan_agg_lowcard(const LaunchCfg& cfg, const ScanParams& P, ScanParams* dparams, int gmax,
                                    GroupRec* partials, uint32_t* partial_ng, int max_grid,
                                    ScanStatus* status, int* grid_out);
 int scan_agg_lowcard_max_grid(const LaunchCfg& cfg);

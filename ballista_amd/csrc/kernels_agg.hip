@@ -29,6 +29,9 @@ struct AggLowCardArgs {
     ScanStatus* status;
 };
 
+constexpr int AGG_DEFAULT_R = 2;
+constexpr bool AGG_DEFAULT_PREFETCH = true;
+
 struct AggLds {
     Key128 keys[AGG_GMAX];
     uint32_t ng;
@@ -38,15 +41,25 @@ struct AggLds {
     uint64_t red[4][AGG_GMAX * AGG_NACC];
 };
 
-template <int R, bool NULLS, int GMAX>
-__global__ void __launch_bounds__(BLOCK)
-scan_agg_lowcard_kernel(const ScanParams P, const AggLowCardArgs<GMAX> A) {
+// The scan parameters (program, column pointers) are read through a pointer to a per-launch copy
+// in device memory: the addresses are wave-uniform, so they are fetched with scalar loads.  (As a
+// by-value kernel argument the 2 KB struct was copied to scratch once the next tile's loads were
+// issued from inside the loop.)
+template <int R, bool NULLS, int GMAX, bool PREFETCH>
+__global__ void __launch_bounds__(BLOCK, (GMAX >= 8 ? 2 : 3))   // >= 2-3 workgroups per CU: caps VGPRs at 256 / 168
+scan_agg_lowcard_kernel(const ScanParams* __restrict__ Pp, const AggLowCardArgs<GMAX> A) {
+    const ScanParams& P = *Pp;
     constexpr int TILE = BLOCK * R;
     constexpr int NACC = AGG_NACC;
     extern __shared__ __align__(16) uint8_t lds_raw[];
     const TileLds L = carve_tile_lds<R, NULLS>(lds_raw, P.prog);
-    AggLds* S = reinterpret_cast<AggLds*>(lds_raw + tile_lds_bytes<R>(P.prog.n_vslots, P.prog.n_bslots, NULLS));
+    BHIP_LDS AggLds* S = (BHIP_LDS AggLds*)((lds_u8*)lds_raw + tile_lds_bytes<R>(P.prog.n_vslots, P.prog.n_bslots, NULLS));
     const int tid = threadIdx.x;
+    const int n_acc = P.n_acc;
+    // all accumulators are SUM(Float64) (TPC-H Q1/Q3/Q5/Q6): no per-accumulator dispatch in the hot loop
+    bool all_sum_f64 = true;
+    for (int a = 0; a < n_acc; ++a) all_sum_f64 &= (P.acc[a].kind == ACC_SUM_F64);
+    const bool key64 = P.key_bytes <= 8;
 
     uint64_t acc[GMAX][NACC];
     // without NULLS every accumulated input is known, so nvalid == rows
@@ -57,25 +70,41 @@ scan_agg_lowcard_kernel(const ScanParams P, const AggLowCardArgs<GMAX> A) {
         rows[g] = 0;
 #pragma unroll
         for (int a = 0; a < NACC; ++a) {
-            acc[g][a] = (a < P.n_acc) ? acc_identity(P.acc[a].kind) : 0;
+            acc[g][a] = (a < n_acc) ? acc_identity(P.acc[a].kind) : 0;
             if (NULLS) nvalid[g][a] = 0;
         }
     }
     if (tid == 0) { S->ng = 0; S->overflow = 0; S->winner = 0xFFFFFFFFu; }
+    if (tid < GMAX) { S->keys[tid].k0 = 0; S->keys[tid].k1 = 0; }
     __syncthreads();
 
     uint32_t err = 0;
     const int64_t n_tiles = (P.n_rows + TILE - 1) / TILE;
+    // register double buffering: the loads of the next tile are in flight while this one is
+    // interpreted and accumulated (first LOAD_GROUP loads; any further ones load blocking)
+    LoadRegs<PREFETCH ? R : 1, NULLS> pre;
+    if (PREFETCH && (int64_t)blockIdx.x < n_tiles) {
+        vm_load_issue_a<PREFETCH ? R : 1, NULLS>(P, (int64_t)blockIdx.x * TILE, 0, pre);
+        vm_load_issue_b<PREFETCH ? R : 1, NULLS>(P, (int64_t)blockIdx.x * TILE, 0, pre, err);
+    }
     for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const int64_t base = t * TILE;
-        vm_load_tile<R, NULLS>(P, L, base);
+        const int64_t next = t + gridDim.x;
+        if (PREFETCH) {
+            vm_load_commit<PREFETCH ? R : 1, NULLS>(P, L, 0, pre);
+            if (next < n_tiles) vm_load_issue_a<PREFETCH ? R : 1, NULLS>(P, next * TILE, 0, pre);
+            if (P.prog.n_loads > LOAD_GROUP) vm_load_tile<R, NULLS>(P, L, base, err, LOAD_GROUP);
+        } else {
+            vm_load_tile<R, NULLS>(P, L, base, err);
+        }
         vm_execute<R, NULLS>(P, L, base, err);
+        if (PREFETCH && next < n_tiles) vm_load_issue_b<PREFETCH ? R : 1, NULLS>(P, next * TILE, 0, pre, err);
 
         // ---- resolve each row's group among this workgroup's keys
         int ng = S->ng;
         Key128 gk[GMAX];
 #pragma unroll
-        for (int g = 0; g < GMAX; ++g) gk[g] = S->keys[g];
+        for (int g = 0; g < GMAX; ++g) { gk[g].k0 = S->keys[g].k0; gk[g].k1 = key64 ? 0 : S->keys[g].k1; }
         Key128 rk[R];
         int lg[R];
         bool pending = false;
@@ -83,17 +112,17 @@ scan_agg_lowcard_kernel(const ScanParams P, const AggLowCardArgs<GMAX> A) {
         for (int r = 0; r < R; ++r) {
             const int idx = r * BLOCK + tid;
             bool live = (base + idx) < P.n_rows;
-            if (live && P.pred_slot >= 0) live = L.bvals[P.pred_slot * TILE + idx] & 1;
+            if (P.pred_slot >= 0) live = live && (L.bvals[P.pred_slot * TILE + idx] & 1);
             rk[r] = Key128{0, 0};
-            lg[r] = -1;
-            if (live) {
-                if (P.n_keyparts > 0) rk[r] = pack_key<R, NULLS>(P, L, base, r, err);
-                lg[r] = -2;   // live, group unknown
+            if (P.n_keyparts > 0) rk[r] = pack_key<R, NULLS>(P, L, base, r, err);
+            int g_found = -2;   // live, group unknown
 #pragma unroll
-                for (int g = 0; g < GMAX; ++g)
-                    if (g < ng && rk[r] == gk[g]) lg[r] = g;
-                pending |= (lg[r] == -2);
+            for (int g = 0; g < GMAX; ++g) {
+                const bool eq = rk[r].k0 == gk[g].k0 && (key64 || rk[r].k1 == gk[g].k1);
+                g_found = (g < ng && eq) ? g : g_found;
             }
+            lg[r] = live ? g_found : -1;
+            pending |= (lg[r] == -2);
         }
         // insertion rounds: rare (at most GMAX times per workgroup)
         while (__syncthreads_or(pending ? 1 : 0)) {
@@ -102,7 +131,7 @@ scan_agg_lowcard_kernel(const ScanParams P, const AggLowCardArgs<GMAX> A) {
 #pragma unroll
                 for (int r = R - 1; r >= 0; --r)
                     if (lg[r] == -2) mine = (uint32_t)(r * BLOCK + tid);
-                atomicMin(&S->winner, mine);
+                atomicMin((uint32_t*)&S->winner, mine);
             }
             __syncthreads();
             const uint32_t w = S->winner;
@@ -115,13 +144,14 @@ scan_agg_lowcard_kernel(const ScanParams P, const AggLowCardArgs<GMAX> A) {
 #pragma unroll
                 for (int r = 0; r < R; ++r)
                     if ((uint32_t)r == w / BLOCK) wk = rk[r];
-                S->keys[cur] = wk;
+                S->keys[cur].k0 = wk.k0;
+                S->keys[cur].k1 = wk.k1;
                 S->ng = cur + 1;
             }
             __syncthreads();
             if (tid == 0) S->winner = 0xFFFFFFFFu;
             if (S->overflow) break;
-            const Key128 nk = S->keys[cur];
+            const Key128 nk{S->keys[cur].k0, S->keys[cur].k1};
             pending = false;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -131,35 +161,49 @@ scan_agg_lowcard_kernel(const ScanParams P, const AggLowCardArgs<GMAX> A) {
         }
         if (S->overflow) break;
 
-        // ---- accumulate (registers, static indices, predicated on the group id)
+        // ---- accumulate (registers, static indices, one predicated block per group)
 #pragma unroll
-        for (int r = 0; r < R; ++r)
+        for (int r = 0; r < R; ++r) {
+            const int idx = r * BLOCK + tid;
+            if (all_sum_f64 && !NULLS) {
+                // fast path: fetch the row's inputs once, then one exec-masked block of adds per group
+                double v[NACC];
 #pragma unroll
-            for (int g = 0; g < GMAX; ++g)
-                if (lg[r] == g) rows[g] += 1;
+                for (int a = 0; a < NACC; ++a) v[a] = (a < n_acc) ? u2d(L.vals[P.acc[a].slot * TILE + idx]) : 0.0;
 #pragma unroll
-        for (int a = 0; a < NACC; ++a) {
-            if (a < P.n_acc) {
-                const AccSpec sp = P.acc[a];
+                for (int g = 0; g < GMAX; ++g) {
+                    if (lg[r] == g) {
+                        rows[g] += 1;
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    if (lg[r] < 0) continue;
-                    const int idx = r * BLOCK + tid;
-                    uint64_t v = 1;
-                    bool k = true;
-                    if (sp.kind == ACC_COUNT_VALID_B) {
-                        k = L.bvals[sp.slot * TILE + idx] >> 1;
-                    } else if (sp.kind != ACC_COUNT_ROWS) {
-                        v = L.vals[sp.slot * TILE + idx];
-                        if (NULLS) k = L.vvalid[sp.slot * TILE + idx];
+                        for (int a = 0; a < NACC; ++a)
+                            if (a < n_acc) acc[g][a] = d2u(u2d(acc[g][a]) + v[a]);
                     }
-                    if (sp.kind == ACC_COUNT_VALID || sp.kind == ACC_COUNT_VALID_B) { v = k ? 1 : 0; k = true; }
-                    if (!k) continue;
+                }
+            } else {
 #pragma unroll
-                    for (int g = 0; g < GMAX; ++g) {
-                        if (lg[r] == g) {
-                            acc[g][a] = acc_combine(acc[g][a], v, sp.kind);
-                            if (NULLS) nvalid[g][a] += 1;
+                for (int g = 0; g < GMAX; ++g)
+                    if (lg[r] == g) rows[g] += 1;
+#pragma unroll
+                for (int a = 0; a < NACC; ++a) {
+                    if (a < n_acc && lg[r] >= 0) {
+                        const AccSpec sp = P.acc[a];
+                        uint64_t v = 1;
+                        bool k = true;
+                        if (sp.kind == ACC_COUNT_VALID_B) {
+                            k = L.bvals[sp.slot * TILE + idx] >> 1;
+                        } else if (sp.kind != ACC_COUNT_ROWS) {
+                            v = L.vals[sp.slot * TILE + idx];
+                            if (NULLS) k = L.vvalid[sp.slot * TILE + idx];
+                        }
+                        if (sp.kind == ACC_COUNT_VALID || sp.kind == ACC_COUNT_VALID_B) { v = k ? 1 : 0; k = true; }
+                        if (k) {
+#pragma unroll
+                            for (int g = 0; g < GMAX; ++g) {
+                                if (lg[r] == g) {
+                                    acc[g][a] = acc_combine(acc[g][a], v, sp.kind);
+                                    if (NULLS) nvalid[NULLS ? g : 0][NULLS ? a : 0] += 1;
+                                }
+                            }
                         }
                     }
                 }
@@ -167,12 +211,11 @@ scan_agg_lowcard_kernel(const ScanParams P, const AggLowCardArgs<GMAX> A) {
         }
     }
 
-    // ---- workgroup reduction in a fixed order: lanes (xor-free shuffle tree) -> waves 0..3
+    // ---- workgroup reduction in a fixed order: lanes (shuffle tree) -> waves 0..3
     const int wave = tid >> 6, lane = tid & 63;
     __syncthreads();
     const int ng = S->ng;
     uint64_t tot_rows = 0, tot_acc = 0, tot_nv = 0;
-    // rows
 #pragma unroll
     for (int g = 0; g < GMAX; ++g) {
         const uint64_t v = wave_reduce((uint64_t)rows[g], ACC_COUNT_ROWS);
@@ -181,19 +224,18 @@ scan_agg_lowcard_kernel(const ScanParams P, const AggLowCardArgs<GMAX> A) {
     __syncthreads();
     if (tid < GMAX) tot_rows = S->red[0][tid] + S->red[1][tid] + S->red[2][tid] + S->red[3][tid];
     __syncthreads();
-    // accumulators
 #pragma unroll
     for (int g = 0; g < GMAX; ++g)
 #pragma unroll
         for (int a = 0; a < NACC; ++a) {
-            const int kind = (a < P.n_acc) ? P.acc[a].kind : ACC_COUNT_ROWS;
+            const int kind = (a < n_acc) ? P.acc[a].kind : ACC_COUNT_ROWS;
             const uint64_t v = wave_reduce(acc[g][a], kind);
             if (lane == 0) S->red[wave][g * NACC + a] = v;
         }
     __syncthreads();
     if (tid < GMAX * NACC) {
         const int a = tid % NACC;
-        const int kind = (a < P.n_acc) ? P.acc[a].kind : ACC_COUNT_ROWS;
+        const int kind = (a < n_acc) ? P.acc[a].kind : ACC_COUNT_ROWS;
         tot_acc = S->red[0][tid];
         tot_acc = acc_combine(tot_acc, S->red[1][tid], kind);
         tot_acc = acc_combine(tot_acc, S->red[2][tid], kind);
@@ -330,42 +372,64 @@ merge_reduce_kernel(const GroupRec* partials, const uint32_t* entry_group, int n
 
 int scan_agg_lowcard_max_grid(const LaunchCfg& cfg) { return cfg.device_cus * 8; }
 
-template <int R, bool NULLS, int GMAX>
-static hipError_t launch_lowcard_t(const LaunchCfg& cfg, const ScanParams& P, GroupRec* partials, uint32_t* partial_ng,
-                                   int max_grid, ScanStatus* status, int* grid_out) {
+template <int R, bool NULLS, int GMAX, bool PREFETCH>
+static hipError_t launch_lowcard_t(const LaunchCfg& cfg, const ScanParams& P, ScanParams* dparams, GroupRec* partials,
+                                   uint32_t* partial_ng, int max_grid, ScanStatus* status, int* grid_out) {
     constexpr int TILE = BLOCK * R;
     const size_t lds = host_tile_bytes<R>(P.prog) + sizeof(AggLds);
+    if (lds > LDS_PER_CU) return hipErrorInvalidValue;
     const int64_t n_tiles = (P.n_rows + TILE - 1) / TILE;
-    int grid = pick_grid(cfg, n_tiles, lds, GMAX >= 8 ? 2 : 4);
-    if (grid > max_grid) grid = max_grid;
-    auto k = scan_agg_lowcard_kernel<R, NULLS, GMAX>;
+    auto k = scan_agg_lowcard_kernel<R, NULLS, GMAX, PREFETCH>;
     hipError_t e = set_lds(k, lds);
     if (e != hipSuccess) return e;
+    // one grid-stride wave of resident workgroups: every workgroup gets the same number of tiles
+    int per_cu = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k), BLOCK, lds);
+    if (e != hipSuccess) return e;
+    if (per_cu < 1) per_cu = 1;
+    static const int forced_per_cu = [] { const char* v = getenv("BHIP_AGG_BLOCKS_PER_CU"); return v ? atoi(v) : 0; }();
+    if (forced_per_cu > 0) per_cu = forced_per_cu;
+    int64_t grid = (int64_t)cfg.device_cus * per_cu;
+    if (grid > n_tiles) grid = n_tiles;
+    if (grid > max_grid) grid = max_grid;
+    if (grid < 1) grid = 1;
+    e = hipMemcpyAsync(dparams, &P, sizeof(ScanParams), hipMemcpyHostToDevice, cfg.stream);
+    if (e != hipSuccess) return e;
     AggLowCardArgs<GMAX> A{partials, partial_ng, status};
-    hipLaunchKernelGGL(k, dim3(grid), dim3(BLOCK), lds, cfg.stream, P, A);
-    *grid_out = grid;
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(BLOCK), lds, cfg.stream, (const ScanParams*)dparams, A);
+    *grid_out = (int)grid;
     return hipGetLastError();
 }
 
+// rows per thread R and register prefetch per variant.  Defaults come from tuning on MI355X
+// (DESIGN.md "Kernel tuning"); BHIP_SCAN_R / BHIP_PREFETCH select other variants in a -DBHIP_TUNE build.
 template <bool NULLS>
-static hipError_t launch_lowcard_n(const LaunchCfg& cfg, const ScanParams& P, int gmax, int r, GroupRec* partials,
-                                   uint32_t* partial_ng, int max_grid, ScanStatus* status, int* grid_out) {
-    // 8 groups x 8 accumulators take 128 VGPRs: that variant only exists with 2 rows per thread
-    if (gmax == 8) return launch_lowcard_t<2, NULLS, 8>(cfg, P, partials, partial_ng, max_grid, status, grid_out);
-    if (gmax == 4)
-        return r == 4 ? launch_lowcard_t<4, NULLS, 4>(cfg, P, partials, partial_ng, max_grid, status, grid_out)
-                      : launch_lowcard_t<2, NULLS, 4>(cfg, P, partials, partial_ng, max_grid, status, grid_out);
-    if (gmax == 1)
-        return r == 4 ? launch_lowcard_t<4, NULLS, 1>(cfg, P, partials, partial_ng, max_grid, status, grid_out)
-                      : launch_lowcard_t<2, NULLS, 1>(cfg, P, partials, partial_ng, max_grid, status, grid_out);
+static hipError_t launch_lowcard_n(const LaunchCfg& cfg, const ScanParams& P, ScanParams* dparams, int gmax,
+                                   GroupRec* partials, uint32_t* partial_ng, int max_grid, ScanStatus* status, int* grid_out) {
+#define BHIP_LC(R_, G_, PF_) launch_lowcard_t<R_, NULLS, G_, PF_>(cfg, P, dparams, partials, partial_ng, max_grid, status, grid_out)
+#ifdef BHIP_TUNE
+    static const int r_env = [] { const char* v = getenv("BHIP_SCAN_R"); return v ? atoi(v) : 0; }();
+    static const int pf_env = [] { const char* v = getenv("BHIP_PREFETCH"); return v ? atoi(v) : -1; }();
+    if (!NULLS && gmax == 4 && (r_env > 0 || pf_env >= 0)) {
+        const int r = r_env > 0 ? r_env : AGG_DEFAULT_R;
+        const bool pf = pf_env >= 0 ? pf_env != 0 : AGG_DEFAULT_PREFETCH;
+        if (r == 1) return pf ? BHIP_LC(1, 4, true) : BHIP_LC(1, 4, false);
+        if (r == 2) return pf ? BHIP_LC(2, 4, true) : BHIP_LC(2, 4, false);
+        if (r == 4) return pf ? BHIP_LC(4, 4, true) : BHIP_LC(4, 4, false);
+    }
+#endif
+    // 8 groups x 8 accumulators take 128 VGPRs: no room for prefetch registers
+    if (gmax == 8) return BHIP_LC(2, 8, false);
+    if (gmax == 4) return BHIP_LC(AGG_DEFAULT_R, 4, AGG_DEFAULT_PREFETCH);
+    if (gmax == 1) return BHIP_LC(AGG_DEFAULT_R, 1, AGG_DEFAULT_PREFETCH);
     return hipErrorInvalidValue;
+#undef BHIP_LC
 }
 
-hipError_t launch_scan_agg_lowcard(const LaunchCfg& cfg, const ScanParams& P, int gmax, GroupRec* partials,
-                                   uint32_t* partial_ng, int max_grid, ScanStatus* status, int* grid_out) {
-    const int r = choose_r(P.prog, sizeof(AggLds));
-    return P.prog.nullable ? launch_lowcard_n<true>(cfg, P, gmax, r, partials, partial_ng, max_grid, status, grid_out)
-                           : launch_lowcard_n<false>(cfg, P, gmax, r, partials, partial_ng, max_grid, status, grid_out);
+hipError_t launch_scan_agg_lowcard(const LaunchCfg& cfg, const ScanParams& P, ScanParams* dparams, int gmax,
+                                   GroupRec* partials, uint32_t* partial_ng, int max_grid, ScanStatus* status, int* grid_out) {
+    return P.prog.nullable ? launch_lowcard_n<true>(cfg, P, dparams, gmax, partials, partial_ng, max_grid, status, grid_out)
+                           : launch_lowcard_n<false>(cfg, P, dparams, gmax, partials, partial_ng, max_grid, status, grid_out);
 }
 
 hipError_t launch_merge_partials(const LaunchCfg& cfg, const GroupRec* partials, const uint32_t* partial_ng,

@@ -54,7 +54,7 @@ scan_agg_hash_kernel(const ScanParams P, const HashAggTable T, uint32_t row_base
     const int64_t n_tiles = (P.n_rows + TILE - 1) / TILE;
     for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const int64_t base = t * TILE;
-        vm_load_tile<R, NULLS>(P, L, base);
+        vm_load_tile<R, NULLS>(P, L, base, err);
         vm_execute<R, NULLS>(P, L, base, err);
 #pragma unroll
         for (int r = 0; r < R; ++r) {

@@ -37,7 +37,7 @@ scan_project_kernel(const ScanParams P, const ProjectOut O, ScanStatus* status) 
     const int64_t n_tiles = (P.n_rows + TILE - 1) / TILE;
     for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const int64_t base = t * TILE;
-        vm_load_tile<R, NULLS>(P, L, base);
+        vm_load_tile<R, NULLS>(P, L, base, err);
         vm_execute<R, NULLS>(P, L, base, err);
         for (int j = 0; j < P.n_out; ++j) {
             const int slot = P.out_slot[j];
@@ -53,22 +53,22 @@ scan_project_kernel(const ScanParams P, const ProjectOut O, ScanStatus* status) 
                     known = b >> 1;
                     const uint64_t word = __ballot(b & 1);
                     if ((tid & 63) == 0 && (row - (tid & 63)) < P.n_rows)
-                        reinterpret_cast<uint64_t*>(O.data[j])[row >> 6] = word;
+                        gptr_w<uint64_t>(O.data[j])[row >> 6] = word;
                 } else {
                     const uint64_t v = L.vals[slot * TILE + idx];
                     if (NULLS) known = L.vvalid[slot * TILE + idx];
                     if (in) {
                         switch (dt) {
                             case DT_INT32:
-                            case DT_DATE32: reinterpret_cast<int32_t*>(O.data[j])[row] = (int32_t)v; break;
-                            case DT_UINT8: reinterpret_cast<uint8_t*>(O.data[j])[row] = (uint8_t)v; break;
-                            default: reinterpret_cast<uint64_t*>(O.data[j])[row] = v; break;
+                            case DT_DATE32: gptr_w<int32_t>(O.data[j])[row] = (int32_t)v; break;
+                            case DT_UINT8: gptr_w<uint8_t>(O.data[j])[row] = (uint8_t)v; break;
+                            default: gptr_w<uint64_t>(O.data[j])[row] = v; break;
                         }
                     }
                 }
                 if (O.validity[j] != nullptr) {
                     const uint64_t vw = __ballot(in && known);
-                    if ((tid & 63) == 0 && (row - (tid & 63)) < P.n_rows) O.validity[j][row >> 6] = vw;
+                    if ((tid & 63) == 0 && (row - (tid & 63)) < P.n_rows) gptr_w<uint64_t>(O.validity[j])[row >> 6] = vw;
                 }
             }
         }
@@ -94,7 +94,7 @@ scan_pred_bitmap_kernel(const ScanParams P, uint64_t* bitmap, uint32_t* tile_cou
         const int64_t base = t * TILE;
         if (tid == 0) s_cnt = 0;
         __syncthreads();
-        vm_load_tile<R, NULLS>(P, L, base);
+        vm_load_tile<R, NULLS>(P, L, base, err);
         vm_execute<R, NULLS>(P, L, base, err);
         uint32_t cnt = 0;
 #pragma unroll
@@ -105,7 +105,7 @@ scan_pred_bitmap_kernel(const ScanParams P, uint64_t* bitmap, uint32_t* tile_cou
             if (sel && P.pred_slot >= 0) sel = L.bvals[P.pred_slot * TILE + idx] & 1;
             const uint64_t word = __ballot(sel);
             if ((tid & 63) == 0) {
-                if ((row) < P.n_rows) bitmap[row >> 6] = word;
+                if ((row) < P.n_rows) gptr_w<uint64_t>(bitmap)[row >> 6] = word;
                 cnt += (uint32_t)__popcll(word);
             }
         }
@@ -144,8 +144,8 @@ __device__ inline uint64_t hash_row(const ScanParams& P, const TileLds& L, int64
         } else if (row < P.n_rows) {
             const ColumnRef& c = P.cols[kp.src];
             if (!NULLS || column_valid_bit(c, row)) {
-                const int32_t o0 = c.offsets[row], o1 = c.offsets[row + 1];
-                const uint8_t* s = reinterpret_cast<const uint8_t*>(c.data);
+                const int32_t o0 = gptr<int32_t>(c.offsets)[row], o1 = gptr<int32_t>(c.offsets)[row + 1];
+                const BHIP_GLOBAL uint8_t* s = gptr<uint8_t>(c.data);
                 uint64_t f = 0xCBF29CE484222325ull;
                 for (int32_t o = o0; o < o1; ++o) f = (f ^ s[o]) * 0x100000001B3ull;
                 bits = f;
@@ -167,7 +167,7 @@ scan_keys_kernel(const ScanParams P, uint64_t* keys128, uint64_t* hashes, uint64
     const int64_t n_tiles = (P.n_rows + TILE - 1) / TILE;
     for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const int64_t base = t * TILE;
-        vm_load_tile<R, NULLS>(P, L, base);
+        vm_load_tile<R, NULLS>(P, L, base, err);
         vm_execute<R, NULLS>(P, L, base, err);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -178,15 +178,15 @@ scan_keys_kernel(const ScanParams P, uint64_t* keys128, uint64_t* hashes, uint64
             if (sel && P.pred_slot >= 0) sel = L.bvals[P.pred_slot * TILE + idx] & 1;
             if (keys128 != nullptr) {
                 const Key128 k = pack_key<R, NULLS>(P, L, base, r, err);
-                if (in) { keys128[2 * row] = k.k0; keys128[2 * row + 1] = k.k1; }
+                if (in) { gptr_w<uint64_t>(keys128)[2 * row] = k.k0; gptr_w<uint64_t>(keys128)[2 * row + 1] = k.k1; }
             }
             if (hashes != nullptr) {
                 const uint64_t h = hash_row<R, NULLS>(P, L, base, r);
-                if (in) hashes[row] = h;
+                if (in) gptr_w<uint64_t>(hashes)[row] = h;
             }
             if (bitmap != nullptr) {
                 const uint64_t word = __ballot(sel);
-                if ((tid & 63) == 0 && row < P.n_rows) bitmap[row >> 6] = word;
+                if ((tid & 63) == 0 && row < P.n_rows) gptr_w<uint64_t>(bitmap)[row >> 6] = word;
             }
         }
     }

@@ -1,0 +1,12 @@
+// kernels_sop_g8.hip — instantiations of the register-resident scan + aggregate kernel
+// (sop_kernel.h) for workgroups holding up to 8 group(s).
+#include "sop_kernel.h"
+
+namespace bhip {
+
+hipError_t launch_scan_agg_sop_g8(const LaunchCfg& cfg, const SopProgram& S, SopProgram* dprog, GroupRec* partials,
+                                  uint32_t* partial_ng, int max_grid, ScanStatus* status, int* grid_out) {
+    return launch_sop_g<8>(cfg, S, dprog, partials, partial_ng, max_grid, status, grid_out);
+}
+
+}  // namespace bhip

@@ -13,10 +13,25 @@ namespace bhip {
 
 constexpr int BLOCK = 256;
 
+// The slot pointers carry the LDS address space in their TYPE: every access compiles to ds_read /
+// ds_write.  (Plain pointers into the dynamic LDS array were treated as generic by the compiler
+// once they crossed a function boundary: flat_load/flat_store, which also force s_waitcnt
+// vmcnt(0) + lgkmcnt(0) and so serialise against the global loads in flight.)
+#define BHIP_LDS __attribute__((address_space(3)))
+// Column pointers reach the kernels inside a struct, so the compiler sees generic pointers and
+// would emit flat_load (which also counts on lgkmcnt and so blocks every LDS wait on the HBM
+// loads in flight).  gptr<T>() states what they are: global memory.
+#define BHIP_GLOBAL __attribute__((address_space(1)))
+template <class T> __device__ inline const BHIP_GLOBAL T* gptr(const void* p) { return (const BHIP_GLOBAL T*)p; }
+template <class T> __device__ inline BHIP_GLOBAL T* gptr_w(void* p) { return (BHIP_GLOBAL T*)p; }
+struct __attribute__((packed)) PackedU64 { uint64_t v; };
+typedef BHIP_LDS uint64_t lds_u64;
+typedef BHIP_LDS uint8_t lds_u8;
+
 struct TileLds {
-    uint64_t* vals;     // [n_vslots][TILE]
-    uint8_t* vvalid;    // [n_vslots][TILE]   (only when NULLS)
-    uint8_t* bvals;     // [n_bslots][TILE]   bit0 = value, bit1 = known (not NULL)
+    lds_u64* vals;      // [n_vslots][TILE]
+    lds_u8* vvalid;     // [n_vslots][TILE]   (only when NULLS)
+    lds_u8* bvals;      // [n_bslots][TILE]   bit0 = value, bit1 = known (not NULL)
 };
 
 template <int R>
@@ -32,10 +47,11 @@ template <int R, bool NULLS>
 __device__ inline TileLds carve_tile_lds(uint8_t* base, const VmProgram& G) {
     constexpr int TILE = BLOCK * R;
     TileLds L;
-    L.vals = reinterpret_cast<uint64_t*>(base);
-    uint8_t* p = base + (size_t)G.n_vslots * TILE * 8;
+    lds_u8* b = (lds_u8*)base;
+    L.vals = (lds_u64*)b;
+    lds_u8* p = b + G.n_vslots * TILE * 8;
     L.vvalid = p;
-    if (NULLS) p += (size_t)G.n_vslots * TILE;
+    if (NULLS) p += G.n_vslots * TILE;
     L.bvals = p;
     return L;
 }
@@ -45,70 +61,137 @@ __device__ inline uint64_t d2u(double d) { return (uint64_t)__double_as_longlong
 
 __device__ inline bool column_valid_bit(const ColumnRef& c, int64_t row) {
     if (c.validity == nullptr) return true;
-    return (c.validity[row >> 6] >> (row & 63)) & 1ull;
+    return (gptr<uint64_t>(c.validity)[row >> 6] >> (row & 63)) & 1ull;
 }
 
-// ---- hoisted column loads: all global loads of a tile are issued before any is consumed
+// ---- hoisted column loads ------------------------------------------------------------------
+// All global loads of a tile are issued before any is consumed, in two dependent stages:
+//   A: fixed-width values and, for short-string packs (DT_UTF8 loads), the two Arrow offsets;
+//   B: the string bytes (one 8-byte load per row) — needs A's offsets.
+// The results sit in registers (statically indexed: the loops are unrolled over LOAD_GROUP) until
+// `commit` writes them to the LDS slots.  The fused-aggregate kernel issues A/B for the NEXT tile
+// before it interprets the current one (register double buffering); the other kernels call
+// vm_load_tile, which runs the three steps back to back.
+constexpr int LOAD_GROUP = 8;
+
 template <int R, bool NULLS>
-__device__ inline void vm_load_tile(const ScanParams& P, const TileLds& L, int64_t tile_base) {
-    constexpr int TILE = BLOCK * R;
-    constexpr int GROUP = 6;
+struct LoadRegs {
+    uint64_t x[LOAD_GROUP][R];
+    uint8_t ok[NULLS ? LOAD_GROUP : 1][NULLS ? R : 1];   // without NULLS every loaded value is known
+};
+
+template <int R, bool NULLS>
+__device__ inline void vm_load_issue_a(const ScanParams& P, int64_t tile_base, int g0, LoadRegs<R, NULLS>& g) {
     const VmProgram& G = P.prog;
     const int tid = threadIdx.x;
-    for (int g0 = 0; g0 < G.n_loads; g0 += GROUP) {
-        uint64_t x[GROUP][R];
-        uint8_t ok[NULLS ? GROUP : 1][NULLS ? R : 1];   // without NULLS every loaded value is known
 #pragma unroll
-        for (int j = 0; j < GROUP; ++j) {
-            if (g0 + j < G.n_loads) {
-                const VmLoad ld = G.loads[g0 + j];
-                const ColumnRef& c = P.cols[ld.col];
+    for (int j = 0; j < LOAD_GROUP; ++j) {
+        if (g0 + j < G.n_loads) {
+            const VmLoad ld = G.loads[g0 + j];
+            const ColumnRef& c = P.cols[ld.col];
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int64_t row = tile_base + r * BLOCK + tid;
-                    uint64_t v = 0;
-                    uint8_t k = 0;
-                    if (row < P.n_rows) {
-                        switch (ld.dtype) {
-                            case DT_FLOAT64:
-                            case DT_INT64:
-                            case DT_UINT64: v = reinterpret_cast<const uint64_t*>(c.data)[row]; break;
-                            case DT_INT32:
-                            case DT_DATE32: v = (uint64_t)(int64_t) reinterpret_cast<const int32_t*>(c.data)[row]; break;
-                            case DT_UINT8: v = reinterpret_cast<const uint8_t*>(c.data)[row]; break;
-                            case DT_BOOLEAN: v = (reinterpret_cast<const uint8_t*>(c.data)[row >> 3] >> (row & 7)) & 1u; break;
-                            default: break;
-                        }
-                        k = NULLS ? (uint8_t)column_valid_bit(c, row) : 1;
+            for (int r = 0; r < R; ++r) {
+                const int64_t row = tile_base + r * BLOCK + tid;
+                uint64_t v = 0;
+                uint8_t k = 0;
+                if (row < P.n_rows) {
+                    switch (ld.dtype) {
+                        case DT_FLOAT64:
+                        case DT_INT64:
+                        case DT_UINT64: v = gptr<uint64_t>(c.data)[row]; break;
+                        case DT_INT32:
+                        case DT_DATE32: v = (uint64_t)(int64_t)gptr<int32_t>(c.data)[row]; break;
+                        case DT_UINT8: v = gptr<uint8_t>(c.data)[row]; break;
+                        case DT_BOOLEAN: v = (gptr<uint8_t>(c.data)[row >> 3] >> (row & 7)) & 1u; break;
+                        case DT_UTF8: {   // stage A of a short-string pack: offset in the low, length in the high half
+                            const int32_t o0 = gptr<int32_t>(c.offsets)[row], o1 = gptr<int32_t>(c.offsets)[row + 1];
+                            v = (uint64_t)(uint32_t)o0 | ((uint64_t)(uint32_t)(o1 - o0) << 32);
+                        } break;
+                        default: break;
                     }
-                    x[j][r] = v;
-                    if (NULLS) ok[j][r] = k;
+                    k = NULLS ? (uint8_t)column_valid_bit(c, row) : 1;
                 }
+                g.x[j][r] = v;
+                if (NULLS) g.ok[NULLS ? j : 0][NULLS ? r : 0] = k;
             }
         }
+    }
+}
+
+// stage B: [len][bytes...] image of each short string (at most width-1 <= 7 chars)
+template <int R, bool NULLS>
+__device__ inline void vm_load_issue_b(const ScanParams& P, int64_t tile_base, int g0, LoadRegs<R, NULLS>& g, uint32_t& err) {
+    const VmProgram& G = P.prog;
+    if (!G.has_utf8_loads) return;
+    const int tid = threadIdx.x;
 #pragma unroll
-        for (int j = 0; j < GROUP; ++j) {
-            if (g0 + j < G.n_loads) {
-                const VmLoad ld = G.loads[g0 + j];
+    for (int j = 0; j < LOAD_GROUP; ++j) {
+        if (g0 + j < G.n_loads && G.loads[g0 + j].dtype == DT_UTF8) {
+            const VmLoad ld = G.loads[g0 + j];
+            const ColumnRef& c = P.cols[ld.col];
+            const BHIP_GLOBAL uint8_t* data = gptr<uint8_t>(c.data);
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int idx = r * BLOCK + tid;
-                    const uint8_t k = NULLS ? ok[NULLS ? j : 0][NULLS ? r : 0] : (uint8_t)1;
-                    if (ld.to_bool) {
-                        L.bvals[ld.dst * TILE + idx] = (uint8_t)((x[j][r] & k) | (k << 1));
+            for (int r = 0; r < R; ++r) {
+                const int64_t row = tile_base + r * BLOCK + tid;
+                uint64_t packed = 0;
+                if (row < P.n_rows) {
+                    const uint32_t o0 = (uint32_t)g.x[j][r];
+                    uint32_t len = (uint32_t)(g.x[j][r] >> 32);
+                    if (len > (uint32_t)ld.width - 1u) { err |= SCAN_ERR_KEY_TOO_LONG; len = ld.width - 1u; }
+                    uint64_t bytes = 0;
+                    if ((int64_t)o0 + 8 <= (int64_t)c.data_bytes) {
+                        bytes = ((const BHIP_GLOBAL PackedU64*)(data + o0))->v;   // one unaligned 8-byte load
                     } else {
-                        L.vals[ld.dst * TILE + idx] = x[j][r];
-                        if (NULLS) L.vvalid[ld.dst * TILE + idx] = k;
+                        for (uint32_t b = 0; b < len; ++b) bytes |= (uint64_t)data[o0 + b] << (8 * b);
                     }
+                    if (len < 8) bytes &= (1ull << (8 * len)) - 1ull;
+                    packed = (uint64_t)len | (bytes << 8);
+                }
+                g.x[j][r] = packed;
+            }
+        }
+    }
+}
+
+template <int R, bool NULLS>
+__device__ inline void vm_load_commit(const ScanParams& P, const TileLds& L, int g0, const LoadRegs<R, NULLS>& g) {
+    constexpr int TILE = BLOCK * R;
+    const VmProgram& G = P.prog;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < LOAD_GROUP; ++j) {
+        if (g0 + j < G.n_loads) {
+            const VmLoad ld = G.loads[g0 + j];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int idx = r * BLOCK + tid;
+                const uint8_t k = NULLS ? g.ok[NULLS ? j : 0][NULLS ? r : 0] : (uint8_t)1;
+                if (ld.to_bool) {
+                    L.bvals[ld.dst * TILE + idx] = (uint8_t)((g.x[j][r] & k) | (k << 1));
+                } else {
+                    L.vals[ld.dst * TILE + idx] = g.x[j][r];
+                    if (NULLS) L.vvalid[ld.dst * TILE + idx] = k;
                 }
             }
         }
     }
 }
 
+// loads [from, n_loads) of a tile, blocking (issue A, issue B, commit per group of LOAD_GROUP)
+template <int R, bool NULLS>
+__device__ inline void vm_load_tile(const ScanParams& P, const TileLds& L, int64_t tile_base, uint32_t& err, int from = 0) {
+    for (int g0 = from; g0 < P.prog.n_loads; g0 += LOAD_GROUP) {
+        LoadRegs<R, NULLS> g;
+        vm_load_issue_a<R, NULLS>(P, tile_base, g0, g);
+        vm_load_issue_b<R, NULLS>(P, tile_base, g0, g, err);
+        vm_load_commit<R, NULLS>(P, L, g0, g);
+    }
+}
+
 // ---- Utf8 helpers --------------------------------------------------------------------
 // three-way compare of a row's string with `lit[0..litlen)` (bytes; UTF-8 byte order)
-__device__ inline int str_cmp3(const uint8_t* s, int len, const uint8_t* t, int tlen) {
+template <class PA, class PB>
+__device__ inline int str_cmp3(PA s, int len, PB t, int tlen) {
     const int m = len < tlen ? len : tlen;
     for (int i = 0; i < m; ++i) {
         const int d = (int)s[i] - (int)t[i];
@@ -128,7 +211,8 @@ __device__ inline bool cmp3_to_bool(int c, int kind) {
     }
 }
 
-__device__ inline bool str_like(const uint8_t* s, int len, const uint8_t* p, int plen, int kind) {
+template <class PA, class PB>
+__device__ inline bool str_like(PA s, int len, PB p, int plen, int kind) {
     if (kind == LIKE_EXACT) return len == plen && str_cmp3(s, len, p, plen) == 0;
     if (len < plen) return false;
     if (kind == LIKE_PREFIX) return str_cmp3(s, plen, p, plen) == 0;
@@ -150,7 +234,7 @@ __device__ inline bool cmp_vals(T a, T b, int kind) {
     }
 }
 
-__device__ inline double math_f64(double x, int fn) {
+__device__ __attribute__((noinline)) double math_f64(double x, int fn) {
     switch (fn) {
         case FN_SQRT: return sqrt(x);
         case FN_ABS: return fabs(x);
@@ -192,10 +276,12 @@ __device__ inline void vm_execute(const ScanParams& P, const TileLds& L, int64_t
 
 #define BHIP_FOR_R _Pragma("unroll") for (int r = 0; r < R; ++r)
 #define IDX (r * BLOCK + tid)
-#define VA ((I.flags & VF_A_LIT) ? lit_a : L.vals[I.a * TILE + IDX])
-#define VB ((I.flags & VF_B_LIT) ? lit_b : L.vals[I.b * TILE + IDX])
-#define KA ((!NULLS || (I.flags & VF_A_LIT)) ? (uint8_t)1 : L.vvalid[I.a * TILE + IDX])
-#define KB ((!NULLS || (I.flags & VF_B_LIT)) ? (uint8_t)1 : L.vvalid[I.b * TILE + IDX])
+// operand fetch without branches: a literal operand still reads slot 0 and the (wave-uniform)
+// select picks the literal — one v_cndmask pair instead of a scalar branch per row
+#define VA (a_lit ? lit_a : L.vals[slot_a * TILE + IDX])
+#define VB (b_lit ? lit_b : L.vals[slot_b * TILE + IDX])
+#define KA ((uint8_t)(NULLS ? (a_lit ? (uint8_t)1 : L.vvalid[slot_a * TILE + IDX]) : (uint8_t)1))
+#define KB ((uint8_t)(NULLS ? (b_lit ? (uint8_t)1 : L.vvalid[slot_b * TILE + IDX]) : (uint8_t)1))
 #define PUT_V(val, known)                                   \
     do {                                                    \
         L.vals[I.dst * TILE + IDX] = (val);                 \
@@ -210,8 +296,10 @@ __device__ inline void vm_execute(const ScanParams& P, const TileLds& L, int64_t
 
     for (int pc = 0; pc < G.n_instr; ++pc) {
         const VmInstr I = G.instr[pc];
-        const uint64_t lit_a = (I.flags & VF_A_LIT) ? G.lits[I.a] : 0;
-        const uint64_t lit_b = (I.flags & VF_B_LIT) ? G.lits[I.b] : 0;
+        const bool a_lit = I.flags & VF_A_LIT, b_lit = I.flags & VF_B_LIT;
+        const uint64_t lit_a = G.lits[a_lit ? I.a : 0];
+        const uint64_t lit_b = G.lits[b_lit ? I.b : 0];
+        const int slot_a = a_lit ? 0 : I.a, slot_b = b_lit ? 0 : I.b;
         switch (I.op) {
             case OP_ADD_F64: BHIP_FOR_R { const uint8_t k = KA & KB; PUT_V(d2u(u2d(VA) + u2d(VB)), k); } break;
             case OP_SUB_F64: BHIP_FOR_R { const uint8_t k = KA & KB; PUT_V(d2u(u2d(VA) - u2d(VB)), k); } break;
@@ -330,8 +418,8 @@ __device__ inline void vm_execute(const ScanParams& P, const TileLds& L, int64_t
                     bool v = false, k = false;
                     if (row < P.n_rows) {
                         k = !NULLS || column_valid_bit(c, row);
-                        const int32_t o0 = c.offsets[row], o1 = c.offsets[row + 1];
-                        const uint8_t* s = reinterpret_cast<const uint8_t*>(c.data) + o0;
+                        const int32_t o0 = gptr<int32_t>(c.offsets)[row], o1 = gptr<int32_t>(c.offsets)[row + 1];
+                        const BHIP_GLOBAL uint8_t* s = gptr<uint8_t>(c.data) + o0;
                         if (I.op == OP_STR_CMP_LIT) v = cmp3_to_bool(str_cmp3(s, o1 - o0, lit, I.b), I.aux);
                         else v = str_like(s, o1 - o0, lit, I.b, I.aux);
                         if (I.flags & VF_NEGATE) v = !v;
@@ -347,10 +435,9 @@ __device__ inline void vm_execute(const ScanParams& P, const TileLds& L, int64_t
                     bool v = false, k = false;
                     if (row < P.n_rows) {
                         k = !NULLS || (column_valid_bit(ca, row) && column_valid_bit(cb, row));
-                        const int32_t a0 = ca.offsets[row], a1 = ca.offsets[row + 1];
-                        const int32_t b0 = cb.offsets[row], b1 = cb.offsets[row + 1];
-                        v = cmp3_to_bool(str_cmp3(reinterpret_cast<const uint8_t*>(ca.data) + a0, a1 - a0,
-                                                  reinterpret_cast<const uint8_t*>(cb.data) + b0, b1 - b0), I.aux);
+                        const int32_t a0 = gptr<int32_t>(ca.offsets)[row], a1 = gptr<int32_t>(ca.offsets)[row + 1];
+                        const int32_t b0 = gptr<int32_t>(cb.offsets)[row], b1 = gptr<int32_t>(cb.offsets)[row + 1];
+                        v = cmp3_to_bool(str_cmp3(gptr<uint8_t>(ca.data) + a0, a1 - a0, gptr<uint8_t>(cb.data) + b0, b1 - b0), I.aux);
                     }
                     PUT_B(v, k);
                 }
@@ -423,11 +510,11 @@ __device__ inline Key128 pack_key(const ScanParams& P, const TileLds& L, int64_t
                 if (NULLS) valid = column_valid_bit(c, row);
                 if (kp.nullable) { key_put(k, pos, valid ? 1 : 0, 1); pos += 1; width -= 1; }
                 if (valid) {
-                    const int32_t o0 = c.offsets[row], o1 = c.offsets[row + 1];
+                    const int32_t o0 = gptr<int32_t>(c.offsets)[row], o1 = gptr<int32_t>(c.offsets)[row + 1];
                     int len = o1 - o0;
                     if (len > width - 1) { err |= SCAN_ERR_KEY_TOO_LONG; len = width - 1; }
                     key_put(k, pos, (uint64_t)len, 1);
-                    const uint8_t* s = reinterpret_cast<const uint8_t*>(c.data) + o0;
+                    const BHIP_GLOBAL uint8_t* s = gptr<uint8_t>(c.data) + o0;
                     for (int j = 0; j < len; ++j) key_put(k, pos + 1 + j, s[j], 1);
                 }
             } else if (kp.nullable) { pos += 1; width -= 1; }

@@ -76,8 +76,10 @@ enum : uint8_t { VF_A_LIT = 1, VF_B_LIT = 2, VF_NEGATE = 4 };
 struct VmLoad {
     uint8_t col;            // index into ScanParams::cols
     uint8_t dst;            // slot
-    uint8_t dtype;          // DType of the column
+    uint8_t dtype;          // DType of the column; DT_UTF8 = short-string pack: [len][bytes...] in one V slot
     uint8_t to_bool;        // 1: Boolean column -> B slot
+    uint8_t width;          // DT_UTF8: bytes of the packed image (1 length byte + at most width-1 <= 7 chars)
+    uint8_t pad[3];
 };
 
 struct ColumnRef {          // one Arrow column, device pointers
@@ -85,7 +87,7 @@ struct ColumnRef {          // one Arrow column, device pointers
     const int32_t* offsets; // Utf8 only
     const uint64_t* validity; // Arrow validity bitmap (bit i = row i valid) or nullptr
     int32_t dtype;
-    int32_t pad;
+    int32_t data_bytes;     // Utf8: number of value bytes (bounds the 8-byte short-string loads)
 };
 
 constexpr int VM_MAX_COLS = 16;
@@ -102,7 +104,8 @@ constexpr int VM_MAX_OUT = 16;
 struct VmProgram {
     int32_t n_loads, n_instr, n_vslots, n_bslots;
     int32_t nullable;       // 1: some input may be NULL -> V-slot validity bytes are live
-    int32_t pad[3];
+    int32_t has_utf8_loads; // 1: some load is a DT_UTF8 short-string pack (two dependent load stages)
+    int32_t pad[2];
     VmLoad loads[VM_MAX_LOADS];
     VmInstr instr[VM_MAX_INSTR];
     uint64_t lits[VM_MAX_LITS];

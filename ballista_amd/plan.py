@@ -172,6 +172,32 @@ class _Lowered:
             raise TypeError(f"not a PhysicalExpr: {e!r}")
 
 
+# ---- Arrow C Data / C Stream interface structs (layout of include/ballista_hip.h) --------------------
+
+class _ArrowSchema(C.Structure):
+    pass
+
+
+_ArrowSchema._fields_ = [("format", C.c_char_p), ("name", C.c_char_p), ("metadata", C.c_char_p), ("flags", C.c_int64),
+                         ("n_children", C.c_int64), ("children", C.c_void_p), ("dictionary", C.c_void_p),
+                         ("release", C.CFUNCTYPE(None, C.POINTER(_ArrowSchema))), ("private_data", C.c_void_p)]
+
+
+class _ArrowArray(C.Structure):
+    pass
+
+
+_ArrowArray._fields_ = [("length", C.c_int64), ("null_count", C.c_int64), ("offset", C.c_int64), ("n_buffers", C.c_int64),
+                        ("n_children", C.c_int64), ("buffers", C.c_void_p), ("children", C.c_void_p),
+                        ("dictionary", C.c_void_p), ("release", C.CFUNCTYPE(None, C.POINTER(_ArrowArray))),
+                        ("private_data", C.c_void_p)]
+
+
+class _ArrowArrayStream(C.Structure):
+    _fields_ = [("get_schema", C.c_void_p), ("get_next", C.c_void_p), ("get_last_error", C.c_void_p),
+                ("release", C.c_void_p), ("private_data", C.c_void_p)]
+
+
 # ---- record batches ---------------------------------------------------------------------------------
 
 class RecordBatch:
@@ -242,21 +268,19 @@ class RecordBatch:
     def from_pyarrow(ctx: Context, batch) -> "RecordBatch":
         """through the Arrow C Data Interface (bhip_batch_import_arrow)"""
         import pyarrow as pa
-        from pyarrow.cffi import ffi
         if isinstance(batch, pa.Table):
             batch = batch.combine_chunks().to_batches()[0] if batch.num_rows else pa.RecordBatch.from_pylist([], schema=batch.schema)
-        c_arr = ffi.new("struct ArrowArray*")
-        c_sch = ffi.new("struct ArrowSchema*")
-        batch._export_to_c(int(ffi.cast("uintptr_t", c_arr)), int(ffi.cast("uintptr_t", c_sch)))
+        c_arr, c_sch = _ArrowArray(), _ArrowSchema()
+        batch._export_to_c(C.addressof(c_arr), C.addressof(c_sch))
         h = C.c_void_p()
         try:
-            L.check(L.lib().bhip_batch_import_arrow(ctx._h, int(ffi.cast("uintptr_t", c_arr)),
-                                                    int(ffi.cast("uintptr_t", c_sch)), C.byref(h)))
+            L.check(L.lib().bhip_batch_import_arrow(ctx._h, C.addressof(c_arr), C.addressof(c_sch), C.byref(h)))
         finally:
-            if c_arr.release != ffi.NULL:
-                c_arr.release(c_arr)
-            if c_sch.release != ffi.NULL:
-                c_sch.release(c_sch)
+            # the array is consumed on success; whatever is still live is released here
+            if c_arr.release:
+                c_arr.release(C.byref(c_arr))
+            if c_sch.release:
+                c_sch.release(C.byref(c_sch))
         return RecordBatch(h, ctx)
 
     # -- accessors
@@ -323,11 +347,9 @@ class RecordBatch:
     def to_pyarrow(self):
         """through the Arrow C Data Interface (bhip_batch_export_arrow)"""
         import pyarrow as pa
-        from pyarrow.cffi import ffi
-        c_arr = ffi.new("struct ArrowArray*")
-        c_sch = ffi.new("struct ArrowSchema*")
-        L.check(L.lib().bhip_batch_export_arrow(self._h, int(ffi.cast("uintptr_t", c_arr)), int(ffi.cast("uintptr_t", c_sch))))
-        return pa.RecordBatch._import_from_c(int(ffi.cast("uintptr_t", c_arr)), int(ffi.cast("uintptr_t", c_sch)))
+        c_arr, c_sch = _ArrowArray(), _ArrowSchema()
+        L.check(L.lib().bhip_batch_export_arrow(self._h, C.addressof(c_arr), C.addressof(c_sch)))
+        return pa.RecordBatch._import_from_c(C.addressof(c_arr), C.addressof(c_sch))
 
 
 class RecordBatchStream:
@@ -361,11 +383,11 @@ class RecordBatchStream:
     def to_arrow_reader(self):
         """hand the stream to pyarrow through the Arrow C Stream Interface (consumes it)"""
         import pyarrow as pa
-        from pyarrow.cffi import ffi
-        c_stream = ffi.new("struct ArrowArrayStream*")
-        L.check(L.lib().bhip_stream_export_arrow(self._h, int(ffi.cast("uintptr_t", c_stream))))
+        c_stream = _ArrowArrayStream()
+        L.check(L.lib().bhip_stream_export_arrow(self._h, C.addressof(c_stream)))
         self._h = None
-        return pa.RecordBatchReader._import_from_c(int(ffi.cast("uintptr_t", c_stream)))
+        # the importer moves the struct out of `c_stream` (C Stream Interface ownership rules)
+        return pa.RecordBatchReader._import_from_c(C.addressof(c_stream))
 
     def __del__(self):
         try:

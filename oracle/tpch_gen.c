@@ -75,6 +75,8 @@ void tpch_gen_lineitem(uint64_t seed, uint64_t row0, uint64_t n,
                        int32_t *flag_off, uint8_t *flag_data,
                        int32_t *status_off, uint8_t *status_data)
 {
+    /* rows are independent (counter hash): generate them on all host cores */
+#pragma omp parallel for schedule(static)
     for (uint64_t k = 0; k < n; k++) {
         uint64_t row = row0 + k;
         uint64_t o = line_to_order(seed, row, n_orders, NULL);
