@@ -14,15 +14,15 @@ struct SopAccExpr {
 
 struct SopPlan {
     SopProgram prog;
-    std::vector<int> col_map;   // SOP column index -> source schema index
+    std::vector<int> col_map;                          // SOP column index -> source schema index
+    std::vector<ProgramBuilder::KeyInfo> key_info;     // packed-key layout of THIS path (for the emit kernels)
 };
 
-// true when (predicate, keys, accumulators) have the chain-of-products shape; `key_info` / `key_bytes`
-// are the packed-key layout of the VM program so both kernels emit identical GroupRec keys
+// true when (predicate, keys, accumulators) have the chain-of-products shape
 bool build_sop(const Schema& schema, const ExprPtr& predicate, const std::vector<ExprPtr>& keys,
-               const std::vector<ProgramBuilder::KeyInfo>& key_info, int key_bytes,
                const std::vector<SopAccExpr>& accs, SopPlan& out);
-// fill in the column pointers of one batch; false when a referenced column carries NULLs
-bool bind_sop(SopPlan& plan, const Batch& b);
+// false when a referenced column of the batch carries NULLs (then the VM kernel runs)
+bool sop_columns_bindable(const SopPlan& plan, const Batch& b);
+void bind_sop(SopPlan& plan, const Batch& b);
 
 }  // namespace bhip

@@ -1,5 +1,14 @@
-// sop.h — the "chain of products" plan table of the register-resident aggregate fast path
-// (kernels_sop.hip); built by host/sop.cpp from the same expressions the VM program is built from.
+// sop.h — plan table of the register-resident aggregate fast path (sop_kernel.h); built by
+// host/sop.cpp from the same expressions the VM program is built from.
+//
+// The table is branch-free by construction — every entry is data for straight-line code:
+//   predicate : AND of ranges   lo <= (double)x <= hi      (one range per column: comparisons on the
+//               same column are intersected; strict bounds move to the neighbouring double / integer)
+//   chain step: f = sgn * x + add ;  t = (start ? 1.0 : t_prev) * f
+//               (column: sgn 1, add -0.0 | lit - col: -1, lit | lit + col: 1, lit | col - lit: 1, -lit |
+//                literal: no column, sgn 0, add lit) — each is ONE correctly rounded add of the same two
+//               operands the reference adds, multiplication by +-1 / 1.0 is exact
+//   keys      : part 0 -> key word 0, part 1 -> key word 1, part 2 -> high half of word 1 (32-bit parts)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -7,7 +16,7 @@
 
 namespace bhip {
 
-constexpr int SOP_NPRED = 6;      // comparisons in the conjunction
+constexpr int SOP_NRANGE = 4;     // predicate ranges (distinct columns)
 constexpr int SOP_NKEY = 3;       // group-key columns
 constexpr int SOP_NSTEP = 8;      // chain steps (= accumulators)
 constexpr int SOP_NCOL = 16;
@@ -17,53 +26,37 @@ struct SopColumn {
     const int32_t* offsets;
     int32_t dtype;
     int32_t data_bytes;
-    // the same column starting `base` rows further (fixed-width types): lets the kernel index with 32 bits
-    __host__ __device__ SopColumn at(int64_t base) const {
-        SopColumn c = *this;
-        int w = 8;
-        if (dtype == DT_INT32 || dtype == DT_DATE32) w = 4;
-        else if (dtype == DT_UINT8) w = 1;
-        c.data = reinterpret_cast<const char*>(data) + base * w;
-        return c;
-    }
 };
 
-struct SopCmp {
-    uint8_t col;        // index into SopProgram::cols
-    uint8_t cmp;        // CmpKind:  value(col) <cmp> lit
-    uint8_t vclass;     // VC_I64, VC_F64, 3 = unsigned 64
-    uint8_t pad[5];
-    uint64_t lit;       // literal bits
+struct SopRange {
+    uint8_t col;        // index into SopProgram::cols (Float64, Int32 or Date32 column)
+    uint8_t is32;       // 1: 32-bit integer column (converted exactly to double)
+    uint8_t pad[6];
+    double lo, hi;
 };
 
-enum SopFactor : uint8_t {
-    SOP_F_COL = 0, SOP_F_LIT_MINUS_COL = 1, SOP_F_LIT_PLUS_COL = 2, SOP_F_COL_MINUS_LIT = 3, SOP_F_COL_PLUS_LIT = 4,
-    SOP_F_LIT = 5
-};
-enum SopOp : uint8_t { SOP_OP_START = 0, SOP_OP_MUL = 1, SOP_OP_DIV = 2 };
-
-struct SopStep {        // t_s = START ? f : t_(s-1) (*|/) f ,  f = factor(col, lit)
+struct SopStep {
     uint8_t col;
-    uint8_t mode;       // SopFactor
-    uint8_t op;         // SopOp
-    uint8_t acc;        // accumulator (GroupRec::acc index) that sums t_s, 0xFF = none
-    uint8_t pad[4];
-    double lit;
+    uint8_t is32;       // 1: Int32/Date32 column under CAST(... AS Float64)
+    uint8_t has_col;    // 0: literal factor
+    uint8_t start;      // 1: starts a new chain
+    uint8_t acc;        // accumulator (GroupRec::acc index) that sums t, 0xFF = none
+    uint8_t pad[3];
+    double sgn, add;
 };
 
+enum SopKeyKind : uint8_t { SOP_KEY_I32 = 0, SOP_KEY_I64 = 1, SOP_KEY_UTF8 = 2 };
 struct SopKey {
     uint8_t col;
-    uint8_t width;      // bytes in the packed key (Utf8: 1 length byte + chars)
-    uint8_t pos;        // byte position in the packed key
-    uint8_t pad;
+    uint8_t kind;       // SopKeyKind
+    uint8_t pad[2];
 };
 
 struct SopProgram {
     int64_t n_rows;
-    int32_t n_cols, n_pred, n_keys, n_steps;
-    int32_t key_bytes, pad;
+    int32_t n_cols, n_ranges, n_keys, n_steps;
     SopColumn cols[SOP_NCOL];
-    SopCmp pred[SOP_NPRED];
+    SopRange ranges[SOP_NRANGE];
     SopKey keys[SOP_NKEY];
     SopStep steps[SOP_NSTEP];
 };

@@ -2,7 +2,7 @@
 # usage: tools/pmc.sh <tag> "<counters>" <bench args...>   (run on the GPU box; output under gpurun_out/<tag>)
 TAG=$1; CTRS=$2; shift 2
 R=$PWD; export TMPDIR=/tmp; cd /tmp
-rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d $R/gpurun_out/$TAG -- python3 $R/bench.py "$@" > $R/gpurun_out/$TAG.log 2>&1
+rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d $R/gpurun_out/$TAG -- python3 $R/${PMC_SCRIPT:-bench.py} "$@" > $R/gpurun_out/$TAG.log 2>&1
 cd $R
 python3 - <<PY
 import csv, collections, glob
