@@ -71,6 +71,7 @@ SYMBOLS = {
     "bhip_ctx_synchronize": (C.c_int32, [_P]),
     "bhip_ctx_memory": (C.c_int32, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "bhip_ctx_kernel_time": (C.c_int32, [_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "bhip_ctx_kernel_name": (C.c_char_p, [_P]),
     "bhip_batch_from_host": (C.c_int32, [_P, C.c_int32, C.POINTER(ColumnDesc), C.c_int64, _PP]),
     "bhip_batch_from_device": (C.c_int32, [_P, C.c_int32, C.POINTER(ColumnDesc), C.c_int64, _PP]),
     "bhip_batch_import_arrow": (C.c_int32, [_P, _P, _P, _PP]),

@@ -76,6 +76,12 @@ bhip_status bhip_ctx_kernel_time(bhip_ctx* ctx, int32_t reset, double* ms, uint6
     BHIP_API_END
 }
 
+const char* bhip_ctx_kernel_name(bhip_ctx* ctx) {
+    static thread_local std::string name;
+    name = ctx ? ctx->p->kernel_name() : std::string();
+    return name.c_str();
+}
+
 // ---- batches ------------------------------------------------------------------------------------------
 static bhip_batch* wrap_batch(BatchPtr b) {
     auto h = new bhip_batch();

@@ -159,10 +159,16 @@ void Context::release_stream(hipStream_t s) {
     stream_pool_.push_back(s);
 }
 
-void Context::add_kernel_time(double ms, uint64_t launches) {
+void Context::add_kernel_time(double ms, uint64_t launches, const char* kernel) {
     std::lock_guard<std::mutex> g(mu_);
     k_ms_ += ms;
     k_launches_ += launches;
+    if (kernel && launches) k_name_ = kernel;
+}
+
+std::string Context::kernel_name() {
+    std::lock_guard<std::mutex> g(mu_);
+    return k_name_;
 }
 
 void Context::kernel_time(bool reset, double* ms, uint64_t* launches) {

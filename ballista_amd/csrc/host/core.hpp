@@ -70,7 +70,8 @@ public:
     void release_stream(hipStream_t s);
 
     // kernel timing hook (bench roofline): accumulated by the aggregate operator
-    void add_kernel_time(double ms, uint64_t launches);
+    void add_kernel_time(double ms, uint64_t launches, const char* kernel = nullptr);
+    std::string kernel_name();
     void kernel_time(bool reset, double* ms, uint64_t* launches);
     bool timing_enabled() const { return timing_; }
 
@@ -85,6 +86,7 @@ private:
     std::vector<hipStream_t> stream_pool_;
     double k_ms_ = 0;
     uint64_t k_launches_ = 0;
+    std::string k_name_;
 };
 using ContextPtr = std::shared_ptr<Context>;
 

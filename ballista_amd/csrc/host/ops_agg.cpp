@@ -147,6 +147,7 @@ struct TimedLaunches {
     void end() {
         if (on) HIP_CHECK(hipEventRecord(ev.back().second, ex.stream));
     }
+    const char* kernel = nullptr;
     void collect() {   // call after the stream was synchronised
         if (!on) return;
         double ms = 0;
@@ -156,7 +157,7 @@ struct TimedLaunches {
             hipEventDestroy(p.first);
             hipEventDestroy(p.second);
         }
-        ex.ctx->add_kernel_time(ms, ev.size());
+        ex.ctx->add_kernel_time(ms, ev.size(), kernel);
         ev.clear();
     }
 };
@@ -362,7 +363,7 @@ std::vector<BatchPtr> HashAggregateExec::run(int partition, const Exec& ex) cons
             ProgramBuilder::bind(P, pb.columns(), *b, nullable);
             int grid = 0;
             const bool timed = b->n_rows >= (1 << 16);   // the bench hook times the dominant (large) launches only
-            if (timed) timer.begin();
+            if (timed) { timer.begin(); timer.kernel = use_sop ? "scan_agg_sop_kernel" : "scan_agg_lowcard_kernel"; }
             if (use_sop) {
                 bind_sop(sop, *b);
                 HIP_CHECK(launch_scan_agg_sop(cfg, sop.prog, tmp.get<SopProgram>(1), gmax, partials + (size_t)n_part * gmax,

@@ -69,6 +69,9 @@ class Context:
         L.check(L.lib().bhip_ctx_kernel_time(self._h, 1 if reset else 0, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def kernel_name(self):
+        return L.lib().bhip_ctx_kernel_name(self._h).decode()
+
     def __del__(self):
         try:
             if getattr(self, "_h", None):

@@ -248,7 +248,7 @@ bhip_status bhip_plan_schema(const bhip_plan* plan, int32_t cap, const char** na
                              int32_t* nullable, int32_t* n_cols);
 /* output_partitioning() */
 bhip_status bhip_plan_output_partitioning(const bhip_plan* plan, int32_t* scheme, int32_t* partition_count);
-/* children(): borrowed handles */
+/* children(): NEW handles (the caller releases each) */
 bhip_status bhip_plan_children(const bhip_plan* plan, int32_t cap, bhip_plan** children, int32_t* n_children);
 /* with_new_children() */
 bhip_status bhip_plan_with_new_children(const bhip_plan* plan, int32_t n, bhip_plan* const* children, bhip_plan** out);
@@ -293,6 +293,8 @@ bhip_status bhip_tpch_orders(bhip_ctx* ctx, double sf, uint64_t seed, uint64_t r
 /* time (ms, HIP events on the stream the kernels ran on) and launch count of the dominant scan
  * kernel accumulated on this context since the last reset */
 bhip_status bhip_ctx_kernel_time(bhip_ctx* ctx, int32_t reset, double* ms, uint64_t* launches);
+/* name of the kernel those launches ran ("" before the first timed launch); valid until the next call */
+const char* bhip_ctx_kernel_name(bhip_ctx* ctx);
 
 #ifdef __cplusplus
 }
