@@ -181,7 +181,7 @@ void Context::kernel_time(bool reset, double* ms, uint64_t* launches) {
 // ---- buffers ------------------------------------------------------------------------------------
 Buffer::Buffer(ContextPtr ctx, size_t bytes, hipStream_t stream)
     : ctx_(std::move(ctx)), ptr_(nullptr), bytes_(bytes), owned_(true), stream_(stream) {
-    ptr_ = ctx_->alloc(bytes ? bytes : 8, stream);
+    ptr_ = ctx_->alloc((bytes ? bytes : 8) + BUFFER_SLACK, stream);
 }
 Buffer::Buffer(ContextPtr ctx, void* borrowed, size_t bytes)
     : ctx_(std::move(ctx)), ptr_(borrowed), bytes_(bytes), owned_(false), stream_(nullptr) {}

@@ -98,6 +98,8 @@ struct Exec {
 };
 
 // ---- device buffers -----------------------------------------------------------------------------
+constexpr size_t BUFFER_SLACK = 16;
+
 class Buffer {
 public:
     Buffer(ContextPtr ctx, size_t bytes, hipStream_t stream);          // owned
@@ -107,6 +109,8 @@ public:
     Buffer& operator=(const Buffer&) = delete;
     void* ptr() const { return ptr_; }
     size_t bytes() const { return bytes_; }
+    // owned buffers carry BUFFER_SLACK readable bytes past bytes(): kernels may over-read short strings
+    bool owned() const { return owned_; }
     template <class T> T* as() const { return reinterpret_cast<T*>(ptr_); }
     void set_stream(hipStream_t s) { stream_ = s; }
 private:

@@ -331,6 +331,11 @@ std::vector<BatchPtr> HashAggregateExec::run(int partition, const Exec& ex) cons
     // the fast path packs keys its own way, so it serves either every batch of the run or none
     for (auto& b : inputs)
         if (use_sop && !sop_columns_bindable(sop, *b)) use_sop = false;
+    // ... and its wide-load variant (lean_kernel.h) when the plan and the buffers allow
+    static const bool lean_disabled = [] { const char* v = getenv("BHIP_NO_LEAN"); return v && atoi(v) != 0; }();
+    bool use_lean = use_sop && !lean_disabled && lean_eligible(sop.prog);
+    for (auto& b : inputs)
+        if (use_lean && !lean_bindable(sop, *b)) use_lean = false;
 
     Temp tmp(ex);
     const LaunchCfg cfg = ex.cfg();
@@ -358,13 +363,18 @@ std::vector<BatchPtr> HashAggregateExec::run(int partition, const Exec& ex) cons
         uint32_t* partial_ng = tmp.get<uint32_t>(max_parts);
         HIP_CHECK(hipMemsetAsync(status, 0, sizeof(ScanStatus), ex.stream));
         int n_part = 0;
+        const bool lean_now = use_sop && use_lean && (gmax == 1 || gmax == 4);
         for (auto& b : inputs) {
             ScanParams P = P0;
             ProgramBuilder::bind(P, pb.columns(), *b, nullable);
             int grid = 0;
             const bool timed = b->n_rows >= (1 << 16);   // the bench hook times the dominant (large) launches only
-            if (timed) { timer.begin(); timer.kernel = use_sop ? "scan_agg_sop_kernel" : "scan_agg_lowcard_kernel"; }
-            if (use_sop) {
+            if (timed) { timer.begin(); timer.kernel = lean_now ? "scan_agg_lean_kernel" : use_sop ? "scan_agg_sop_kernel" : "scan_agg_lowcard_kernel"; }
+            if (lean_now) {
+                bind_sop(sop, *b);
+                HIP_CHECK(launch_scan_agg_lean(cfg, sop.prog, tmp.get<SopProgram>(1), gmax, partials + (size_t)n_part * gmax,
+                                               partial_ng + n_part, max_grid, status, &grid));
+            } else if (use_sop) {
                 bind_sop(sop, *b);
                 HIP_CHECK(launch_scan_agg_sop(cfg, sop.prog, tmp.get<SopProgram>(1), gmax, partials + (size_t)n_part * gmax,
                                               partial_ng + n_part, max_grid, status, &grid));
@@ -382,6 +392,10 @@ std::vector<BatchPtr> HashAggregateExec::run(int partition, const Exec& ex) cons
         HIP_CHECK(launch_merge_partials(cfg, partials, partial_ng, n_part, gmax, specs, n_acc, table, cap, entry_group, status));
         ScanStatus st = read_device(ex, status);
         timer.collect();
+        if (lean_now && (st.flags & SCAN_ERR_KEY_TOO_LONG)) {
+            use_lean = false;                // a string key longer than 3 bytes: the 7-byte variant next
+            continue;
+        }
         if (use_sop && (st.flags & SCAN_ERR_KEY_TOO_LONG)) {
             use_sop = false;                 // a string key longer than the fast path's 7 bytes: the VM packs up to 15
             continue;

@@ -231,4 +231,26 @@ void bind_sop(SopPlan& plan, const Batch& b) {
     }
 }
 
+bool lean_eligible(const SopProgram& prog) {
+    if (prog.n_keys > 2) return false;
+    for (int q = 0; q < prog.n_keys; ++q)
+        if (prog.keys[q].kind != SOP_KEY_I32 && prog.keys[q].kind != SOP_KEY_UTF8) return false;
+    for (int s = 0; s < prog.n_steps; ++s) {
+        const SopStep& st = prog.steps[s];
+        if (!st.has_col || st.is32) return false;
+        if (st.sgn != 1.0 && st.sgn != -1.0) return false;
+    }
+    return true;
+}
+
+bool lean_bindable(const SopPlan& plan, const Batch& b) {
+    for (int ci : plan.col_map) {
+        const Column& c = b.cols[ci];
+        if (c.data && ((uintptr_t)c.data->ptr() & 15)) return false;
+        if (c.offsets && ((uintptr_t)c.offsets->ptr() & 15)) return false;
+        if (c.dtype == DT_UTF8 && c.data && !c.data->owned()) return false;
+    }
+    return true;
+}
+
 }  // namespace bhip

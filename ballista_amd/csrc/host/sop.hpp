@@ -25,4 +25,10 @@ bool build_sop(const Schema& schema, const ExprPtr& predicate, const std::vector
 bool sop_columns_bindable(const SopPlan& plan, const Batch& b);
 void bind_sop(SopPlan& plan, const Batch& b);
 
+// the wide-load variant (lean_kernel.h): every chain factor a Float64 column, <= 2 key parts of 32 bits
+// (Int32 / Date32 / Utf8 of <= 3 bytes, checked by the kernel)
+bool lean_eligible(const SopProgram& prog);
+// its loads need 16-byte aligned column buffers and slack behind the string bytes (owned buffers have both)
+bool lean_bindable(const SopPlan& plan, const Batch& b);
+
 }  // namespace bhip

@@ -65,4 +65,8 @@ struct SopProgram {
 hipError_t launch_scan_agg_sop(const LaunchCfg& cfg, const SopProgram& S, SopProgram* dprog, int gmax, GroupRec* partials,
                                uint32_t* partial_ng, int max_grid, ScanStatus* status, int* grid_out);
 
+// wide-load variant (lean_kernel.h): gmax 1 or 4, plans accepted by host/sop.cpp::lean_eligible
+hipError_t launch_scan_agg_lean(const LaunchCfg& cfg, const SopProgram& S, SopProgram* dprog, int gmax, GroupRec* partials,
+                                uint32_t* partial_ng, int max_grid, ScanStatus* status, int* grid_out);
+
 }  // namespace bhip
