@@ -268,6 +268,27 @@ class RecordBatch:
         return RecordBatch(h, ctx)
 
     @staticmethod
+    def from_device_columns(ctx: Context, owner: "RecordBatch") -> "RecordBatch":
+        """bhip_batch_from_device: a batch that BORROWS the device buffers of `owner` (zero copy; the
+        result keeps `owner` alive).  Any caller-owned device memory laid out as Arrow works the same."""
+        descs, keep = [], []
+        for i in range(owner.num_columns):
+            name, dtype, nullable, nbytes, _ = owner.column_info(i)
+            data, offsets, validity = owner.column_device(i)
+            d = L.ColumnDesc()
+            nb = name.encode()
+            keep.append(nb)
+            d.name, d.dtype, d.nullable = nb, DTYPE_ID[dtype], 1 if nullable else 0
+            d.data, d.offsets, d.validity, d.data_bytes = data, offsets, validity, nbytes
+            descs.append(d)
+        arr = (L.ColumnDesc * max(1, len(descs)))(*descs)
+        h = C.c_void_p()
+        L.check(L.lib().bhip_batch_from_device(ctx._h, len(descs), arr, owner.num_rows, C.byref(h)))
+        rb = RecordBatch(h, ctx)
+        rb._owner = owner
+        return rb
+
+    @staticmethod
     def from_pyarrow(ctx: Context, batch) -> "RecordBatch":
         """through the Arrow C Data Interface (bhip_batch_import_arrow)"""
         import pyarrow as pa
