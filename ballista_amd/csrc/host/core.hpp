@@ -185,8 +185,10 @@ BatchPtr batch_from_host(const ContextPtr& ctx, int n_cols, const bhip_column_de
 void column_to_host(const Batch& b, int i, void* data, int32_t* offsets, uint8_t* validity);
 
 // whole-batch operations (ops_basic.cpp)
-BatchPtr take_batch(const Exec& ex, const Batch& in, const uint32_t* indices, int64_t n_out, SchemaPtr schema = nullptr);
-Column take_column(const Exec& ex, const Column& c, const uint32_t* indices, int64_t n_out);
+// permutation: `indices` holds every input row exactly once (Utf8 value bytes are then known without a read-back)
+BatchPtr take_batch(const Exec& ex, const Batch& in, const uint32_t* indices, int64_t n_out, SchemaPtr schema = nullptr,
+                    bool permutation = false);
+Column take_column(const Exec& ex, const Column& c, const uint32_t* indices, int64_t n_out, int64_t known_bytes = -1);
 BatchPtr concat_batches(const Exec& ex, const SchemaPtr& schema, const std::vector<BatchPtr>& parts);
 BatchPtr slice_head(const Exec& ex, const Batch& in, int64_t n);
 

@@ -435,6 +435,10 @@ std::vector<BatchPtr> HashAggregateExec::run(int partition, const Exec& ex) cons
     out->ctx = ex.ctx;
     out->n_rows = n_groups;
     const auto& kinfo = use_sop ? sop.key_info : pb.key_info();
+    // Utf8 key columns: the value bytes have the packed key's bound (width - 1 per group), so the bytes are
+    // written before their total is known (width bytes per group bounds them); the totals come back in ONE read after everything is queued
+    uint64_t* totals = tmp.get<uint64_t>(group_.size() + 1);
+    std::vector<size_t> utf8_cols;
     for (size_t gi = 0; gi < group_.size(); ++gi) {
         Column c;
         c.dtype = schema_->fields[gi].dtype;
@@ -445,13 +449,12 @@ std::vector<BatchPtr> HashAggregateExec::run(int partition, const Exec& ex) cons
         if (c.dtype == DT_UTF8) {
             uint32_t* lengths = tmp.get<uint32_t>((size_t)n_groups + 1);
             c.offsets = make_buffer(ex, (size_t)(n_groups + 1) * 4);
-            uint64_t* total = tmp.get<uint64_t>(1);
             void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes(n_groups));
             if (n_groups) HIP_CHECK(launch_emit_group_key(cfg, table, n_groups, ks, nullptr, vptr, lengths));
-            HIP_CHECK(exclusive_scan_u32_i32(ex.stream, lengths, n_groups, c.offsets->as<int32_t>(), true, total, scan_tmp));
-            c.data_bytes = (int64_t)read_device(ex, total);
-            c.data = make_buffer(ex, (size_t)c.data_bytes + 8);
+            HIP_CHECK(exclusive_scan_u32_i32(ex.stream, lengths, n_groups, c.offsets->as<int32_t>(), true, totals + gi, scan_tmp));
+            c.data = make_buffer(ex, (size_t)n_groups * (size_t)kinfo[gi].width + 8);
             if (n_groups) HIP_CHECK(launch_emit_group_utf8(cfg, table, n_groups, ks, c.offsets->as<int32_t>(), c.data->as<uint8_t>()));
+            utf8_cols.push_back(gi);
         } else {
             const size_t bytes = c.dtype == DT_BOOLEAN ? bitmap_bytes(n_groups) : (size_t)n_groups * dtype_width(c.dtype);
             c.data = make_buffer(ex, bytes + 8);
@@ -459,6 +462,9 @@ std::vector<BatchPtr> HashAggregateExec::run(int partition, const Exec& ex) cons
         }
         out->cols.push_back(std::move(c));
     }
+    // value columns: one launch per EMIT_BATCH_MAX columns
+    EmitValueBatch vb;
+    vb.n = 0;
     for (size_t k = 0; k < emits.size(); ++k) {
         EmitValueSpec sp = emits[k];
         sp.count_is_rows = nullable ? 0 : 1;
@@ -468,11 +474,23 @@ std::vector<BatchPtr> HashAggregateExec::run(int partition, const Exec& ex) cons
         c.length = n_groups;
         c.data = make_buffer(ex, (size_t)n_groups * dtype_width(c.dtype) + 8);
         if (fld.nullable) c.validity = make_buffer(ex, bitmap_bytes(n_groups) + 8);
-        if (n_groups)
-            HIP_CHECK(launch_emit_group_value(cfg, table, n_groups, sp, c.data->ptr(), c.validity ? c.validity->as<uint64_t>() : nullptr));
+        vb.spec[vb.n] = sp;
+        vb.data[vb.n] = c.data->ptr();
+        vb.validity[vb.n] = c.validity ? c.validity->as<uint64_t>() : nullptr;
+        if (++vb.n == EMIT_BATCH_MAX || k + 1 == emits.size()) {
+            HIP_CHECK(launch_emit_group_values(cfg, table, n_groups, vb));
+            vb.n = 0;
+        }
         out->cols.push_back(std::move(c));
     }
-    HIP_CHECK(hipStreamSynchronize(ex.stream));
+    if (!utf8_cols.empty()) {
+        std::vector<uint64_t> host(group_.size());
+        HIP_CHECK(hipMemcpyAsync(host.data(), totals, group_.size() * 8, hipMemcpyDeviceToHost, ex.stream));
+        HIP_CHECK(hipStreamSynchronize(ex.stream));
+        for (size_t gi : utf8_cols) out->cols[gi].data_bytes = (int64_t)host[gi];
+    } else {
+        HIP_CHECK(hipStreamSynchronize(ex.stream));
+    }
     return {out};
 }
 

@@ -49,7 +49,9 @@ static ScanStatus* new_status(Temp& tmp) {
 }
 
 // ---- take ------------------------------------------------------------------------------------------
-Column take_column(const Exec& ex, const Column& c, const uint32_t* idx, int64_t n) {
+// known_bytes >= 0: the caller knows the Utf8 value bytes of the result (a permutation keeps them) — no
+// host round trip for the total
+Column take_column(const Exec& ex, const Column& c, const uint32_t* idx, int64_t n, int64_t known_bytes) {
     const LaunchCfg cfg = ex.cfg();
     Column out;
     out.dtype = c.dtype;
@@ -62,7 +64,7 @@ Column take_column(const Exec& ex, const Column& c, const uint32_t* idx, int64_t
         uint64_t* total = tmp.get<uint64_t>(1);
         void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes(n));
         HIP_CHECK(exclusive_scan_u32_i32(ex.stream, lengths, n, out.offsets->as<int32_t>(), true, total, scan_tmp));
-        const uint64_t bytes = read_device(ex, total);
+        const uint64_t bytes = known_bytes >= 0 ? (uint64_t)known_bytes : read_device(ex, total);
         if (bytes > 0x7FFFFFFFull) fail(BHIP_EEXEC, "Utf8 column exceeds 2 GiB of value bytes");
         out.data_bytes = (int64_t)bytes;
         out.data = make_buffer(ex, (size_t)bytes + 8);
@@ -80,8 +82,9 @@ Column take_column(const Exec& ex, const Column& c, const uint32_t* idx, int64_t
 }
 
 // `may_null`: indices can hold NULL_INDEX (outer joins) -> always build a validity bitmap
-static Column take_column_v(const Exec& ex, const Column& c, const uint32_t* idx, int64_t n, bool may_null) {
-    Column out = take_column(ex, c, idx, n);
+static Column take_column_v(const Exec& ex, const Column& c, const uint32_t* idx, int64_t n, bool may_null,
+                            bool permutation = false) {
+    Column out = take_column(ex, c, idx, n, permutation && c.dtype == DT_UTF8 ? c.data_bytes : -1);
     if (c.validity || may_null) {
         out.validity = make_buffer(ex, bitmap_bytes(n) + 8);
         HIP_CHECK(launch_take_bitmap(ex.cfg(), c.validity ? c.validity->as<uint64_t>() : nullptr, idx, n,
@@ -90,12 +93,12 @@ static Column take_column_v(const Exec& ex, const Column& c, const uint32_t* idx
     return out;
 }
 
-BatchPtr take_batch(const Exec& ex, const Batch& in, const uint32_t* idx, int64_t n_out, SchemaPtr schema) {
+BatchPtr take_batch(const Exec& ex, const Batch& in, const uint32_t* idx, int64_t n_out, SchemaPtr schema, bool permutation) {
     auto out = std::make_shared<Batch>();
     out->schema = schema ? schema : in.schema;
     out->ctx = in.ctx;
     out->n_rows = n_out;
-    for (const auto& c : in.cols) out->cols.push_back(take_column_v(ex, c, idx, n_out, false));
+    for (const auto& c : in.cols) out->cols.push_back(take_column_v(ex, c, idx, n_out, false, permutation));
     return out;
 }
 

@@ -18,6 +18,10 @@ namespace bhip {
 void radix_sort_pairs(const Exec& ex, BufferPtr& keys, BufferPtr& perm, int64_t n) {
     if (n <= 1) return;
     const LaunchCfg cfg = ex.cfg();
+    if (n <= small_sort_max()) {
+        HIP_CHECK(small_sort_pairs(cfg, keys->as<uint64_t>(), perm->as<uint32_t>(), n));
+        return;
+    }
     Temp tmp(ex);
     uint64_t* diff_dev = tmp.get<uint64_t>(1);
     HIP_CHECK(radix_key_diff(cfg, keys->as<uint64_t>(), n, diff_dev));
@@ -78,10 +82,13 @@ StreamPtr SortExec::execute(int partition, const Exec& ex) const {
             const Column col = evaluate_column(ex, *in, sd.expr);
             const ColumnRef cr = col.ref();
             if (col.dtype == DT_UTF8) {
-                Temp tmp(ex);
-                uint32_t* maxlen_dev = tmp.get<uint32_t>(1);
-                HIP_CHECK(launch_utf8_max_len(cfg, col.offsets->as<int32_t>(), n, maxlen_dev));
-                const uint32_t maxlen = read_device(ex, maxlen_dev);
+                uint32_t maxlen = (uint32_t)col.data_bytes;      // an upper bound: passes over all-zero chunks keep the order
+                if (col.data_bytes > 32) {
+                    Temp tmp(ex);
+                    uint32_t* maxlen_dev = tmp.get<uint32_t>(1);
+                    HIP_CHECK(launch_utf8_max_len(cfg, col.offsets->as<int32_t>(), n, maxlen_dev));
+                    maxlen = read_device(ex, maxlen_dev);
+                }
                 // least significant first: the length, then the 8-byte chunks from the last to the first
                 HIP_CHECK(launch_sort_key_utf8(cfg, cr, perm->as<uint32_t>(), n, -1, sd.descending, keys->as<uint64_t>()));
                 radix_sort_pairs(ex, keys, perm, n);
@@ -99,7 +106,7 @@ StreamPtr SortExec::execute(int partition, const Exec& ex) const {
                 radix_sort_pairs(ex, keys, perm, n);
             }
         }
-        BatchPtr out = take_batch(ex, *in, perm->as<uint32_t>(), n);
+        BatchPtr out = take_batch(ex, *in, perm->as<uint32_t>(), n, nullptr, /*permutation=*/true);
         HIP_CHECK(hipStreamSynchronize(ex.stream));
         return {out};
     }));

@@ -105,6 +105,37 @@ hipError_t radix_key_diff(const LaunchCfg& cfg, const uint64_t* keys, int64_t n,
     return hipGetLastError();
 }
 
+// ---- small inputs: one workgroup, stable rank sort in LDS, in place ----------------------------------
+// (a Q1 / Q5 result is 4-5 rows: eight radix passes of three launches each plus a host round trip for
+// the byte-difference mask would cost ~100x the work; rank = #smaller + #equal-and-earlier is stable)
+constexpr int SMALL_SORT_MAX = 1024;
+__global__ void __launch_bounds__(SORT_BLOCK)
+small_sort_pairs_kernel(uint64_t* keys, uint32_t* vals, int n) {
+    __shared__ uint64_t k[SMALL_SORT_MAX];
+    __shared__ uint32_t v[SMALL_SORT_MAX];
+    for (int i = threadIdx.x; i < n; i += SORT_BLOCK) { k[i] = keys[i]; v[i] = vals[i]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += SORT_BLOCK) {
+        const uint64_t ki = k[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const uint64_t kj = k[j];                       // same address for the whole wave: LDS broadcast
+            rank += (kj < ki || (kj == ki && j < i)) ? 1 : 0;
+        }
+        keys[rank] = ki;
+        vals[rank] = v[i];
+    }
+}
+
+int small_sort_max() { return SMALL_SORT_MAX; }
+
+hipError_t small_sort_pairs(const LaunchCfg& cfg, uint64_t* keys, uint32_t* vals, int64_t n) {
+    if (n <= 1) return hipSuccess;
+    if (n > SMALL_SORT_MAX) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(small_sort_pairs_kernel, dim3(1), dim3(SORT_BLOCK), 0, cfg.stream, keys, vals, (int)n);
+    return hipGetLastError();
+}
+
 // one stable pass on byte `byte` of the keys: (keys, vals) -> (keys_out, vals_out)
 hipError_t radix_pass(const LaunchCfg& cfg, const uint64_t* keys, const uint32_t* vals, int64_t n, int byte,
                       uint64_t* keys_out, uint32_t* vals_out, void* temp) {

@@ -404,8 +404,12 @@ emit_group_utf8_kernel(const GroupRec* table, int64_t n_groups, EmitKeySpec spec
     }
 }
 
+// all value columns of an aggregate's output in ONE launch: blockIdx.y selects the column
 __global__ void __launch_bounds__(BLOCK)
-emit_group_value_kernel(const GroupRec* table, int64_t n_groups, EmitValueSpec spec, void* data, uint64_t* validity) {
+emit_group_values_kernel(const GroupRec* table, int64_t n_groups, EmitValueBatch batch) {
+    const EmitValueSpec spec = batch.spec[blockIdx.y];
+    void* data = batch.data[blockIdx.y];
+    uint64_t* validity = batch.validity[blockIdx.y];
     const int64_t n_round = (n_groups + 63) & ~(int64_t)63;
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n_round; i += (int64_t)gridDim.x * BLOCK) {
         bool valid = false;
@@ -459,8 +463,14 @@ hipError_t launch_emit_group_utf8(const LaunchCfg& cfg, const GroupRec* table, i
 hipError_t launch_emit_group_value(const LaunchCfg& cfg, const GroupRec* table, int64_t n_groups,
                                    const EmitValueSpec& spec, void* data, uint64_t* validity) {
     if (n_groups == 0) return hipSuccess;
-    hipLaunchKernelGGL(emit_group_value_kernel, dim3(grid_for(cfg, n_groups)), dim3(BLOCK), 0, cfg.stream, table,
-                       n_groups, spec, data, validity);
+    EmitValueBatch b;
+    b.n = 1; b.spec[0] = spec; b.data[0] = data; b.validity[0] = validity;
+    return launch_emit_group_values(cfg, table, n_groups, b);
+}
+hipError_t launch_emit_group_values(const LaunchCfg& cfg, const GroupRec* table, int64_t n_groups, const EmitValueBatch& batch) {
+    if (n_groups == 0 || batch.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(emit_group_values_kernel, dim3(grid_for(cfg, n_groups), batch.n), dim3(BLOCK), 0, cfg.stream, table,
+                       n_groups, batch);
     return hipGetLastError();
 }
 

@@ -8,6 +8,9 @@ namespace bhip {
 
 size_t radix_sort_temp_bytes(int64_t n);
 // bits that differ between any two keys (device u64)
+// n <= small_sort_max(): stable sort of (key, value) pairs in place, one launch, no host round trip
+int small_sort_max();
+hipError_t small_sort_pairs(const LaunchCfg& cfg, uint64_t* keys, uint32_t* vals, int64_t n);
 hipError_t radix_key_diff(const LaunchCfg& cfg, const uint64_t* keys, int64_t n, uint64_t* diff_out);
 // one stable 8-bit pass on byte `byte` (0 = least significant)
 hipError_t radix_pass(const LaunchCfg& cfg, const uint64_t* keys, const uint32_t* vals, int64_t n, int byte,

@@ -55,6 +55,14 @@ struct EmitValueSpec {
     int32_t count_is_rows;   // program has no NULLs: count(a) == rows
     int32_t dtype;
 };
+constexpr int EMIT_BATCH_MAX = 16;
+struct EmitValueBatch {
+    int32_t n;
+    EmitValueSpec spec[EMIT_BATCH_MAX];
+    void* data[EMIT_BATCH_MAX];
+    uint64_t* validity[EMIT_BATCH_MAX];
+};
+hipError_t launch_emit_group_values(const LaunchCfg& cfg, const GroupRec* table, int64_t n_groups, const EmitValueBatch& batch);
 hipError_t launch_emit_group_key(const LaunchCfg& cfg, const GroupRec* table, int64_t n_groups, const EmitKeySpec& spec,
                                  void* data, uint64_t* validity, uint32_t* utf8_lengths);
 hipError_t launch_emit_group_utf8(const LaunchCfg& cfg, const GroupRec* table, int64_t n_groups, const EmitKeySpec& spec,
