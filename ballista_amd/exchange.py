@@ -41,6 +41,55 @@ def unpack_batch(slot):
     return batches[0]
 
 
+def _ipc_bytes(batch):
+    import pyarrow as pa
+    sink = pa.BufferOutputStream()
+    with pa.ipc.new_stream(sink, batch.schema) as w:
+        w.write_batch(batch)
+    return np.frombuffer(sink.getvalue(), dtype=np.uint8)
+
+
+def all_to_all_batches(dist, outgoing, device="cpu"):
+    """The exchange step of a repartitioned join (RepartitionExec(Hash(keys), N),
+    rust/core/src/serde/physical_plan/from_proto.rs:133-147, read back by ShuffleReaderExec): rank r holds
+    `outgoing[d]` = the rows of its shard whose key hashes to rank d (ballista_amd.plan.hash_partition) and
+    receives, in source-rank order, the batches every rank holds for r.
+
+    Two phases: byte counts by all_gather, then one point-to-point send/recv per peer pair (xGMI is
+    point-to-point: 7 peers = 7 links busy at once).  Payload = Arrow IPC bytes of each batch, staged through
+    host memory in this round; exchanging the column buffers device-to-device is the next step."""
+    import pyarrow as pa
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if len(outgoing) != world:
+        raise ValueError(f"need one outgoing batch per rank ({world}), got {len(outgoing)}")
+    payload = [_ipc_bytes(b) for b in outgoing]
+    sizes = torch.tensor([p.size for p in payload], dtype=torch.int64, device=device)
+    all_sizes = [torch.empty_like(sizes) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes)
+    incoming = [int(all_sizes[src][rank].item()) for src in range(world)]
+    send = [torch.from_numpy(payload[d].copy()).to(device) for d in range(world)]
+    recv = [torch.empty(incoming[s], dtype=torch.uint8, device=device) for s in range(world)]
+    ops = []
+    for peer in range(world):
+        if peer == rank:
+            continue
+        ops.append(dist.P2POp(dist.isend, send[peer], peer))
+        ops.append(dist.P2POp(dist.irecv, recv[peer], peer))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    recv[rank] = send[rank]
+    out = []
+    for s in range(world):
+        raw = recv[s].cpu().numpy().tobytes()
+        batches = pa.ipc.open_stream(pa.py_buffer(raw)).read_all().to_batches()
+        if len(batches) > 1:
+            batches = [pa.Table.from_batches(batches).combine_chunks().to_batches()[0]]
+        out.append(batches[0] if batches else pa.RecordBatch.from_pylist([], schema=outgoing[0].schema))
+    return out
+
+
 def all_gather_batches(dist, batch, device="cpu", slot_bytes=SLOT_BYTES):
     """Every rank contributes one small pyarrow.RecordBatch and receives the batches of all ranks, in
     rank order (the order MergeExec concatenates partitions in, rust/scheduler/src/planner.rs:136-148).

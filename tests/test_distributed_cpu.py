@@ -43,7 +43,11 @@ def _from_arrow(rb):
     from oracle.engine import OCol
     inv = {"int32": "Int32", "int64": "Int64", "uint64": "UInt64", "double": "Float64", "string": "Utf8", "bool": "Boolean"}
     out = OrderedDict()
+    import pyarrow as pa
     for name, col in zip(rb.schema.names, rb.columns):
+        if pa.types.is_date32(col.type):
+            out[name] = OCol("Date32", np.asarray(col.cast(pa.int32()).to_pylist(), dtype=np.int32))
+            continue
         vals = col.to_pylist()
         dt = inv[str(col.type)]
         valid = None if col.null_count == 0 else np.array([v is not None for v in vals])
@@ -105,6 +109,66 @@ def test_two_rank_partial_state_exchange_gloo(query):
     q = mpc.Queue()
     port = _free_port()
     procs = [mpc.Process(target=_rank_main, args=(r, 2, port, query, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for rank, msg in sorted(results):
+        assert msg == "ok", f"rank {rank}:\n{msg}"
+
+
+def _join_rank_main(rank, world, port, q):
+    """repartitioned join: both sides sharded by row block, exchanged by hash(join key) % world, joined locally"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from ballista_amd import expr as E
+    from ballista_amd.exchange import all_to_all_batches
+    from oracle import engine as og, gen
+    import helpers
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        od, li = gen.orders(SF), helpers.slice_batch(gen.lineitem(SF), 0, 9000)
+
+        def shard(b):
+            n = og.batch_len(b)
+            per = (n + world - 1) // world
+            return helpers.slice_batch(b, rank * per, min(n, (rank + 1) * per))
+
+        def exchange(b, key):
+            parts = og.repartition_hash(b, [E.col(key)], world)          # the row-hash spec of DESIGN.md §6
+            got = all_to_all_batches(dist, [_to_arrow(p) for p in parts], device="cpu")
+            assert len(got) == world
+            return og.concat_batches([_from_arrow(g) for g in got if g.num_rows] or [_from_arrow(got[0])])
+
+        mine_o, mine_l = exchange(shard(od), "o_orderkey"), exchange(shard(li), "l_orderkey")
+        # co-location: every key I hold hashes to me
+        for b, key in ((mine_o, "o_orderkey"), (mine_l, "l_orderkey")):
+            h = og.row_hash([b[key]], og.batch_len(b))
+            assert all(int(x) % world == rank for x in h)
+        local = og.hash_join(mine_o, mine_l, [("o_orderkey", "l_orderkey")], "Inner")
+        whole = og.hash_join(od, li, [("o_orderkey", "l_orderkey")], "Inner")
+        hw = og.row_hash([whole["o_orderkey"]], og.batch_len(whole))
+        keep = [i for i, x in enumerate(hw) if int(x) % world == rank]
+        want = helpers.slice_batch(whole, 0, 0) if not keep else type(whole)((k, c.take(np.array(keep))) for k, c in whole.items())
+        helpers.assert_rows_equal(local, want, ordered=False)
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except BaseException as e:          # noqa: BLE001 - reported to the parent
+        import traceback
+        q.put((rank, "".join(traceback.format_exception(type(e), e, e.__traceback__))))
+
+
+def test_two_rank_repartitioned_join_gloo():
+    pytest.importorskip("pyarrow")
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_join_rank_main, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
     results = [q.get(timeout=240) for _ in procs]
