@@ -6,6 +6,7 @@
 
 #include "../util_kernels.h"
 #include "plan.hpp"
+#include "sop.hpp"
 
 namespace bhip {
 
@@ -215,7 +216,17 @@ int64_t filter_indices(const Exec& ex, const Batch& in, const ExprPtr& predicate
     uint32_t* tile_counts = tmp.get<uint32_t>((size_t)n_tiles + 1);
     ScanStatus* st = new_status(tmp);
     if (n == 0) { indices_out = make_buffer(ex, 8); return 0; }
-    HIP_CHECK(launch_scan_pred_bitmap(ex.cfg(), P, bitmap, tile_counts, st));
+    // AND of column-vs-literal comparisons over NULL-free numeric columns: the wide-load range kernel
+    // (kernels_range.hip) writes the same bitmap + tile counts as the expression VM
+    static const bool range_disabled = [] { const char* v = getenv("BHIP_NO_RANGE_FILTER"); return v && atoi(v) != 0; }();
+    SopPlan rp;
+    if (!range_disabled && build_sop(*in.schema, predicate, {}, {}, rp) && rp.prog.n_ranges >= 1 && sop_columns_bindable(rp, in) &&
+        lean_bindable(rp, in)) {
+        bind_sop(rp, in);
+        HIP_CHECK(launch_range_bitmap(ex.cfg(), rp.prog, tmp.get<SopProgram>(1), bitmap, tile_counts));
+    } else {
+        HIP_CHECK(launch_scan_pred_bitmap(ex.cfg(), P, bitmap, tile_counts, st));
+    }
     uint64_t* tile_off = tmp.get<uint64_t>((size_t)n_tiles + 1);
     uint64_t* total = tmp.get<uint64_t>(1);
     void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes(n_tiles));

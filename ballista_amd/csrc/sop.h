@@ -69,4 +69,8 @@ hipError_t launch_scan_agg_sop(const LaunchCfg& cfg, const SopProgram& S, SopPro
 hipError_t launch_scan_agg_lean(const LaunchCfg& cfg, const SopProgram& S, SopProgram* dprog, int gmax, GroupRec* partials,
                                 uint32_t* partial_ng, int max_grid, ScanStatus* status, int* grid_out);
 
+// FilterExec's predicate pass for AND-of-ranges predicates (kernels_range.hip): selection bitmap + kept rows per
+// 1024-row tile, the interface of launch_scan_pred_bitmap
+hipError_t launch_range_bitmap(const LaunchCfg& cfg, const SopProgram& S, SopProgram* dprog, uint64_t* bitmap, uint32_t* tile_counts);
+
 }  // namespace bhip
