@@ -34,6 +34,7 @@ struct JoinTable {
     uint32_t* next;           // [n_left]   id+1 of the next build row with the same key
     uint64_t mask;
     const uint64_t* keys128;  // packed keys of the build rows
+    uint32_t* dup_flag;       // set by the build when two build rows share a key (may be null)
 };
 hipError_t launch_join_build(const LaunchCfg& cfg, const JoinTable& T, const uint64_t* sel, uint32_t n_left);
 hipError_t launch_join_probe_count(const LaunchCfg& cfg, const JoinTable& T, const uint64_t* rkeys128, const uint64_t* rsel,
@@ -41,6 +42,12 @@ hipError_t launch_join_probe_count(const LaunchCfg& cfg, const JoinTable& T, con
 hipError_t launch_join_probe_emit(const LaunchCfg& cfg, const JoinTable& T, const uint64_t* rkeys128, const uint64_t* rsel,
                                   uint32_t n_right, bool right_outer, const uint64_t* offsets, uint32_t* left_idx,
                                   uint32_t* right_idx, uint32_t* matched);
+// unique build keys: one table probe per row (partner kept in match[]: build row id + 1, 0 = none), then a
+// streaming emit
+hipError_t launch_join_probe_match(const LaunchCfg& cfg, const JoinTable& T, const uint64_t* rkeys128, const uint64_t* rsel,
+                                   uint32_t n_right, bool right_outer, uint32_t* counts, uint32_t* match);
+hipError_t launch_join_emit_match(const LaunchCfg& cfg, const uint32_t* match, uint32_t n_right, bool right_outer,
+                                  const uint64_t* offsets, uint32_t* left_idx, uint32_t* right_idx, uint32_t* matched);
 hipError_t launch_join_unmatched_flags(const LaunchCfg& cfg, const uint32_t* matched, uint32_t n_left, uint32_t* flags);
 hipError_t launch_compact_flags(const LaunchCfg& cfg, const uint32_t* flags, const uint64_t* offsets, uint32_t n, uint32_t* out);
 

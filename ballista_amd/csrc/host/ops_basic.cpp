@@ -388,9 +388,45 @@ Column evaluate_column(const Exec& ex, const Batch& in, const ExprPtr& e) {
 
 StreamPtr ProjectionExec::execute(int partition, const Exec& ex) const {
     check_partition(*this, partition);
-    auto child = std::shared_ptr<RecordBatchStream>(input_->execute(partition, ex).release());
     auto exprs = exprs_;
     SchemaPtr sch = schema_;
+    // Projection over (CoalesceBatches over) Filter: the reference's filter copies EVERY column of the surviving
+    // rows and the projection then drops most of them; here only the columns the projection
+    // reads are gathered.  Same rows, same order, same values.
+    const ExecutionPlan* below = input_.get();
+    while (auto co = dynamic_cast<const CoalesceBatchesExec*>(below)) below = co->children()[0].get();
+    if (auto flt = dynamic_cast<const FilterExec*>(below)) {
+        PlanPtr src = flt->children()[0];
+        const ExprPtr pred = flt->predicate();
+        const SchemaPtr in_schema = src->schema();
+        std::vector<std::string> used;
+        for (auto& en : exprs) collect_columns(en.first, used);
+        auto narrow = std::make_shared<Schema>();
+        std::vector<int> keep;
+        for (size_t i = 0; i < in_schema->fields.size(); ++i)
+            for (auto& u : used)
+                if (u == in_schema->fields[i].name) { narrow->fields.push_back(in_schema->fields[i]); keep.push_back((int)i); break; }
+        if (keep.size() < in_schema->fields.size()) {
+            auto child = std::shared_ptr<RecordBatchStream>(src->execute(partition, ex).release());
+            SchemaPtr nsch = narrow;
+            return StreamPtr(new LazyStream(sch, [child, exprs, ex, sch, pred, nsch, keep]() {
+                std::vector<BatchPtr> out;
+                while (BatchPtr b = child->next()) {
+                    BufferPtr idx;
+                    const int64_t n = filter_indices(ex, *b, pred, idx);
+                    auto nb = std::make_shared<Batch>();
+                    nb->schema = nsch;
+                    nb->ctx = b->ctx;
+                    nb->n_rows = b->n_rows;
+                    for (int ci : keep) nb->cols.push_back(b->cols[ci]);
+                    BatchPtr sel = n == b->n_rows ? BatchPtr(nb) : take_batch(ex, *nb, idx->as<uint32_t>(), n);
+                    out.push_back(project_batch(ex, *sel, exprs, sch));
+                }
+                return out;
+            }));
+        }
+    }
+    auto child = std::shared_ptr<RecordBatchStream>(input_->execute(partition, ex).release());
     return StreamPtr(new LazyStream(sch, [child, exprs, ex, sch]() {
         std::vector<BatchPtr> out;
         while (BatchPtr b = child->next()) out.push_back(project_batch(ex, *b, exprs, sch));

@@ -16,9 +16,10 @@ namespace bhip {
 
 struct JoinBuildSide {
     BatchPtr batch;                 // all left rows
-    BufferPtr keys, sel, owner, head, next;
+    BufferPtr keys, sel, owner, head, next, dup;
     JoinTable table;
     bool has_sel = false;
+    bool unique = false;            // no two build rows share a key: probe rows have at most one partner
 };
 
 static const char* join_name(int t) { return t == BHIP_JOIN_INNER ? "Inner" : (t == BHIP_JOIN_LEFT ? "Left" : "Right"); }
@@ -145,9 +146,13 @@ std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) co
     bs->table.next = bs->next->as<uint32_t>();
     bs->table.mask = cap - 1;
     bs->table.keys128 = bs->keys->as<uint64_t>();
+    bs->dup = make_buffer(ex, 8);
+    HIP_CHECK(hipMemsetAsync(bs->dup->ptr(), 0, 8, ex.stream));
+    bs->table.dup_flag = bs->dup->as<uint32_t>();
     HIP_CHECK(launch_join_build(ex.cfg(), bs->table, bs->has_sel ? bs->sel->as<uint64_t>() : nullptr, (uint32_t)n));
     // other tasks (other HIP streams) will read the table: it must be complete before it is published
-    HIP_CHECK(hipStreamSynchronize(ex.stream));
+    bs->unique = read_device(ex, bs->dup->as<uint32_t>()) == 0;
+    bs->table.dup_flag = nullptr;
     cache_->built = bs;
     return bs;
 }
@@ -199,15 +204,23 @@ StreamPtr HashJoinExec::execute(int partition, const Exec& ex) const {
             uint64_t* total = tmp.get<uint64_t>(1);
             void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes(n_right));
             const uint64_t* rselp = has_rsel ? rsel->as<uint64_t>() : nullptr;
-            HIP_CHECK(launch_join_probe_count(cfg, bs->table, rkeys->as<uint64_t>(), rselp, (uint32_t)n_right, right_outer, counts));
+            uint32_t* match = bs->unique ? tmp.get<uint32_t>((size_t)n_right + 1) : nullptr;
+            if (bs->unique)
+                HIP_CHECK(launch_join_probe_match(cfg, bs->table, rkeys->as<uint64_t>(), rselp, (uint32_t)n_right, right_outer, counts, match));
+            else
+                HIP_CHECK(launch_join_probe_count(cfg, bs->table, rkeys->as<uint64_t>(), rselp, (uint32_t)n_right, right_outer, counts));
             HIP_CHECK(exclusive_scan_u32_u64(ex.stream, counts, n_right, offsets, false, total, scan_tmp));
             const uint64_t n_out = read_device(ex, total);
             if (n_out > 0xFFFFFFF0ull) fail(BHIP_EEXEC, "join output of one probe batch exceeds 2^32 rows");
             if (n_out == 0) continue;
             uint32_t* lidx = tmp.get<uint32_t>((size_t)n_out);
             uint32_t* ridx = tmp.get<uint32_t>((size_t)n_out);
-            HIP_CHECK(launch_join_probe_emit(cfg, bs->table, rkeys->as<uint64_t>(), rselp, (uint32_t)n_right, right_outer, offsets,
-                                             lidx, ridx, left_outer ? matched->as<uint32_t>() : nullptr));
+            if (bs->unique)
+                HIP_CHECK(launch_join_emit_match(cfg, match, (uint32_t)n_right, right_outer, offsets, lidx, ridx,
+                                                 left_outer ? matched->as<uint32_t>() : nullptr));
+            else
+                HIP_CHECK(launch_join_probe_emit(cfg, bs->table, rkeys->as<uint64_t>(), rselp, (uint32_t)n_right, right_outer, offsets,
+                                                 lidx, ridx, left_outer ? matched->as<uint32_t>() : nullptr));
             emit(rb.get(), lidx, ridx, (int64_t)n_out);
             HIP_CHECK(hipStreamSynchronize(ex.stream));   // index scratch is released at the end of the iteration
         }

@@ -130,7 +130,9 @@ join_build_kernel(JoinTable T, const uint64_t* sel, uint32_t n_left) {
         if (!bit_at(sel, row)) continue;                       // NULL keys never match
         const Key128 key{T.keys128[2ull * row], T.keys128[2ull * row + 1]};
         const uint32_t slot = table_upsert(T.owner, T.mask, T.keys128, key, row);
-        T.next[row] = atomicExch(&T.head[slot], row + 1u);     // push on the slot's chain
+        const uint32_t prev = atomicExch(&T.head[slot], row + 1u);     // push on the slot's chain
+        T.next[row] = prev;
+        if (prev != 0 && T.dup_flag) *T.dup_flag = 1u;                 // a second row with this key: not a unique build side
     }
 }
 
@@ -183,6 +185,37 @@ join_probe_emit_kernel(JoinTable T, const uint64_t* rkeys128, const uint64_t* rs
     }
 }
 
+// ---- unique build keys (primary-key side: every TPC-H join): a probe row has at most one partner, so the
+// table is probed ONCE — the partner is kept per probe row and the emit pass is a streaming compaction
+__global__ void __launch_bounds__(BLOCK)
+join_probe_match_kernel(JoinTable T, const uint64_t* rkeys128, const uint64_t* rsel, uint32_t n_right, int right_outer,
+                        uint32_t* counts, uint32_t* match) {
+    for (uint32_t row = blockIdx.x * BLOCK + threadIdx.x; row < n_right; row += gridDim.x * BLOCK) {
+        uint32_t m = 0;
+        if (bit_at(rsel, row)) {
+            const Key128 key{rkeys128[2ull * row], rkeys128[2ull * row + 1]};
+            const uint32_t slot = table_find(T, key);
+            if (slot != 0xFFFFFFFFu) m = T.head[slot];
+        }
+        match[row] = m;
+        counts[row] = (right_outer || m != 0) ? 1u : 0u;
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK)
+join_emit_match_kernel(const uint32_t* match, uint32_t n_right, int right_outer, const uint64_t* offsets, uint32_t* left_idx,
+                       uint32_t* right_idx, uint32_t* matched) {
+    for (uint32_t row = blockIdx.x * BLOCK + threadIdx.x; row < n_right; row += gridDim.x * BLOCK) {
+        const uint32_t m = match[row];
+        if (m != 0 || right_outer) {
+            const uint64_t pos = offsets[row];
+            left_idx[pos] = m != 0 ? m - 1u : 0xFFFFFFFFu;
+            right_idx[pos] = row;
+            if (matched && m != 0) atomicOr(&matched[(m - 1u) >> 5], 1u << ((m - 1u) & 31));
+        }
+    }
+}
+
 __global__ void __launch_bounds__(BLOCK)
 join_unmatched_flags_kernel(const uint32_t* matched, uint32_t n_left, uint32_t* flags) {
     for (uint32_t row = blockIdx.x * BLOCK + threadIdx.x; row < n_left; row += gridDim.x * BLOCK)
@@ -221,6 +254,20 @@ hipError_t launch_join_probe_emit(const LaunchCfg& cfg, const JoinTable& T, cons
     if (n_right == 0) return hipSuccess;
     hipLaunchKernelGGL(join_probe_emit_kernel, dim3(grid_rows(cfg, n_right)), dim3(BLOCK), 0, cfg.stream, T, rkeys128, rsel,
                        n_right, right_outer ? 1 : 0, offsets, left_idx, right_idx, matched);
+    return hipGetLastError();
+}
+hipError_t launch_join_probe_match(const LaunchCfg& cfg, const JoinTable& T, const uint64_t* rkeys128, const uint64_t* rsel,
+                                   uint32_t n_right, bool right_outer, uint32_t* counts, uint32_t* match) {
+    if (n_right == 0) return hipSuccess;
+    hipLaunchKernelGGL(join_probe_match_kernel, dim3(grid_rows(cfg, n_right)), dim3(BLOCK), 0, cfg.stream, T, rkeys128, rsel,
+                       n_right, right_outer ? 1 : 0, counts, match);
+    return hipGetLastError();
+}
+hipError_t launch_join_emit_match(const LaunchCfg& cfg, const uint32_t* match, uint32_t n_right, bool right_outer,
+                                  const uint64_t* offsets, uint32_t* left_idx, uint32_t* right_idx, uint32_t* matched) {
+    if (n_right == 0) return hipSuccess;
+    hipLaunchKernelGGL(join_emit_match_kernel, dim3(grid_rows(cfg, n_right)), dim3(BLOCK), 0, cfg.stream, match, n_right,
+                       right_outer ? 1 : 0, offsets, left_idx, right_idx, matched);
     return hipGetLastError();
 }
 hipError_t launch_join_unmatched_flags(const LaunchCfg& cfg, const uint32_t* matched, uint32_t n_left, uint32_t* flags) {
