@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--query", default="q1", choices=["q1", "q6"])
     ap.add_argument("--cpu-rows", type=int, default=96_000_000, help="rows of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse the N-rank flow on a box with fewer GPUs)")
     return ap.parse_args()
 
 
@@ -99,8 +101,12 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
+        n_dev = torch.cuda.device_count()
+        if args.backend == "gloo":
+            local_rank = local_rank % max(n_dev, 1)        # rehearsal: ranks may share a GPU
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl")
+        dist.init_process_group(args.backend)
+    coll_device = "cpu" if args.backend == "gloo" else f"cuda:{local_rank}"
 
     import ballista_amd as ba
     from ballista_amd import tpch
@@ -128,8 +134,11 @@ def main():
         def step():
             part = stage1.collect()[0].to_pyarrow()
             # ONE 16-KiB all_gather (RCCL) of the partial-state batches; tests/test_distributed_cpu.py
-            parts = all_gather_batches(dist, part, device=f"cuda:{local_rank}")
-            merged = ba.MemoryExec([[ba.RecordBatch.from_pyarrow(ctx, p)] for p in parts], ctx)
+            parts = all_gather_batches(dist, part, device=coll_device)
+            # one import for all ranks' state rows (MergeExec semantics: the partitions' rows, concatenated)
+            import pyarrow as pa
+            state = pa.Table.from_batches(parts).combine_chunks().to_batches()[0]
+            merged = ba.MemoryExec([[ba.RecordBatch.from_pyarrow(ctx, state)]], ctx)
             if args.query == "q1":
                 final = tpch.q1_final(merged)
             else:
@@ -156,7 +165,7 @@ def main():
     k_ms, k_launches = ctx.kernel_time(reset=True)
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
