@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "../util_kernels.h"
 #include "plan.hpp"
 
 using namespace bhip;
@@ -113,6 +114,30 @@ void export_schema(const Schema& schema, ArrowSchema* out) {
     out->private_data = top;
 }
 
+// small batches (stage outputs of aggregates: a few rows x a dozen columns): every buffer is packed into one
+// device block by ONE kernel and comes back in ONE copy, instead of one blocking copy per buffer
+static bool plan_small_export(const Batch& b, PackDesc& d, size_t& total) {
+    const int64_t n = b.n_rows;
+    d.n = 0;
+    total = 0;
+    auto add = [&](const void* dev, size_t bytes) -> bool {
+        if (d.n >= PACK_MAX || bytes > (1u << 20)) return false;
+        d.src[d.n] = dev; d.bytes[d.n] = (uint32_t)bytes; d.dst[d.n] = (uint32_t)total;
+        ++d.n;
+        total += (bytes + 63) & ~(size_t)63;
+        return true;
+    };
+    for (const Column& c : b.cols) {
+        if (c.validity && !add(c.validity->ptr(), (size_t)((n + 7) / 8))) return false;
+        if (c.dtype == DT_UTF8) {
+            if (!add(c.offsets->ptr(), (size_t)(n + 1) * 4) || !add(c.data->ptr(), (size_t)c.data_bytes)) return false;
+        } else if (c.dtype == DT_BOOLEAN) {
+            if (!add(c.data->ptr(), (size_t)((n + 7) / 8))) return false;
+        } else if (!add(c.data->ptr(), (size_t)n * dtype_width(c.dtype))) return false;
+    }
+    return total <= (4u << 20) && d.n > 0;
+}
+
 void export_batch(const Batch& b, ArrowArray* out) {
     b.ctx->set_device();
     HIP_CHECK(hipDeviceSynchronize());
@@ -120,6 +145,20 @@ void export_batch(const Batch& b, ArrowArray* out) {
     std::unique_ptr<ExportedArray> guard(top);
     top->child_storage.resize(b.cols.size());
     for (auto& c : top->child_storage) memset(&c, 0, sizeof(c));
+    PackDesc pd;
+    size_t packed_total = 0;
+    uint8_t* packed = nullptr;
+    int packed_next = 0;
+    if (plan_small_export(b, pd, packed_total)) {
+        packed = static_cast<uint8_t*>(malloc(packed_total + 64));
+        if (!packed) fail(BHIP_EOOM, "host allocation failed");
+        top->owned.push_back(packed);
+        void* dev_block = b.ctx->alloc(packed_total + 64, nullptr);
+        hipError_t e = launch_pack_buffers(LaunchCfg{b.ctx->cus(), nullptr}, pd, static_cast<uint8_t*>(dev_block));
+        if (e == hipSuccess) e = hipMemcpy(packed, dev_block, packed_total, hipMemcpyDeviceToHost);
+        b.ctx->free(dev_block, nullptr);
+        HIP_CHECK(e);
+    }
     for (size_t i = 0; i < b.cols.size(); ++i) {
         const Column& c = b.cols[i];
         auto* cp = new ExportedArray();
@@ -127,6 +166,7 @@ void export_batch(const Batch& b, ArrowArray* out) {
         a.private_data = cp;
         a.release = release_array;
         auto host_copy = [&](const void* dev, size_t bytes) -> void* {
+            if (packed) return packed + pd.dst[packed_next++];       // same order as plan_small_export
             void* h = malloc(bytes ? bytes : 8);
             if (!h) fail(BHIP_EOOM, "host allocation failed");
             cp->owned.push_back(h);

@@ -446,6 +446,20 @@ emit_group_values_kernel(const GroupRec* table, int64_t n_groups, EmitValueBatch
     }
 }
 
+// ---- pack many small device buffers into one block (one launch + one D2H copy on export) ---------------
+__global__ void __launch_bounds__(BLOCK)
+pack_buffers_kernel(PackDesc d, uint8_t* out) {
+    const int b = blockIdx.x;
+    const uint8_t* src = reinterpret_cast<const uint8_t*>(d.src[b]);
+    uint8_t* dst = out + d.dst[b];
+    for (uint32_t i = threadIdx.x; i < d.bytes[b]; i += BLOCK) dst[i] = src[i];
+}
+hipError_t launch_pack_buffers(const LaunchCfg& cfg, const PackDesc& d, uint8_t* out) {
+    if (d.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_buffers_kernel, dim3(d.n), dim3(BLOCK), 0, cfg.stream, d, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_emit_group_key(const LaunchCfg& cfg, const GroupRec* table, int64_t n_groups, const EmitKeySpec& spec,
                                  void* data, uint64_t* validity, uint32_t* utf8_lengths) {
     if (n_groups == 0) return hipSuccess;

@@ -55,6 +55,16 @@ struct EmitValueSpec {
     int32_t count_is_rows;   // program has no NULLs: count(a) == rows
     int32_t dtype;
 };
+// up to PACK_MAX small device buffers -> one contiguous block (offsets chosen by the host)
+constexpr int PACK_MAX = 64;
+struct PackDesc {
+    int32_t n;
+    const void* src[PACK_MAX];
+    uint32_t bytes[PACK_MAX];
+    uint32_t dst[PACK_MAX];
+};
+hipError_t launch_pack_buffers(const LaunchCfg& cfg, const PackDesc& d, uint8_t* out);
+
 constexpr int EMIT_BATCH_MAX = 16;
 struct EmitValueBatch {
     int32_t n;
