@@ -185,6 +185,8 @@ Buffer::Buffer(ContextPtr ctx, size_t bytes, hipStream_t stream)
 }
 Buffer::Buffer(ContextPtr ctx, void* borrowed, size_t bytes)
     : ctx_(std::move(ctx)), ptr_(borrowed), bytes_(bytes), owned_(false), stream_(nullptr) {}
+Buffer::Buffer(ContextPtr ctx, std::shared_ptr<Buffer> parent, void* ptr, size_t bytes)
+    : ctx_(std::move(ctx)), ptr_(ptr), bytes_(bytes), owned_(false), stream_(nullptr), parent_(std::move(parent)) {}
 Buffer::~Buffer() {
     if (owned_ && ptr_) ctx_->free(ptr_, stream_);
 }
@@ -216,6 +218,41 @@ BatchPtr batch_from_host(const ContextPtr& ctx, int n_cols, const bhip_column_de
     batch->n_rows = n_rows;
     hipStream_t st = nullptr;   // null stream: synchronous wrt the caller
     Exec ex{ctx, st};
+    // small host batches (stage inputs of a Final aggregate, dimension tables): all buffers travel in ONE block
+    // and ONE copy; the columns are slices of it (256-byte aligned, zero padded to whole words + slack)
+    std::vector<uint8_t> staging;
+    std::vector<size_t> slice_off;
+    BufferPtr block;
+    if (!device_ptrs) {
+        size_t total = 0;
+        bool small = true;
+        auto plan = [&](const void* p, size_t bytes) {
+            if (!p) return;
+            slice_off.push_back(total);
+            total += (bytes + 8 + BUFFER_SLACK + 255) & ~(size_t)255;
+            if (bytes > (1u << 20)) small = false;
+        };
+        for (int i = 0; i < n_cols && small; ++i) {
+            const bhip_column_desc& d = cols[i];
+            if (d.dtype < DT_INT32 || d.dtype > DT_UTF8) { small = false; break; }
+            const size_t db = d.dtype == DT_UTF8 ? (size_t)d.data_bytes : d.dtype == DT_BOOLEAN ? bitmap_bytes(n_rows) : (size_t)n_rows * dtype_width(d.dtype);
+            plan(d.data ? d.data : (const void*)"", db);
+            if (d.offsets) plan(d.offsets, (size_t)(n_rows + 1) * 4);
+            if (d.validity) plan(d.validity, bitmap_bytes(n_rows));
+        }
+        if (small && total > 0 && total <= (4u << 20)) {
+            staging.assign(total, 0);
+            block = make_buffer(ex, total);
+        } else {
+            slice_off.clear();
+        }
+    }
+    size_t next_slice = 0;
+    auto slice = [&](const void* host, size_t copy_bytes, size_t logical_bytes) -> BufferPtr {
+        const size_t off = slice_off[next_slice++];
+        if (copy_bytes && host) memcpy(staging.data() + off, host, copy_bytes);
+        return std::make_shared<Buffer>(ctx, block, static_cast<uint8_t*>(block->ptr()) + off, logical_bytes);
+    };
     for (int i = 0; i < n_cols; ++i) {
         const bhip_column_desc& d = cols[i];
         if (!d.name) fail(BHIP_EINVAL, "column without a name");
@@ -239,6 +276,11 @@ BatchPtr batch_from_host(const ContextPtr& ctx, int n_cols, const bhip_column_de
             c.data = std::make_shared<Buffer>(ctx, const_cast<void*>(d.data), data_bytes);
             if (d.offsets) c.offsets = std::make_shared<Buffer>(ctx, const_cast<int32_t*>(d.offsets), (size_t)(n_rows + 1) * 4);
             if (d.validity) c.validity = std::make_shared<Buffer>(ctx, const_cast<uint8_t*>(d.validity), bitmap_bytes(n_rows));
+        } else if (block) {
+            const size_t padded = d.dtype == DT_BOOLEAN ? bitmap_bytes(n_rows) : data_bytes;
+            c.data = slice(d.data, data_bytes, padded + 8);
+            if (d.offsets) c.offsets = slice(d.offsets, (size_t)(n_rows + 1) * 4, (size_t)(n_rows + 1) * 4);
+            if (d.validity) c.validity = slice(d.validity, (size_t)((n_rows + 7) / 8), bitmap_bytes(n_rows) + 8);
         } else {
             // device copies are padded to whole 64-bit words (bitmaps are read as u64)
             const size_t padded = d.dtype == DT_BOOLEAN ? bitmap_bytes(n_rows) : data_bytes;
@@ -257,6 +299,7 @@ BatchPtr batch_from_host(const ContextPtr& ctx, int n_cols, const bhip_column_de
         }
         batch->cols.push_back(std::move(c));
     }
+    if (block) HIP_CHECK(hipMemcpy(block->ptr(), staging.data(), staging.size(), hipMemcpyHostToDevice));
     batch->schema = schema;
     return batch;
 }

@@ -104,13 +104,15 @@ class Buffer {
 public:
     Buffer(ContextPtr ctx, size_t bytes, hipStream_t stream);          // owned
     Buffer(ContextPtr ctx, void* borrowed, size_t bytes);              // borrowed device pointer
+    // slice of `parent` (kept alive); the slicer leaves BUFFER_SLACK readable bytes behind every slice
+    Buffer(ContextPtr ctx, std::shared_ptr<Buffer> parent, void* ptr, size_t bytes);
     ~Buffer();
     Buffer(const Buffer&) = delete;
     Buffer& operator=(const Buffer&) = delete;
     void* ptr() const { return ptr_; }
     size_t bytes() const { return bytes_; }
     // owned buffers carry BUFFER_SLACK readable bytes past bytes(): kernels may over-read short strings
-    bool owned() const { return owned_; }
+    bool owned() const { return owned_ || parent_ != nullptr; }
     template <class T> T* as() const { return reinterpret_cast<T*>(ptr_); }
     void set_stream(hipStream_t s) { stream_ = s; }
 private:
@@ -119,6 +121,7 @@ private:
     size_t bytes_;
     bool owned_;
     hipStream_t stream_;
+    std::shared_ptr<Buffer> parent_;
 };
 using BufferPtr = std::shared_ptr<Buffer>;
 BufferPtr make_buffer(const Exec& ex, size_t bytes);
