@@ -42,12 +42,11 @@ hipError_t launch_join_probe_count(const LaunchCfg& cfg, const JoinTable& T, con
 hipError_t launch_join_probe_emit(const LaunchCfg& cfg, const JoinTable& T, const uint64_t* rkeys128, const uint64_t* rsel,
                                   uint32_t n_right, bool right_outer, const uint64_t* offsets, uint32_t* left_idx,
                                   uint32_t* right_idx, uint32_t* matched);
-// unique build keys: one table probe per row (partner kept in match[]: build row id + 1, 0 = none), then a
-// streaming emit
+// unique build keys: one table probe per row -> partner[] (build row id, 0xFFFFFFFF = none) + the selection bitmap of
+// emitting rows and its counts per SEL_TILE rows (the inputs of launch_select_indices)
 hipError_t launch_join_probe_match(const LaunchCfg& cfg, const JoinTable& T, const uint64_t* rkeys128, const uint64_t* rsel,
-                                   uint32_t n_right, bool right_outer, uint32_t* counts, uint32_t* match);
-hipError_t launch_join_emit_match(const LaunchCfg& cfg, const uint32_t* match, uint32_t n_right, bool right_outer,
-                                  const uint64_t* offsets, uint32_t* left_idx, uint32_t* right_idx, uint32_t* matched);
+                                   uint32_t n_right, bool right_outer, uint32_t* partner, uint64_t* bitmap, uint32_t* tile_counts,
+                                   uint32_t* matched);
 hipError_t launch_join_unmatched_flags(const LaunchCfg& cfg, const uint32_t* matched, uint32_t n_left, uint32_t* flags);
 hipError_t launch_compact_flags(const LaunchCfg& cfg, const uint32_t* flags, const uint64_t* offsets, uint32_t n, uint32_t* out);
 

@@ -199,28 +199,41 @@ StreamPtr HashJoinExec::execute(int partition, const Exec& ex) const {
             bool has_rsel = false;
             side_keys(ex, *rb, rcols, rkeys, rsel, has_rsel);
             Temp tmp(ex);
-            uint32_t* counts = tmp.get<uint32_t>((size_t)n_right + 1);
-            uint64_t* offsets = tmp.get<uint64_t>((size_t)n_right + 1);
-            uint64_t* total = tmp.get<uint64_t>(1);
-            void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes(n_right));
             const uint64_t* rselp = has_rsel ? rsel->as<uint64_t>() : nullptr;
-            uint32_t* match = bs->unique ? tmp.get<uint32_t>((size_t)n_right + 1) : nullptr;
-            if (bs->unique)
-                HIP_CHECK(launch_join_probe_match(cfg, bs->table, rkeys->as<uint64_t>(), rselp, (uint32_t)n_right, right_outer, counts, match));
-            else
+            uint64_t* total = tmp.get<uint64_t>(1);
+            uint32_t *lidx = nullptr, *ridx = nullptr;
+            uint64_t n_out = 0;
+            if (bs->unique) {
+                // one probe per row -> selection bitmap -> indices (the index pass of FilterExec)
+                const int64_t n_tiles = (n_right + SEL_TILE - 1) / SEL_TILE;
+                uint32_t* partner = tmp.get<uint32_t>((size_t)n_right + 1);
+                uint64_t* bitmap = tmp.get<uint64_t>((size_t)(n_right + 63) / 64 + 1);
+                uint32_t* tile_counts = tmp.get<uint32_t>((size_t)n_tiles + 1);
+                uint64_t* tile_off = tmp.get<uint64_t>((size_t)n_tiles + 1);
+                void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes(n_tiles));
+                HIP_CHECK(launch_join_probe_match(cfg, bs->table, rkeys->as<uint64_t>(), rselp, (uint32_t)n_right, right_outer, partner,
+                                                  bitmap, tile_counts, left_outer ? matched->as<uint32_t>() : nullptr));
+                HIP_CHECK(exclusive_scan_u32_u64(ex.stream, tile_counts, n_tiles, tile_off, false, total, scan_tmp));
+                n_out = read_device(ex, total);
+                if (n_out == 0) continue;
+                lidx = tmp.get<uint32_t>((size_t)n_out);
+                ridx = tmp.get<uint32_t>((size_t)n_out);
+                HIP_CHECK(launch_select_indices(cfg, bitmap, tile_off, n_right, ridx));
+                HIP_CHECK(launch_take_fixed(cfg, partner, 4, ridx, (int64_t)n_out, lidx));
+            } else {
+                uint32_t* counts = tmp.get<uint32_t>((size_t)n_right + 1);
+                uint64_t* offsets = tmp.get<uint64_t>((size_t)n_right + 1);
+                void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes(n_right));
                 HIP_CHECK(launch_join_probe_count(cfg, bs->table, rkeys->as<uint64_t>(), rselp, (uint32_t)n_right, right_outer, counts));
-            HIP_CHECK(exclusive_scan_u32_u64(ex.stream, counts, n_right, offsets, false, total, scan_tmp));
-            const uint64_t n_out = read_device(ex, total);
-            if (n_out > 0xFFFFFFF0ull) fail(BHIP_EEXEC, "join output of one probe batch exceeds 2^32 rows");
-            if (n_out == 0) continue;
-            uint32_t* lidx = tmp.get<uint32_t>((size_t)n_out);
-            uint32_t* ridx = tmp.get<uint32_t>((size_t)n_out);
-            if (bs->unique)
-                HIP_CHECK(launch_join_emit_match(cfg, match, (uint32_t)n_right, right_outer, offsets, lidx, ridx,
-                                                 left_outer ? matched->as<uint32_t>() : nullptr));
-            else
+                HIP_CHECK(exclusive_scan_u32_u64(ex.stream, counts, n_right, offsets, false, total, scan_tmp));
+                n_out = read_device(ex, total);
+                if (n_out > 0xFFFFFFF0ull) fail(BHIP_EEXEC, "join output of one probe batch exceeds 2^32 rows");
+                if (n_out == 0) continue;
+                lidx = tmp.get<uint32_t>((size_t)n_out);
+                ridx = tmp.get<uint32_t>((size_t)n_out);
                 HIP_CHECK(launch_join_probe_emit(cfg, bs->table, rkeys->as<uint64_t>(), rselp, (uint32_t)n_right, right_outer, offsets,
                                                  lidx, ridx, left_outer ? matched->as<uint32_t>() : nullptr));
+            }
             emit(rb.get(), lidx, ridx, (int64_t)n_out);
             HIP_CHECK(hipStreamSynchronize(ex.stream));   // index scratch is released at the end of the iteration
         }

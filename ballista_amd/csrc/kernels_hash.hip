@@ -186,32 +186,31 @@ join_probe_emit_kernel(JoinTable T, const uint64_t* rkeys128, const uint64_t* rs
 }
 
 // ---- unique build keys (primary-key side: every TPC-H join): a probe row has at most one partner, so the
-// table is probed ONCE — the partner is kept per probe row and the emit pass is a streaming compaction
+// table is probed ONCE and the result is a selection: partner[row] (build row id, 0xFFFFFFFF = none), the bitmap
+// of emitting rows and its per-1024-row counts — the index pass of FilterExec (select_indices) then yields the
+// probe-side indices in row order and one gather of partner[] the build-side indices.  With unique keys the
+// slot's owner IS its only row: the chain head is never read (two random reads per probe instead of three).
 __global__ void __launch_bounds__(BLOCK)
 join_probe_match_kernel(JoinTable T, const uint64_t* rkeys128, const uint64_t* rsel, uint32_t n_right, int right_outer,
-                        uint32_t* counts, uint32_t* match) {
-    for (uint32_t row = blockIdx.x * BLOCK + threadIdx.x; row < n_right; row += gridDim.x * BLOCK) {
-        uint32_t m = 0;
-        if (bit_at(rsel, row)) {
+                        uint32_t* partner, uint64_t* bitmap, uint32_t* tile_counts, uint32_t* matched) {
+    const uint64_t n_round = ((uint64_t)n_right + 63u) & ~(uint64_t)63;
+    for (uint64_t row64 = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; row64 < n_round; row64 += (uint64_t)gridDim.x * BLOCK) {
+        const uint32_t row = (uint32_t)row64;
+        uint32_t m = 0xFFFFFFFFu;
+        const bool in = row64 < n_right;
+        if (in && bit_at(rsel, row)) {
             const Key128 key{rkeys128[2ull * row], rkeys128[2ull * row + 1]};
             const uint32_t slot = table_find(T, key);
-            if (slot != 0xFFFFFFFFu) m = T.head[slot];
+            if (slot != 0xFFFFFFFFu) {
+                m = T.owner[slot] - 1u;
+                if (matched) atomicOr(&matched[m >> 5], 1u << (m & 31));
+            }
         }
-        match[row] = m;
-        counts[row] = (right_outer || m != 0) ? 1u : 0u;
-    }
-}
-
-__global__ void __launch_bounds__(BLOCK)
-join_emit_match_kernel(const uint32_t* match, uint32_t n_right, int right_outer, const uint64_t* offsets, uint32_t* left_idx,
-                       uint32_t* right_idx, uint32_t* matched) {
-    for (uint32_t row = blockIdx.x * BLOCK + threadIdx.x; row < n_right; row += gridDim.x * BLOCK) {
-        const uint32_t m = match[row];
-        if (m != 0 || right_outer) {
-            const uint64_t pos = offsets[row];
-            left_idx[pos] = m != 0 ? m - 1u : 0xFFFFFFFFu;
-            right_idx[pos] = row;
-            if (matched && m != 0) atomicOr(&matched[(m - 1u) >> 5], 1u << ((m - 1u) & 31));
+        if (in) partner[row] = m;
+        const uint64_t word = __ballot(in && (right_outer || m != 0xFFFFFFFFu));
+        if ((threadIdx.x & 63) == 0) {
+            bitmap[row64 >> 6] = word;
+            if (word) atomicAdd(&tile_counts[row64 / SEL_TILE], (uint32_t)__popcll(word));
         }
     }
 }
@@ -257,17 +256,14 @@ hipError_t launch_join_probe_emit(const LaunchCfg& cfg, const JoinTable& T, cons
     return hipGetLastError();
 }
 hipError_t launch_join_probe_match(const LaunchCfg& cfg, const JoinTable& T, const uint64_t* rkeys128, const uint64_t* rsel,
-                                   uint32_t n_right, bool right_outer, uint32_t* counts, uint32_t* match) {
+                                   uint32_t n_right, bool right_outer, uint32_t* partner, uint64_t* bitmap, uint32_t* tile_counts,
+                                   uint32_t* matched) {
     if (n_right == 0) return hipSuccess;
+    const size_t n_tiles = ((size_t)n_right + SEL_TILE - 1) / SEL_TILE;
+    hipError_t e = hipMemsetAsync(tile_counts, 0, n_tiles * 4, cfg.stream);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(join_probe_match_kernel, dim3(grid_rows(cfg, n_right)), dim3(BLOCK), 0, cfg.stream, T, rkeys128, rsel,
-                       n_right, right_outer ? 1 : 0, counts, match);
-    return hipGetLastError();
-}
-hipError_t launch_join_emit_match(const LaunchCfg& cfg, const uint32_t* match, uint32_t n_right, bool right_outer,
-                                  const uint64_t* offsets, uint32_t* left_idx, uint32_t* right_idx, uint32_t* matched) {
-    if (n_right == 0) return hipSuccess;
-    hipLaunchKernelGGL(join_emit_match_kernel, dim3(grid_rows(cfg, n_right)), dim3(BLOCK), 0, cfg.stream, match, n_right,
-                       right_outer ? 1 : 0, offsets, left_idx, right_idx, matched);
+                       n_right, right_outer ? 1 : 0, partner, bitmap, tile_counts, matched);
     return hipGetLastError();
 }
 hipError_t launch_join_unmatched_flags(const LaunchCfg& cfg, const uint32_t* matched, uint32_t n_left, uint32_t* flags) {
