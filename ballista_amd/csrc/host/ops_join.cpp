@@ -191,13 +191,14 @@ StreamPtr HashJoinExec::execute(int partition, const Exec& ex) const {
             out.push_back(b);
         };
 
-        auto rs = self->right_->execute(partition, ex);
-        while (BatchPtr rb = rs->next()) {
-            const int64_t n_right = rb->n_rows;
-            if (n_right == 0) continue;
+        // probe: `probe` holds the key columns of the probe rows; output columns are gathered from `outsrc`, whose
+        // row of probe row i is remap[i] (nullptr: the same row)
+        auto process = [&](const Batch& probe, const Batch* outsrc, const uint32_t* remap) {
+            const int64_t n_right = probe.n_rows;
+            if (n_right == 0) return;
             BufferPtr rkeys, rsel;
             bool has_rsel = false;
-            side_keys(ex, *rb, rcols, rkeys, rsel, has_rsel);
+            side_keys(ex, probe, rcols, rkeys, rsel, has_rsel);
             Temp tmp(ex);
             const uint64_t* rselp = has_rsel ? rsel->as<uint64_t>() : nullptr;
             uint64_t* total = tmp.get<uint64_t>(1);
@@ -215,7 +216,7 @@ StreamPtr HashJoinExec::execute(int partition, const Exec& ex) const {
                                                   bitmap, tile_counts, left_outer ? matched->as<uint32_t>() : nullptr));
                 HIP_CHECK(exclusive_scan_u32_u64(ex.stream, tile_counts, n_tiles, tile_off, false, total, scan_tmp));
                 n_out = read_device(ex, total);
-                if (n_out == 0) continue;
+                if (n_out == 0) return;
                 lidx = tmp.get<uint32_t>((size_t)n_out);
                 ridx = tmp.get<uint32_t>((size_t)n_out);
                 HIP_CHECK(launch_select_indices(cfg, bitmap, tile_off, n_right, ridx));
@@ -228,14 +229,65 @@ StreamPtr HashJoinExec::execute(int partition, const Exec& ex) const {
                 HIP_CHECK(exclusive_scan_u32_u64(ex.stream, counts, n_right, offsets, false, total, scan_tmp));
                 n_out = read_device(ex, total);
                 if (n_out > 0xFFFFFFF0ull) fail(BHIP_EEXEC, "join output of one probe batch exceeds 2^32 rows");
-                if (n_out == 0) continue;
+                if (n_out == 0) return;
                 lidx = tmp.get<uint32_t>((size_t)n_out);
                 ridx = tmp.get<uint32_t>((size_t)n_out);
                 HIP_CHECK(launch_join_probe_emit(cfg, bs->table, rkeys->as<uint64_t>(), rselp, (uint32_t)n_right, right_outer, offsets,
                                                  lidx, ridx, left_outer ? matched->as<uint32_t>() : nullptr));
             }
-            emit(rb.get(), lidx, ridx, (int64_t)n_out);
+            if (remap) {
+                uint32_t* orig = tmp.get<uint32_t>((size_t)n_out);
+                HIP_CHECK(launch_take_fixed(cfg, remap, 4, ridx, (int64_t)n_out, orig));
+                ridx = orig;
+            }
+            emit(outsrc, lidx, ridx, (int64_t)n_out);
             HIP_CHECK(hipStreamSynchronize(ex.stream));   // index scratch is released at the end of the iteration
+        };
+
+        // Late materialisation of the probe side: when it is a column projection over a filter (Q3: lineitem, orders),
+        // only the join-key columns of the surviving rows are gathered before the probe; the other output columns are
+        // gathered once, for the MATCHING rows only, straight from the unfiltered batch (index composition).
+        const ProjectionExec* proj = dynamic_cast<const ProjectionExec*>(self->right_.get());
+        const ExecutionPlan* below = proj ? proj->children()[0].get() : nullptr;
+        while (below && dynamic_cast<const CoalesceBatchesExec*>(below)) below = below->children()[0].get();
+        const FilterExec* flt = below ? dynamic_cast<const FilterExec*>(below) : nullptr;
+        bool late = flt != nullptr;
+        if (late)
+            for (auto& en : proj->exprs()) late = late && en.first->kind == BHIP_EXPR_COLUMN;
+        if (late) {
+            PlanPtr src = flt->children()[0];
+            const SchemaPtr src_schema = src->schema();
+            const SchemaPtr out_schema = self->right_->schema();
+            std::vector<int> src_of;                       // projection output i -> source column
+            for (auto& en : proj->exprs()) src_of.push_back(src_schema->index_of(en.first->name));
+            auto key_schema = std::make_shared<Schema>();
+            std::vector<int> key_src;
+            for (auto& rc : rcols) {
+                const int j = out_schema->index_of(rc);
+                key_schema->fields.push_back(out_schema->fields[j]);
+                key_src.push_back(src_of[j]);
+            }
+            auto ss = src->execute(partition, ex);
+            while (BatchPtr b = ss->next()) {
+                if (b->n_rows == 0) continue;
+                BufferPtr sel;
+                const int64_t n_sel = filter_indices(ex, *b, flt->predicate(), sel);
+                if (n_sel == 0) continue;
+                auto kb = std::make_shared<Batch>();
+                kb->schema = key_schema;
+                kb->ctx = b->ctx;
+                kb->n_rows = n_sel;
+                for (int ci : key_src) kb->cols.push_back(take_batch_column(ex, b->cols[ci], sel->as<uint32_t>(), n_sel));
+                Batch pv;                                  // the projection's view of the unfiltered batch
+                pv.schema = out_schema;
+                pv.ctx = b->ctx;
+                pv.n_rows = b->n_rows;
+                for (int ci : src_of) pv.cols.push_back(b->cols[ci]);
+                process(*kb, &pv, sel->as<uint32_t>());
+            }
+        } else {
+            auto rs = self->right_->execute(partition, ex);
+            while (BatchPtr rb = rs->next()) process(*rb, rb.get(), nullptr);
         }
         if (left_outer && n_left > 0) {
             // left rows no probe row matched: right columns NULL
