@@ -77,6 +77,18 @@ std::string HashJoinExec::describe() const {
 // packed keys (+ "no NULL key" selection) of one side
 static void side_keys(const Exec& ex, const Batch& b, const std::vector<std::string>& cols, BufferPtr& keys, BufferPtr& sel,
                       bool& has_sel) {
+    // one NULL-free integer key column (every TPC-H join): the image is a widening copy, no expression program
+    if (cols.size() == 1) {
+        const int ci = b.schema->index_of(cols[0]);
+        const Column& c = b.cols[ci];
+        const int w = (c.dtype == DT_INT32 || c.dtype == DT_DATE32) ? 4 : (c.dtype == DT_INT64 || c.dtype == DT_UINT64) ? 8 : 0;
+        if (w && !c.validity) {
+            keys = make_buffer(ex, (size_t)b.n_rows * 16 + 16);
+            has_sel = false;
+            HIP_CHECK(launch_widen_key(ex.cfg(), c.data->ptr(), w, b.n_rows, keys->as<uint64_t>()));
+            return;
+        }
+    }
     ProgramBuilder pb(*b.schema);
     ExprPtr pred;
     for (auto& c : cols) {

@@ -446,6 +446,29 @@ emit_group_values_kernel(const GroupRec* table, int64_t n_groups, EmitValueBatch
     }
 }
 
+// ---- join / repartition key of ONE NULL-free integer column: the packed-key image the expression VM builds
+// (low `width` bytes of the value in word 0, word 1 = 0), as a streaming pass
+template <class T>
+__global__ void __launch_bounds__(BLOCK)
+widen_key_kernel(const T* src, int64_t n, uint64_t* keys128) {
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+        ulonglong2 k;
+        k.x = sizeof(T) == 4 ? (uint64_t)(uint32_t)src[i] : (uint64_t)src[i];
+        k.y = 0;
+        reinterpret_cast<ulonglong2*>(keys128)[i] = k;
+    }
+}
+hipError_t launch_widen_key(const LaunchCfg& cfg, const void* src, int width, int64_t n, uint64_t* keys128) {
+    if (n == 0) return hipSuccess;
+    if (width == 4)
+        hipLaunchKernelGGL(widen_key_kernel<uint32_t>, dim3(grid_for(cfg, n)), dim3(BLOCK), 0, cfg.stream, (const uint32_t*)src, n, keys128);
+    else if (width == 8)
+        hipLaunchKernelGGL(widen_key_kernel<uint64_t>, dim3(grid_for(cfg, n)), dim3(BLOCK), 0, cfg.stream, (const uint64_t*)src, n, keys128);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 // ---- pack many small device buffers into one block (one launch + one D2H copy on export) ---------------
 __global__ void __launch_bounds__(BLOCK)
 pack_buffers_kernel(PackDesc d, uint8_t* out) {

@@ -55,6 +55,9 @@ struct EmitValueSpec {
     int32_t count_is_rows;   // program has no NULLs: count(a) == rows
     int32_t dtype;
 };
+// packed-key image of one NULL-free Int32 / Date32 / Int64 / UInt64 column (width 4 or 8)
+hipError_t launch_widen_key(const LaunchCfg& cfg, const void* src, int width, int64_t n, uint64_t* keys128);
+
 // up to PACK_MAX small device buffers -> one contiguous block (offsets chosen by the host)
 constexpr int PACK_MAX = 64;
 struct PackDesc {
