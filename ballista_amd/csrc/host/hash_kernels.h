@@ -47,6 +47,17 @@ hipError_t launch_join_probe_emit(const LaunchCfg& cfg, const JoinTable& T, cons
 hipError_t launch_join_probe_match(const LaunchCfg& cfg, const JoinTable& T, const uint64_t* rkeys128, const uint64_t* rsel,
                                    uint32_t n_right, bool right_outer, uint32_t* partner, uint64_t* bitmap, uint32_t* tile_counts,
                                    uint32_t* matched);
+// one Int32 / Date32 key column, unique build side: key and build row share the slot (kernels_hash.hip)
+struct NarrowJoinTable {
+    uint64_t* slots;          // [capacity] key | (build row + 1) << 32, 0 = empty
+    uint64_t mask;
+    uint32_t* dup_flag;       // set when two build rows share a key: the host falls back to JoinTable
+};
+hipError_t launch_join_build_narrow(const LaunchCfg& cfg, const NarrowJoinTable& T, const uint32_t* keys, const uint64_t* sel,
+                                    uint32_t n_left);
+hipError_t launch_join_probe_match_narrow(const LaunchCfg& cfg, const NarrowJoinTable& T, const uint32_t* rkeys, const uint64_t* rsel,
+                                          uint32_t n_right, bool right_outer, uint32_t* partner, uint64_t* bitmap,
+                                          uint32_t* tile_counts, uint32_t* matched);
 hipError_t launch_join_unmatched_flags(const LaunchCfg& cfg, const uint32_t* matched, uint32_t n_left, uint32_t* flags);
 hipError_t launch_compact_flags(const LaunchCfg& cfg, const uint32_t* flags, const uint64_t* offsets, uint32_t n, uint32_t* out);
 

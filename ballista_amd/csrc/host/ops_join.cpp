@@ -20,6 +20,9 @@ struct JoinBuildSide {
     JoinTable table;
     bool has_sel = false;
     bool unique = false;            // no two build rows share a key: probe rows have at most one partner
+    bool narrow = false;            // ONE Int32 / Date32 key, unique: NarrowJoinTable instead of JoinTable
+    BufferPtr slots;
+    NarrowJoinTable ntable;
 };
 
 static const char* join_name(int t) { return t == BHIP_JOIN_INNER ? "Inner" : (t == BHIP_JOIN_LEFT ? "Left" : "Right"); }
@@ -116,6 +119,15 @@ static void side_keys(const Exec& ex, const Batch& b, const std::vector<std::str
     check_scan_status(ex, st);
 }
 
+// ONE key pair, both sides Int32 / Date32 columns
+bool HashJoinExec::narrow_key_types() const {
+    if (on_.size() != 1) return false;
+    const Schema &ls = *left_->schema(), &rs = *right_->schema();
+    const int lt = ls.fields[ls.index_of(on_[0].first)].dtype, rt = rs.fields[rs.index_of(on_[0].second)].dtype;
+    auto four = [](int t) { return t == DT_INT32 || t == DT_DATE32; };
+    return four(lt) && four(rt);
+}
+
 std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) const {
     std::lock_guard<std::mutex> g(cache_->mu);
     if (cache_->built) return cache_->built;
@@ -145,9 +157,28 @@ std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) co
     const int64_t n = bs->batch->n_rows;
     std::vector<std::string> lcols;
     for (auto& p : on_) lcols.push_back(p.first);
-    side_keys(ex, *bs->batch, lcols, bs->keys, bs->sel, bs->has_sel);
     uint64_t cap = 1024;
     while (cap < 2ull * (uint64_t)n) cap <<= 1;
+    static const bool narrow_disabled = [] { const char* v = getenv("BHIP_NO_NARROW_JOIN"); return v && atoi(v) != 0; }();
+    if (!narrow_disabled && narrow_key_types()) {
+        // optimistic: the build side of a key join is almost always unique
+        const Column& kc = bs->batch->cols[bs->batch->schema->index_of(lcols[0])];
+        bs->slots = make_buffer(ex, cap * 8);
+        bs->dup = make_buffer(ex, 8);
+        HIP_CHECK(hipMemsetAsync(bs->slots->ptr(), 0, cap * 8, ex.stream));
+        HIP_CHECK(hipMemsetAsync(bs->dup->ptr(), 0, 8, ex.stream));
+        bs->ntable = NarrowJoinTable{bs->slots->as<uint64_t>(), cap - 1, bs->dup->as<uint32_t>()};
+        HIP_CHECK(launch_join_build_narrow(ex.cfg(), bs->ntable, kc.data->as<uint32_t>(),
+                                           kc.validity ? kc.validity->as<uint64_t>() : nullptr, (uint32_t)n));
+        if (read_device(ex, bs->dup->as<uint32_t>()) == 0) {
+            bs->narrow = bs->unique = true;
+            bs->ntable.dup_flag = nullptr;
+            cache_->built = bs;
+            return bs;
+        }
+        bs->slots.reset();
+    }
+    side_keys(ex, *bs->batch, lcols, bs->keys, bs->sel, bs->has_sel);
     bs->owner = make_buffer(ex, cap * 4);
     bs->head = make_buffer(ex, cap * 4);
     bs->next = make_buffer(ex, (size_t)(n + 1) * 4);
@@ -210,7 +241,7 @@ StreamPtr HashJoinExec::execute(int partition, const Exec& ex) const {
             if (n_right == 0) return;
             BufferPtr rkeys, rsel;
             bool has_rsel = false;
-            side_keys(ex, probe, rcols, rkeys, rsel, has_rsel);
+            if (!bs->narrow) side_keys(ex, probe, rcols, rkeys, rsel, has_rsel);
             Temp tmp(ex);
             const uint64_t* rselp = has_rsel ? rsel->as<uint64_t>() : nullptr;
             uint64_t* total = tmp.get<uint64_t>(1);
@@ -224,8 +255,15 @@ StreamPtr HashJoinExec::execute(int partition, const Exec& ex) const {
                 uint32_t* tile_counts = tmp.get<uint32_t>((size_t)n_tiles + 1);
                 uint64_t* tile_off = tmp.get<uint64_t>((size_t)n_tiles + 1);
                 void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes(n_tiles));
-                HIP_CHECK(launch_join_probe_match(cfg, bs->table, rkeys->as<uint64_t>(), rselp, (uint32_t)n_right, right_outer, partner,
-                                                  bitmap, tile_counts, left_outer ? matched->as<uint32_t>() : nullptr));
+                if (bs->narrow) {
+                    const Column& kc = probe.cols[probe.schema->index_of(rcols[0])];
+                    HIP_CHECK(launch_join_probe_match_narrow(cfg, bs->ntable, kc.data->as<uint32_t>(),
+                                                             kc.validity ? kc.validity->as<uint64_t>() : nullptr, (uint32_t)n_right,
+                                                             right_outer, partner, bitmap, tile_counts,
+                                                             left_outer ? matched->as<uint32_t>() : nullptr));
+                } else
+                    HIP_CHECK(launch_join_probe_match(cfg, bs->table, rkeys->as<uint64_t>(), rselp, (uint32_t)n_right, right_outer, partner,
+                                                      bitmap, tile_counts, left_outer ? matched->as<uint32_t>() : nullptr));
                 HIP_CHECK(exclusive_scan_u32_u64(ex.stream, tile_counts, n_tiles, tile_off, false, total, scan_tmp));
                 n_out = read_device(ex, total);
                 if (n_out == 0) return;

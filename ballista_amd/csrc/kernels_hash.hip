@@ -215,6 +215,60 @@ join_probe_match_kernel(JoinTable T, const uint64_t* rkeys128, const uint64_t* r
     }
 }
 
+// ---- narrow keys: ONE Int32 / Date32 key column and a unique build side (the primary-key joins of TPC-H).
+// The slot holds the key and the build row together (key | (row + 1) << 32), so a probe step is ONE random
+// 8-byte read instead of a slot read followed by a dependent read of the 16-byte packed key; no packed keys are
+// materialised on either side.  A second build row with the same key raises dup_flag and the host rebuilds
+// with the general table.
+__device__ inline uint64_t narrow_hash(uint32_t key) { return mix64((uint64_t)key); }
+
+__global__ void __launch_bounds__(BLOCK)
+join_build_narrow_kernel(NarrowJoinTable T, const uint32_t* keys, const uint64_t* sel, uint32_t n_left) {
+    for (uint32_t row = blockIdx.x * BLOCK + threadIdx.x; row < n_left; row += gridDim.x * BLOCK) {
+        if (!bit_at(sel, row)) continue;                       // NULL keys never match
+        const uint32_t key = keys[row];
+        const unsigned long long mine = (unsigned long long)key | ((unsigned long long)(row + 1u) << 32);
+        uint64_t slot = narrow_hash(key) & T.mask;
+        for (;;) {
+            unsigned long long v = T.slots[slot];
+            if (v == 0) {
+                v = atomicCAS(reinterpret_cast<unsigned long long*>(&T.slots[slot]), 0ull, mine);
+                if (v == 0) break;                             // claimed
+            }
+            if ((uint32_t)v == key) { *T.dup_flag = 1u; break; }
+            slot = (slot + 1) & T.mask;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK)
+join_probe_match_narrow_kernel(NarrowJoinTable T, const uint32_t* rkeys, const uint64_t* rsel, uint32_t n_right, int right_outer,
+                               uint32_t* partner, uint64_t* bitmap, uint32_t* tile_counts, uint32_t* matched) {
+    const uint64_t n_round = ((uint64_t)n_right + 63u) & ~(uint64_t)63;
+    for (uint64_t row64 = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; row64 < n_round; row64 += (uint64_t)gridDim.x * BLOCK) {
+        const uint32_t row = (uint32_t)row64;
+        uint32_t m = 0xFFFFFFFFu;
+        const bool in = row64 < n_right;
+        if (in && bit_at(rsel, row)) {
+            const uint32_t key = rkeys[row];
+            uint64_t slot = narrow_hash(key) & T.mask;
+            for (;;) {
+                const uint64_t v = T.slots[slot];
+                if (v == 0) break;
+                if ((uint32_t)v == key) { m = (uint32_t)(v >> 32) - 1u; break; }
+                slot = (slot + 1) & T.mask;
+            }
+            if (matched && m != 0xFFFFFFFFu) atomicOr(&matched[m >> 5], 1u << (m & 31));
+        }
+        if (in) partner[row] = m;
+        const uint64_t word = __ballot(in && (right_outer || m != 0xFFFFFFFFu));
+        if ((threadIdx.x & 63) == 0) {
+            bitmap[row64 >> 6] = word;
+            if (word) atomicAdd(&tile_counts[row64 / SEL_TILE], (uint32_t)__popcll(word));
+        }
+    }
+}
+
 __global__ void __launch_bounds__(BLOCK)
 join_unmatched_flags_kernel(const uint32_t* matched, uint32_t n_left, uint32_t* flags) {
     for (uint32_t row = blockIdx.x * BLOCK + threadIdx.x; row < n_left; row += gridDim.x * BLOCK)
@@ -263,6 +317,23 @@ hipError_t launch_join_probe_match(const LaunchCfg& cfg, const JoinTable& T, con
     hipError_t e = hipMemsetAsync(tile_counts, 0, n_tiles * 4, cfg.stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(join_probe_match_kernel, dim3(grid_rows(cfg, n_right)), dim3(BLOCK), 0, cfg.stream, T, rkeys128, rsel,
+                       n_right, right_outer ? 1 : 0, partner, bitmap, tile_counts, matched);
+    return hipGetLastError();
+}
+hipError_t launch_join_build_narrow(const LaunchCfg& cfg, const NarrowJoinTable& T, const uint32_t* keys, const uint64_t* sel,
+                                    uint32_t n_left) {
+    if (n_left == 0) return hipSuccess;
+    hipLaunchKernelGGL(join_build_narrow_kernel, dim3(grid_rows(cfg, n_left)), dim3(BLOCK), 0, cfg.stream, T, keys, sel, n_left);
+    return hipGetLastError();
+}
+hipError_t launch_join_probe_match_narrow(const LaunchCfg& cfg, const NarrowJoinTable& T, const uint32_t* rkeys, const uint64_t* rsel,
+                                          uint32_t n_right, bool right_outer, uint32_t* partner, uint64_t* bitmap,
+                                          uint32_t* tile_counts, uint32_t* matched) {
+    if (n_right == 0) return hipSuccess;
+    const size_t n_tiles = ((size_t)n_right + SEL_TILE - 1) / SEL_TILE;
+    hipError_t e = hipMemsetAsync(tile_counts, 0, n_tiles * 4, cfg.stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(join_probe_match_narrow_kernel, dim3(grid_rows(cfg, n_right)), dim3(BLOCK), 0, cfg.stream, T, rkeys, rsel,
                        n_right, right_outer ? 1 : 0, partner, bitmap, tile_counts, matched);
     return hipGetLastError();
 }
