@@ -1,0 +1,97 @@
+"""GPU parity of HashJoinExec's table variants against the CPU oracle (reference operator:
+rust/core/src/serde/physical_plan/from_proto.rs:253-276 — Inner / Left / Right, equi-keys by column name):
+
+  narrow   one Int32 / Date32 key, unique build side: key + build row in one 8-byte slot, probe reads the key column
+  general  packed 16-byte keys: duplicates on the build side, Int64 / multi-column / Utf8 keys
+  late materialisation  probe side = column projection over a filter: only its key columns are gathered before the probe
+
+Row multisets must match exactly (join output order is unspecified)."""
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+
+import ballista_amd as ba
+from ballista_amd import expr as E
+from ballista_amd.expr import col, lit
+from oracle import plan_eval
+from oracle.engine import OCol
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+JOIN_TYPES = [ba.plan.INNER, ba.plan.LEFT, ba.plan.RIGHT]
+
+
+def sides(n_left, n_right, key_type="Int32", unique=True, nulls=False, seed=0, key_range=None):
+    rng = np.random.default_rng(seed)
+    key_range = key_range or 2 * n_left
+    lk = rng.permutation(key_range)[:n_left] if unique else rng.integers(0, max(2, n_left // 3), n_left)
+    rk = rng.integers(0, key_range + 50, n_right)
+    np_t = np.int64 if key_type == "Int64" else np.int32
+    lv = (rng.random(n_left) > 0.1) if nulls else None
+    rv = (rng.random(n_right) > 0.1) if nulls else None
+    left = OrderedDict([("lk", OCol(key_type, lk.astype(np_t) - 7, lv)), ("lx", OCol("Float64", rng.random(n_left))),
+                        ("ls", OCol("Utf8", [f"L{i % 11}" for i in range(n_left)]))])
+    right = OrderedDict([("rk", OCol(key_type, rk.astype(np_t) - 7, rv)), ("ry", OCol("Int64", rng.integers(0, 10 ** 9, n_right))),
+                         ("rd", OCol("Date32", rng.integers(9000, 10000, n_right).astype(np.int32)))])
+    return left, right
+
+
+def check(plan, keys):
+    got = helpers.concat(helpers.collect_product(plan))
+    helpers.assert_rows_equal(got, plan_eval.collect(plan), ordered=False, key_cols=keys)
+    return got
+
+
+@pytest.mark.parametrize("jt", JOIN_TYPES)
+@pytest.mark.parametrize("key_type", ["Int32", "Date32", "Int64"])
+@pytest.mark.parametrize("unique", [True, False])
+@pytest.mark.parametrize("nulls", [False, True])
+def test_table_variants(ctx, jt, key_type, unique, nulls):
+    left, right = sides(900, 5000, key_type, unique, nulls, seed=11)
+    lm = helpers.memory_exec(ctx, [[helpers.slice_batch(left, 0, 400)], [helpers.slice_batch(left, 400, 900)]])
+    rm = helpers.memory_exec(ctx, [[helpers.slice_batch(right, 0, 1025), helpers.slice_batch(right, 1025, 3000)], [helpers.slice_batch(right, 3000, 5000)]])
+    plan = ba.HashJoinExec(lm, rm, [("lk", "rk")], jt)
+    for p in range(2):
+        got = helpers.concat([helpers.from_device(b) for b in plan.execute(p)])
+        want = helpers.concat(plan_eval.execute(plan, p))
+        helpers.assert_rows_equal(got, want, ordered=False, key_cols=["lk", "rk", "ry", "lx"])
+
+
+@pytest.mark.parametrize("jt", JOIN_TYPES)
+def test_probe_side_projection_over_filter(ctx, jt):
+    """the Q3 shape: HashJoin(build, Projection(Filter(probe))) with a renamed and a dropped column"""
+    left, right = sides(600, 4000, "Int32", True, False, seed=5)
+    schema = {"rk": "Int32", "ry": "Int64", "rd": "Date32"}
+    flt = ba.FilterExec(E.coerce(col("rd") > E.date32("1996-01-01"), schema), helpers.memory_exec(ctx, [[right]]))
+    proj = ba.ProjectionExec([(col("ry"), "payload"), (col("rk"), "rk")], ba.CoalesceBatchesExec(flt, 4096))
+    plan = ba.HashJoinExec(helpers.memory_exec(ctx, [[left]]), proj, [("lk", "rk")], jt)
+    assert [n for n, _, _ in plan.schema()] == ["lk", "lx", "ls", "payload", "rk"]
+    check(plan, ["lk", "rk", "payload", "lx"])
+
+
+def test_probe_side_filter_selects_nothing_or_everything(ctx):
+    left, right = sides(300, 2000, "Int32", True, False, seed=9)
+    schema = {"rk": "Int32", "ry": "Int64", "rd": "Date32"}
+    for pred in (col("rd") > E.date32("2030-01-01"), col("rd") > E.date32("1970-01-01")):
+        flt = ba.FilterExec(E.coerce(pred, schema), helpers.memory_exec(ctx, [[right]]))
+        proj = ba.ProjectionExec([(col("rk"), "rk"), (col("rd"), "rd")], flt)
+        check(ba.HashJoinExec(helpers.memory_exec(ctx, [[left]]), proj, [("lk", "rk")], ba.plan.INNER), ["lk", "rk", "rd", "lx"])
+
+
+def test_probe_sizes_around_the_selection_tile(ctx):
+    for n in (1, 63, 64, 65, 1023, 1024, 1025, 4097):
+        left, right = sides(200, n, "Int32", True, False, seed=n)
+        plan = ba.HashJoinExec(helpers.memory_exec(ctx, [[left]]), helpers.memory_exec(ctx, [[right]]), [("lk", "rk")], ba.plan.INNER)
+        check(plan, ["lk", "rk", "ry", "lx"])
+
+
+def test_negative_and_extreme_keys(ctx):
+    lk = np.array([-2 ** 31, -1, 0, 1, 2 ** 31 - 1, 123456789], dtype=np.int32)
+    left = OrderedDict([("lk", OCol("Int32", lk)), ("lx", OCol("Float64", np.arange(6, dtype=np.float64)))])
+    rk = np.array([2 ** 31 - 1, -2 ** 31, 5, 0, 0, -1, 123456789, 7], dtype=np.int32)
+    right = OrderedDict([("rk", OCol("Int32", rk)), ("ry", OCol("Int64", np.arange(8)))])
+    plan = ba.HashJoinExec(helpers.memory_exec(ctx, [[left]]), helpers.memory_exec(ctx, [[right]]), [("lk", "rk")], ba.plan.INNER)
+    got = check(plan, ["lk", "rk", "ry", "lx"])
+    assert len(got["lk"].values) == 6
