@@ -191,7 +191,7 @@ def main():
         groups = result[0].to_pydict() if result else {}
         out["result_check"] = {"groups": len(next(iter(groups.values()))) if groups else 0,
                                "rows_counted": int(sum(groups.get("count_order", [0])))}
-        if not args.no_cpu_baseline and args.cpu_rows > 0:
+        if world == 1 and not args.no_cpu_baseline and args.cpu_rows > 0:      # the CPU leg runs at N=1 only
             # free the GPU table first? no: host memory only; the sample lives in host RAM
             out["cpu_baseline"] = cpu_baseline(args.query, min(args.cpu_rows, rows))
         else:
