@@ -24,16 +24,22 @@ __device__ inline uint64_t spread32(uint64_t x) {
     return x;
 }
 
+// own tile constants: the selection interface fixes 1024-row tiles whatever lean_kernel.h is tuned to
+constexpr int RB_U = 2;
+constexpr int RB_SUB = BLOCK * 2;
+constexpr int RB_TILE = RB_SUB * RB_U;
+constexpr int RB_ROWS = 2 * RB_U;
+
 template <int NRANGE>
 __global__ void __launch_bounds__(BLOCK)
 range_bitmap_kernel(const SopProgram* __restrict__ Sp, uint64_t* bitmap, uint32_t* tile_counts) {
-    static_assert(LEAN_TILE == SEL_TILE, "selection tiles are 1024 rows");
+    static_assert(RB_TILE == SEL_TILE, "selection tiles are 1024 rows");
     const SopProgram& S = *Sp;
-    constexpr int U = LEAN_U;
+    constexpr int U = RB_U;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_ranges = S.n_ranges;
     const int64_t n_rows = S.n_rows;
-    const int64_t n_tiles = n_rows / LEAN_TILE;                 // full tiles
+    const int64_t n_tiles = n_rows / RB_TILE;                 // full tiles
     const int64_t grid = gridDim.x;
 
     const BHIP_GLOBAL char* rp[NRANGE];
@@ -51,7 +57,7 @@ range_bitmap_kernel(const SopProgram* __restrict__ Sp, uint64_t* bitmap, uint32_
     const uint32_t t8 = (uint32_t)tid * 8u, t16 = (uint32_t)tid * 16u;
 
     for (int64_t t = blockIdx.x; t < n_tiles; t += grid) {
-        const int64_t row0 = t * LEAN_TILE;
+        const int64_t row0 = t * RB_TILE;
         LeanU4 rv[NRANGE][U];
 #pragma unroll
         for (int p = 0; p < NRANGE; ++p)
@@ -59,17 +65,17 @@ range_bitmap_kernel(const SopProgram* __restrict__ Sp, uint64_t* bitmap, uint32_
                 if (r32[p]) {
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
-                        const LeanU2 v = lean_ld2(rp[p] + row0 * 4 + u * (LEAN_SUB * 4) + t8);
+                        const LeanU2 v = lean_ld2(rp[p] + row0 * 4 + u * (RB_SUB * 4) + t8);
                         rv[p][u].x = v.x; rv[p][u].y = v.y; rv[p][u].z = 0; rv[p][u].w = 0;
                     }
                 } else {
 #pragma unroll
-                    for (int u = 0; u < U; ++u) rv[p][u] = lean_ld4(rp[p] + row0 * 8 + u * (LEAN_SUB * 8) + t16);
+                    for (int u = 0; u < U; ++u) rv[p][u] = lean_ld4(rp[p] + row0 * 8 + u * (RB_SUB * 8) + t16);
                 }
             }
-        bool live[LEAN_ROWS];
+        bool live[RB_ROWS];
 #pragma unroll
-        for (int r = 0; r < LEAN_ROWS; ++r) live[r] = true;
+        for (int r = 0; r < RB_ROWS; ++r) live[r] = true;
 #pragma unroll
         for (int p = 0; p < NRANGE; ++p)
             if (p < n_ranges) {
@@ -98,7 +104,7 @@ range_bitmap_kernel(const SopProgram* __restrict__ Sp, uint64_t* bitmap, uint32_
             const uint64_t w_hi = spread32(b0 >> 32) | (spread32(b1 >> 32) << 1);
             cnt += (uint32_t)(__popcll(b0) + __popcll(b1));
             if (lane == 0) {
-                uint64_t* out = bitmap + (row0 >> 6) + u * (LEAN_SUB / 64) + wave * 2;
+                uint64_t* out = bitmap + (row0 >> 6) + u * (RB_SUB / 64) + wave * 2;
                 out[0] = w_lo;
                 out[1] = w_hi;
             }
@@ -107,10 +113,10 @@ range_bitmap_kernel(const SopProgram* __restrict__ Sp, uint64_t* bitmap, uint32_
     }
 
     // ragged tail (< 1024 rows): one row per lane, the ballot is already in row order
-    if ((int64_t)blockIdx.x == n_tiles % grid && n_tiles * LEAN_TILE < n_rows) {
-        const int64_t tail0 = n_tiles * LEAN_TILE;
+    if ((int64_t)blockIdx.x == n_tiles % grid && n_tiles * RB_TILE < n_rows) {
+        const int64_t tail0 = n_tiles * RB_TILE;
         uint32_t cnt = 0;
-        for (int k = 0; k < LEAN_TILE / BLOCK; ++k) {
+        for (int k = 0; k < RB_TILE / BLOCK; ++k) {
             const int64_t i = tail0 + (int64_t)k * BLOCK + tid;
             bool ok = i < n_rows;
             if (ok) {
@@ -133,7 +139,7 @@ range_bitmap_kernel(const SopProgram* __restrict__ Sp, uint64_t* bitmap, uint32_
 template <int NRANGE>
 static hipError_t launch_range_t(const LaunchCfg& cfg, const SopProgram& S, SopProgram* dprog, uint64_t* bitmap, uint32_t* tile_counts) {
     auto k = range_bitmap_kernel<NRANGE>;
-    const int64_t n_tiles = (S.n_rows + LEAN_TILE - 1) / LEAN_TILE;
+    const int64_t n_tiles = (S.n_rows + RB_TILE - 1) / RB_TILE;
     hipError_t e = hipMemsetAsync(tile_counts, 0, (size_t)n_tiles * 4, cfg.stream);
     if (e != hipSuccess) return e;
     int64_t grid = (int64_t)cfg.device_cus * 8;

@@ -10,7 +10,7 @@
 //   * at most 4 groups per workgroup (SCAN_OVERFLOW_GROUPS -> sop_kernel.h with 8 -> hash path).
 // host/sop.cpp::lean_eligible decides; results are identical by construction (same per-row arithmetic,
 // same fixed reduction order), only the instruction count differs.  What changed against sop_kernel.h,
-// each point sized on its ISA (profiles/r01_lean_*):
+// each point sized on its ISA and measured (profiles/r01_shapes_120M_rows_lean_vs_sop.txt):
 //   * a thread owns TWO CONSECUTIVE rows of each 512-row sub-tile, so one global_load_dwordx4 brings
 //     both Float64 values of a column (a wave reads 1 KiB contiguous), one dwordx2 both dates, one
 //     dwordx2 + dword the three Arrow offsets of both strings, and one unaligned 8-byte load the bytes
@@ -36,7 +36,10 @@
 
 namespace bhip {
 
-constexpr int LEAN_U = 2;                       // sub-tiles per loop iteration
+#ifndef LEAN_U_VALUE
+#define LEAN_U_VALUE 2
+#endif
+constexpr int LEAN_U = LEAN_U_VALUE;            // sub-tiles per loop iteration
 constexpr int LEAN_SUB = BLOCK * 2;             // rows per sub-tile (two consecutive rows per thread)
 constexpr int LEAN_TILE = LEAN_SUB * LEAN_U;    // 1024 rows
 constexpr int LEAN_ROWS = 2 * LEAN_U;           // rows per thread and tile
