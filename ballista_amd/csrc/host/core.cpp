@@ -223,6 +223,19 @@ BatchPtr batch_from_host(const ContextPtr& ctx, int n_cols, const bhip_column_de
     std::vector<uint8_t> staging;
     std::vector<size_t> slice_off;
     BufferPtr block;
+    // a validity bitmap with every bit set says "no NULLs" (Arrow producers often attach one): the column is
+    // imported without it, so the NULL-free kernels serve it; the schema keeps its nullability
+    std::vector<const uint8_t*> validity((size_t)n_cols, nullptr);
+    for (int i = 0; i < n_cols; ++i) {
+        validity[i] = cols[i].validity;
+        if (device_ptrs || !cols[i].validity) continue;
+        const uint8_t* v = cols[i].validity;
+        const int64_t whole = n_rows / 8;
+        bool all = true;
+        for (int64_t k = 0; k < whole && all; ++k) all = v[k] == 0xFF;
+        if (all && (n_rows & 7)) all = (v[whole] & ((1u << (n_rows & 7)) - 1u)) == ((1u << (n_rows & 7)) - 1u);
+        if (all) validity[i] = nullptr;
+    }
     if (!device_ptrs) {
         size_t total = 0;
         bool small = true;
@@ -238,7 +251,7 @@ BatchPtr batch_from_host(const ContextPtr& ctx, int n_cols, const bhip_column_de
             const size_t db = d.dtype == DT_UTF8 ? (size_t)d.data_bytes : d.dtype == DT_BOOLEAN ? bitmap_bytes(n_rows) : (size_t)n_rows * dtype_width(d.dtype);
             plan(d.data ? d.data : (const void*)"", db);
             if (d.offsets) plan(d.offsets, (size_t)(n_rows + 1) * 4);
-            if (d.validity) plan(d.validity, bitmap_bytes(n_rows));
+            if (validity[i]) plan(validity[i], bitmap_bytes(n_rows));
         }
         if (small && total > 0 && total <= (4u << 20)) {
             staging.assign(total, 0);
@@ -280,7 +293,7 @@ BatchPtr batch_from_host(const ContextPtr& ctx, int n_cols, const bhip_column_de
             const size_t padded = d.dtype == DT_BOOLEAN ? bitmap_bytes(n_rows) : data_bytes;
             c.data = slice(d.data, data_bytes, padded + 8);
             if (d.offsets) c.offsets = slice(d.offsets, (size_t)(n_rows + 1) * 4, (size_t)(n_rows + 1) * 4);
-            if (d.validity) c.validity = slice(d.validity, (size_t)((n_rows + 7) / 8), bitmap_bytes(n_rows) + 8);
+            if (validity[i]) c.validity = slice(validity[i], (size_t)((n_rows + 7) / 8), bitmap_bytes(n_rows) + 8);
         } else {
             // device copies are padded to whole 64-bit words (bitmaps are read as u64)
             const size_t padded = d.dtype == DT_BOOLEAN ? bitmap_bytes(n_rows) : data_bytes;
@@ -291,10 +304,10 @@ BatchPtr batch_from_host(const ContextPtr& ctx, int n_cols, const bhip_column_de
                 c.offsets = make_buffer(ex, (size_t)(n_rows + 1) * 4);
                 HIP_CHECK(hipMemcpy(c.offsets->ptr(), d.offsets, (size_t)(n_rows + 1) * 4, hipMemcpyHostToDevice));
             }
-            if (d.validity) {
+            if (validity[i]) {
                 c.validity = make_buffer(ex, bitmap_bytes(n_rows) + 8);
                 HIP_CHECK(hipMemset(c.validity->ptr(), 0, bitmap_bytes(n_rows) + 8));
-                HIP_CHECK(hipMemcpy(c.validity->ptr(), d.validity, (size_t)((n_rows + 7) / 8), hipMemcpyHostToDevice));
+                HIP_CHECK(hipMemcpy(c.validity->ptr(), validity[i], (size_t)((n_rows + 7) / 8), hipMemcpyHostToDevice));
             }
         }
         batch->cols.push_back(std::move(c));

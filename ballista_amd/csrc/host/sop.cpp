@@ -24,12 +24,11 @@ struct Builder {
         return (int)out.col_map.size() - 1;
     }
 
-    // non-nullable column reference -> schema index, or -1
+    // column reference -> schema index, or -1.  A nullable field is accepted: whether a batch really carries
+    // NULLs (a validity bitmap) is decided per batch by sop_columns_bindable
     int plain_column(const ExprPtr& e) const {
         if (e->kind != BHIP_EXPR_COLUMN) return -1;
-        const int i = schema.index_of(e->name);
-        if (i < 0 || schema.fields[i].nullable) return -1;
-        return i;
+        return schema.index_of(e->name);
     }
 
     // ---- predicate: AND of  column <op> literal  over Float64 / Int32 / Date32 columns, folded into one

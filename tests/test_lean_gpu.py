@@ -169,3 +169,33 @@ def test_borrowed_device_buffers_take_the_other_path(ctx):
     part = ba.HashAggregateExec(ba.plan.PARTIAL, g, AGGS_Q1, src)
     got = helpers.concat(helpers.collect_product(part))
     helpers.assert_rows_equal(got, plan_eval.collect(part), ordered=False, float_rtol=RTOL, key_cols=["ks"])
+
+
+def test_all_valid_bitmaps_are_dropped_at_import_and_take_the_fast_kernels():
+    """Arrow producers often attach validity bitmaps with every bit set: such columns are imported without the
+    bitmap (the schema stays nullable) and the NULL-free kernels serve them — same answer as the oracle"""
+    c = ba.Context(0)
+    n = 70_001
+    b = batch(n, 91, vocab=("A", "N", "R"))
+    allv = np.ones(n, dtype=bool)
+    cols = [(name, x.dtype, list(x.values) if x.dtype == "Utf8" else x.values, allv) for name, x in b.items()]
+    dev = ba.RecordBatch.from_columns(c, cols)
+    assert all(dev.column_info(i)[2] for i in range(dev.num_columns))            # nullable in the schema
+    assert not any(dev.column_info(i)[4] for i in range(dev.num_columns))        # ... but no validity buffer on the device
+    src = ba.MemoryExec([[dev]], c)
+    src._oracle_partitions = [[b]]
+    g = [(col("ks"), "ks")]                                        # 3 groups: fits the 4 per workgroup
+    part = ba.HashAggregateExec(ba.plan.PARTIAL, g, AGGS_Q1, ba.FilterExec(E.coerce(col("d") <= E.date32("1998-09-02"), SCHEMA), src))
+    c.kernel_time(reset=True)
+    got = helpers.concat(helpers.collect_product(part))
+    ms, launches = c.kernel_time(reset=True)
+    assert launches == 1 and c.kernel_name() == "scan_agg_lean_kernel"
+    helpers.assert_rows_equal(got, plan_eval.collect(part), ordered=False, float_rtol=RTOL, key_cols=["ks"])
+    # one real NULL keeps the bitmap and the general path: same answer as the oracle with that NULL
+    v = allv.copy()
+    v[12345] = False
+    b2 = OrderedDict((k, OCol(x.dtype, x.values, v if k == "x" else None)) for k, x in b.items())
+    part2 = ba.HashAggregateExec(ba.plan.PARTIAL, g, AGGS_Q1,
+                                 ba.FilterExec(E.coerce(col("d") <= E.date32("1998-09-02"), SCHEMA), helpers.memory_exec(c, [[b2]])))
+    got2 = helpers.concat(helpers.collect_product(part2))
+    helpers.assert_rows_equal(got2, plan_eval.collect(part2), ordered=False, float_rtol=RTOL, key_cols=["ks"])
