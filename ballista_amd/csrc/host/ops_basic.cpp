@@ -94,12 +94,56 @@ static Column take_column_v(const Exec& ex, const Column& c, const uint32_t* idx
     return out;
 }
 
+// several columns by the same index vector: the fixed-width values and all bitmaps go in ONE launch
+// (a Q1 result batch is 10 columns x 4 rows: ten launches of four threads otherwise); Utf8 columns one by one
+std::vector<Column> take_columns(const Exec& ex, const std::vector<const Column*>& cols, const uint32_t* idx, int64_t n,
+                                 bool may_null, bool permutation) {
+    std::vector<Column> out(cols.size());
+    TakeMany tm;
+    tm.n = 0;
+    auto flush = [&]() {
+        if (tm.n) HIP_CHECK(launch_take_many(ex.cfg(), tm, idx, n));
+        tm.n = 0;
+    };
+    auto add = [&](const void* src, void* dst, int width) {
+        if (tm.n == TAKE_MANY_MAX) flush();
+        tm.src[tm.n] = src; tm.dst[tm.n] = dst; tm.width[tm.n] = width;
+        ++tm.n;
+    };
+    for (size_t i = 0; i < cols.size(); ++i) {
+        const Column& c = *cols[i];
+        Column& o = out[i];
+        if (c.dtype == DT_UTF8) {
+            o = take_column(ex, c, idx, n, permutation ? c.data_bytes : -1);
+        } else {
+            o.dtype = c.dtype;
+            o.length = n;
+            if (c.dtype == DT_BOOLEAN) {
+                o.data = make_buffer(ex, bitmap_bytes(n) + 8);
+                add(c.data->ptr(), o.data->ptr(), 0);
+            } else {
+                const int w = dtype_width(c.dtype);
+                o.data = make_buffer(ex, (size_t)n * w + 8);
+                add(c.data->ptr(), o.data->ptr(), w);
+            }
+        }
+        if (c.validity || may_null) {
+            o.validity = make_buffer(ex, bitmap_bytes(n) + 8);
+            add(c.validity ? c.validity->ptr() : nullptr, o.validity->ptr(), 0);
+        }
+    }
+    flush();
+    return out;
+}
+
 BatchPtr take_batch(const Exec& ex, const Batch& in, const uint32_t* idx, int64_t n_out, SchemaPtr schema, bool permutation) {
     auto out = std::make_shared<Batch>();
     out->schema = schema ? schema : in.schema;
     out->ctx = in.ctx;
     out->n_rows = n_out;
-    for (const auto& c : in.cols) out->cols.push_back(take_column_v(ex, c, idx, n_out, false, permutation));
+    std::vector<const Column*> cols;
+    for (const auto& c : in.cols) cols.push_back(&c);
+    out->cols = take_columns(ex, cols, idx, n_out, false, permutation);
     return out;
 }
 

@@ -224,12 +224,14 @@ StreamPtr HashJoinExec::execute(int partition, const Exec& ex) const {
             b->schema = self->schema_;
             b->ctx = ex.ctx;
             b->n_rows = n_out;
-            for (auto& c : L.cols) b->cols.push_back(right_outer ? take_column_nullable(ex, c, lidx, n_out)
-                                                                  : take_batch_column(ex, c, lidx, n_out));
-            for (int ci : self->right_cols_) {
-                if (R) b->cols.push_back(left_outer ? take_column_nullable(ex, R->cols[ci], ridx, n_out)
-                                                    : take_batch_column(ex, R->cols[ci], ridx, n_out));
-                else b->cols.push_back(null_column(ex, self->right_->schema()->fields[ci].dtype, n_out));
+            std::vector<const Column*> lc, rc;
+            for (auto& c : L.cols) lc.push_back(&c);
+            for (auto& c : take_columns(ex, lc, lidx, n_out, right_outer)) b->cols.push_back(std::move(c));
+            if (R) {
+                for (int ci : self->right_cols_) rc.push_back(&R->cols[ci]);
+                for (auto& c : take_columns(ex, rc, ridx, n_out, left_outer)) b->cols.push_back(std::move(c));
+            } else {
+                for (int ci : self->right_cols_) b->cols.push_back(null_column(ex, self->right_->schema()->fields[ci].dtype, n_out));
             }
             out.push_back(b);
         };

@@ -269,6 +269,9 @@ void check_scan_status(const Exec& ex, const ScanStatus* dev_status, ScanStatus*
 Column evaluate_column(const Exec& ex, const Batch& in, const ExprPtr& e);
 // gather of one column incl. its validity bitmap
 Column take_batch_column(const Exec& ex, const Column& c, const uint32_t* idx, int64_t n);
+// columns gathered by one index vector; may_null: the indices may hold 0xFFFFFFFF (outer joins) -> validity always built
+std::vector<Column> take_columns(const Exec& ex, const std::vector<const Column*>& cols, const uint32_t* idx, int64_t n,
+                                 bool may_null, bool permutation = false);
 // n NULLs of the given type
 Column null_column(const Exec& ex, int dtype, int64_t n);
 // gather where indices may hold 0xFFFFFFFF (= NULL row): always carries a validity bitmap

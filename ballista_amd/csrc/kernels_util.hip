@@ -213,6 +213,36 @@ take_bitmap_kernel(const uint64_t* src, const uint32_t* idx, int64_t n, uint64_t
     }
 }
 
+// every fixed-width column and every bitmap of a batch in ONE launch: blockIdx.y selects the buffer
+__global__ void __launch_bounds__(BLOCK)
+take_many_kernel(TakeMany d, const uint32_t* idx, int64_t n) {
+    const int c = blockIdx.y;
+    const void* src = d.src[c];
+    void* dst = d.dst[c];
+    const int width = d.width[c];
+    if (width == 0) {                                      // bitmap (src == nullptr: all set)
+        const uint64_t* bs = reinterpret_cast<const uint64_t*>(src);
+        uint64_t* bd = reinterpret_cast<uint64_t*>(dst);
+        const int64_t n_round = (n + 63) & ~(int64_t)63;
+        for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n_round; i += (int64_t)gridDim.x * BLOCK) {
+            bool bit = false;
+            if (i < n) {
+                const uint32_t j = idx[i];
+                if (j != NULL_INDEX) bit = bs == nullptr ? true : ((bs[j >> 6] >> (j & 63)) & 1ull);
+            }
+            const uint64_t word = __ballot(bit);
+            if ((threadIdx.x & 63) == 0) bd[i >> 6] = word;
+        }
+        return;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+        const uint32_t j = idx[i];
+        if (width == 8) reinterpret_cast<uint64_t*>(dst)[i] = j == NULL_INDEX ? 0ull : reinterpret_cast<const uint64_t*>(src)[j];
+        else if (width == 4) reinterpret_cast<uint32_t*>(dst)[i] = j == NULL_INDEX ? 0u : reinterpret_cast<const uint32_t*>(src)[j];
+        else reinterpret_cast<uint8_t*>(dst)[i] = j == NULL_INDEX ? (uint8_t)0 : reinterpret_cast<const uint8_t*>(src)[j];
+    }
+}
+
 __global__ void __launch_bounds__(BLOCK)
 take_utf8_lengths_kernel(const int32_t* offsets, const uint32_t* idx, int64_t n, uint32_t* lengths) {
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
@@ -252,6 +282,12 @@ hipError_t launch_take_fixed(const LaunchCfg& cfg, const void* src, int width, c
                                    (const uint64_t*)src, idx, n, (uint64_t*)dst); break;
         default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_take_many(const LaunchCfg& cfg, const TakeMany& d, const uint32_t* idx, int64_t n) {
+    if (n == 0 || d.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(take_many_kernel, dim3(grid_for(cfg, n), d.n), dim3(BLOCK), 0, cfg.stream, d, idx, n);
     return hipGetLastError();
 }
 

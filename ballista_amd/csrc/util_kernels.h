@@ -22,6 +22,15 @@ hipError_t launch_select_indices(const LaunchCfg& cfg, const uint64_t* bitmap, c
                                  int64_t n_rows, uint32_t* indices);
 
 // ---- take ----------------------------------------------------------------------------------
+// up to TAKE_MANY_MAX gathers by the same index vector in one launch (width 1 / 4 / 8 bytes, 0 = bitmap)
+constexpr int TAKE_MANY_MAX = 32;
+struct TakeMany {
+    int32_t n;
+    const void* src[TAKE_MANY_MAX];
+    void* dst[TAKE_MANY_MAX];
+    int32_t width[TAKE_MANY_MAX];
+};
+hipError_t launch_take_many(const LaunchCfg& cfg, const TakeMany& d, const uint32_t* idx, int64_t n);
 hipError_t launch_take_fixed(const LaunchCfg& cfg, const void* src, int width, const uint32_t* idx, int64_t n, void* dst);
 hipError_t launch_take_bitmap(const LaunchCfg& cfg, const uint64_t* src, const uint32_t* idx, int64_t n, uint64_t* dst);
 hipError_t launch_take_utf8_lengths(const LaunchCfg& cfg, const int32_t* offsets, const uint32_t* idx, int64_t n,
