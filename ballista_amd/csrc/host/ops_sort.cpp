@@ -117,8 +117,52 @@ std::vector<BatchPtr> hash_partition_batch(const Exec& ex, const BatchPtr& in, c
     const int64_t n = in->n_rows;
     const LaunchCfg cfg = ex.cfg();
     std::vector<BatchPtr> out((size_t)n_parts);
-    BufferPtr perm = make_buffer(ex, (size_t)n * 4 + 8);
     std::vector<uint32_t> first((size_t)n_parts + 1, 0);
+    // ONE NULL-free integer key over fixed-width NULL-free columns (the exchange of the TPC-H joins): scatter pass
+    {
+        const Column* kc = nullptr;
+        if (exprs.size() == 1 && exprs[0]->kind == BHIP_EXPR_COLUMN) {
+            const int ci = in->schema->index_of(exprs[0]->name);
+            if (ci >= 0) kc = &in->cols[ci];
+        }
+        const int kw = !kc || kc->validity ? 0 : (kc->dtype == DT_INT32 || kc->dtype == DT_DATE32) ? 4 : (kc->dtype == DT_INT64 || kc->dtype == DT_UINT64) ? 8 : 0;
+        bool fixed = kw != 0 && n > 0 && n_parts <= 256 && (int)in->cols.size() <= TAKE_MANY_MAX;
+        for (auto& c : in->cols) fixed = fixed && !c.validity && c.dtype != DT_UTF8 && c.dtype != DT_BOOLEAN;
+        static const bool disabled = [] { const char* v = getenv("BHIP_NO_PARTITION_SCATTER"); return v && atoi(v) != 0; }();
+        if (fixed && !disabled) {
+            TakeMany tm;
+            tm.n = 0;
+            std::vector<BufferPtr> whole;
+            for (auto& c : in->cols) {
+                const int w = dtype_width(c.dtype);
+                whole.push_back(make_buffer(ex, (size_t)n * w + 8));
+                tm.src[tm.n] = c.data->ptr(); tm.dst[tm.n] = whole.back()->ptr(); tm.width[tm.n] = w;
+                ++tm.n;
+            }
+            Temp tmp(ex);
+            void* temp = tmp.get<uint8_t>(partition_scatter_temp_bytes(n));
+            HIP_CHECK(partition_scatter(cfg, kc->data->ptr(), kw, n, (uint32_t)n_parts, tm, temp, first.data()));
+            for (int p = 0; p < n_parts; ++p) {
+                auto b = std::make_shared<Batch>();
+                b->schema = in->schema;
+                b->ctx = in->ctx;
+                b->n_rows = (int64_t)first[p + 1] - (int64_t)first[p];
+                for (size_t ci = 0; ci < in->cols.size(); ++ci) {
+                    const int w = dtype_width(in->cols[ci].dtype);
+                    Column c;
+                    c.dtype = in->cols[ci].dtype;
+                    c.length = b->n_rows;
+                    // a partition's column is a slice of the scattered column (kept alive by the slice)
+                    c.data = std::make_shared<Buffer>(ex.ctx, whole[ci], static_cast<uint8_t*>(whole[ci]->ptr()) + (size_t)first[p] * w,
+                                                      (size_t)b->n_rows * w);
+                    b->cols.push_back(std::move(c));
+                }
+                out[p] = b;
+            }
+            return out;
+        }
+    }
+    BufferPtr perm = make_buffer(ex, (size_t)n * 4 + 8);
     if (n > 0) {
         ProgramBuilder pb(*in->schema);
         pb.set_hash_only();

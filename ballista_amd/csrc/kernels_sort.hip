@@ -75,6 +75,107 @@ radix_scatter_kernel(const uint64_t* keys, const uint32_t* vals, int64_t n, int 
     }
 }
 
+// ---- hash partitioning of fixed-width columns in two passes over the key column + one over the payload --------
+// RepartitionExec(Hash(key), n) for ONE NULL-free integer key (every exchange of the TPC-H joins): the partition id
+// (row hash % n) is recomputed from the key column in both passes instead of being materialised, and
+// the scatter pass writes every payload column straight to its partition-contiguous position — each byte is read
+// once and written once, where sort-by-partition-id + one gather per partition re-reads every cache line of every
+// column once per partition.  Rows keep their input order inside a partition (same stable ranks as the radix pass).
+template <int KEYW>
+__device__ inline uint32_t partition_of(const void* keys, int64_t j, uint32_t n_parts) {
+    uint64_t bits;
+    if (KEYW == 4) bits = (uint64_t)(int64_t) reinterpret_cast<const int32_t*>(keys)[j];      // sign-extended
+    else bits = reinterpret_cast<const uint64_t*>(keys)[j];
+    return (uint32_t)(mix64(bits) % n_parts);                                                  // h = mix64(0 ^ bits)
+}
+
+template <int KEYW>
+__global__ void __launch_bounds__(SORT_BLOCK)
+partition_hist_kernel(const void* keys, int64_t n, uint32_t n_parts, uint32_t* hist, int n_blocks) {
+    __shared__ uint32_t s_hist[256];
+    s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * SORT_CHUNK;
+#pragma unroll
+    for (int i = 0; i < SORT_ITEMS; ++i) {
+        const int64_t j = base + i * SORT_BLOCK + threadIdx.x;
+        if (j < n) atomicAdd(&s_hist[partition_of<KEYW>(keys, j, n_parts)], 1u);
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * n_blocks + blockIdx.x] = s_hist[threadIdx.x];   // partition-major
+}
+
+template <int KEYW>
+__global__ void __launch_bounds__(SORT_BLOCK)
+partition_scatter_kernel(const void* keys, int64_t n, uint32_t n_parts, const uint32_t* offsets, int n_blocks, TakeMany cols) {
+    __shared__ uint32_t s_base[256];
+    __shared__ uint32_t s_wave[4][256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    s_base[tid] = offsets[(size_t)tid * n_blocks + blockIdx.x];
+    const int64_t base = (int64_t)blockIdx.x * SORT_CHUNK;
+    for (int i = 0; i < SORT_ITEMS; ++i) {
+        for (int w = 0; w < 4; ++w) s_wave[w][tid] = 0;
+        __syncthreads();
+        const int64_t j = base + i * SORT_BLOCK + tid;
+        const bool in = j < n;
+        const uint32_t digit = in ? partition_of<KEYW>(keys, j, n_parts) : 0u;
+        uint64_t same = __ballot(in);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const uint64_t m = __ballot((digit >> b) & 1);
+            same &= ((digit >> b) & 1) ? m : ~m;
+        }
+        const uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        if (in && rank == 0) s_wave[wave][digit] = (uint32_t)__popcll(same);
+        __syncthreads();
+        if (in) {
+            uint32_t pos = s_base[digit] + rank;
+            for (int w = 0; w < wave; ++w) pos += s_wave[w][digit];
+            for (int c = 0; c < cols.n; ++c) {
+                const int w = cols.width[c];
+                if (w == 8) reinterpret_cast<uint64_t*>(cols.dst[c])[pos] = reinterpret_cast<const uint64_t*>(cols.src[c])[j];
+                else if (w == 4) reinterpret_cast<uint32_t*>(cols.dst[c])[pos] = reinterpret_cast<const uint32_t*>(cols.src[c])[j];
+                else reinterpret_cast<uint8_t*>(cols.dst[c])[pos] = reinterpret_cast<const uint8_t*>(cols.src[c])[j];
+            }
+        }
+        __syncthreads();
+        s_base[tid] += s_wave[0][tid] + s_wave[1][tid] + s_wave[2][tid] + s_wave[3][tid];
+        __syncthreads();
+    }
+}
+
+size_t partition_scatter_temp_bytes(int64_t n) {
+    const int64_t n_blocks = (n + SORT_CHUNK - 1) / SORT_CHUNK;
+    const size_t hist = (size_t)256 * (n_blocks > 0 ? n_blocks : 1) * 4;
+    return 2 * hist + exclusive_scan_temp_bytes(256 * n_blocks) + 64;
+}
+
+// first[p] (host, n_parts + 1 entries) = first output row of partition p
+hipError_t partition_scatter(const LaunchCfg& cfg, const void* keys, int key_width, int64_t n, uint32_t n_parts, const TakeMany& cols,
+                             void* temp, uint32_t* first_host) {
+    if (n_parts == 0 || n_parts > 256 || (key_width != 4 && key_width != 8)) return hipErrorInvalidValue;
+    for (uint32_t p = 0; p <= n_parts; ++p) first_host[p] = 0;
+    if (n == 0) return hipSuccess;
+    const int n_blocks = (int)((n + SORT_CHUNK - 1) / SORT_CHUNK);
+    const size_t hist_elems = (size_t)256 * n_blocks;
+    uint32_t* hist = reinterpret_cast<uint32_t*>(temp);
+    uint32_t* offsets = hist + hist_elems;
+    void* scan_tmp = offsets + hist_elems + 4;
+    if (key_width == 4) hipLaunchKernelGGL(partition_hist_kernel<4>, dim3(n_blocks), dim3(SORT_BLOCK), 0, cfg.stream, keys, n, n_parts, hist, n_blocks);
+    else hipLaunchKernelGGL(partition_hist_kernel<8>, dim3(n_blocks), dim3(SORT_BLOCK), 0, cfg.stream, keys, n, n_parts, hist, n_blocks);
+    hipError_t e = exclusive_scan_u32_u32(cfg.stream, hist, (int64_t)hist_elems, offsets, false, nullptr, scan_tmp);
+    if (e != hipSuccess) return e;
+    if (key_width == 4) hipLaunchKernelGGL(partition_scatter_kernel<4>, dim3(n_blocks), dim3(SORT_BLOCK), 0, cfg.stream, keys, n, n_parts, offsets, n_blocks, cols);
+    else hipLaunchKernelGGL(partition_scatter_kernel<8>, dim3(n_blocks), dim3(SORT_BLOCK), 0, cfg.stream, keys, n, n_parts, offsets, n_blocks, cols);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    // offsets[p * n_blocks] = rows of partitions < p
+    e = hipMemcpy2DAsync(first_host, 4, offsets, (size_t)n_blocks * 4, 4, n_parts, hipMemcpyDeviceToHost, cfg.stream);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(cfg.stream);
+    first_host[n_parts] = (uint32_t)n;
+    return e;
+}
+
 // OR over all keys of (key XOR first key): bits that differ somewhere
 __global__ void __launch_bounds__(SORT_BLOCK)
 key_diff_kernel(const uint64_t* keys, int64_t n, uint64_t* out) {

@@ -1,5 +1,6 @@
 // sort_kernels.h — launchers of kernels_sort.hip (internal C++ interface).
 #pragma once
+#include "util_kernels.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "kernels.h"
@@ -22,6 +23,12 @@ hipError_t launch_sort_key_utf8(const LaunchCfg& cfg, const ColumnRef& c, const 
 hipError_t launch_sort_key_null(const LaunchCfg& cfg, const uint64_t* validity, const uint32_t* perm, int64_t n, bool nulls_first,
                                 uint64_t* out);
 hipError_t launch_utf8_max_len(const LaunchCfg& cfg, const int32_t* offsets, int64_t n, uint32_t* out);
+// hash partitioning of fixed-width columns by ONE NULL-free Int32 / Date32 (key_width 4) or Int64 / UInt64 (8) key:
+// histogram + scan + one scatter of every payload column (util_kernels.h: TakeMany, widths 1 / 4 / 8);
+// first_host[0..n_parts] = partition boundaries in the scattered columns.  n_parts <= 256.
+size_t partition_scatter_temp_bytes(int64_t n);
+hipError_t partition_scatter(const LaunchCfg& cfg, const void* keys, int key_width, int64_t n, uint32_t n_parts, const TakeMany& cols,
+                             void* temp, uint32_t* first_host);
 hipError_t launch_hash_to_pid(const LaunchCfg& cfg, const uint64_t* hashes, int64_t n, uint32_t n_parts, uint64_t* out);
 hipError_t launch_partition_bounds(const LaunchCfg& cfg, const uint64_t* sorted_keys, int64_t n, uint32_t n_parts, uint32_t* first);
 
