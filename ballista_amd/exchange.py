@@ -90,6 +90,55 @@ def all_to_all_batches(dist, outgoing, device="cpu"):
     return out
 
 
+class _DeviceBytes:
+    """a device buffer as torch sees it (the CUDA array interface; PyTorch-ROCm implements it for HIP memory)"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def all_to_all_device(dist, outgoing, ctx, device):
+    """The same exchange with the column buffers moving device to device (RCCL over xGMI): `outgoing[d]` is the
+    device-resident batch for rank d, as `ballista_amd.plan.hash_partition` returns them — fixed-width NULL-free
+    columns (the probe / build columns of the TPC-H joins).  One int64 all_gather of the row counts, then ONE
+    all_to_all per column with uneven splits straight out of the partition slices into one receive buffer per
+    column; the received batch wraps those buffers without a copy.  Source-rank order, input order inside."""
+    import torch
+    from . import plan as P
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if len(outgoing) != world:
+        raise ValueError(f"need one outgoing batch per rank ({world}), got {len(outgoing)}")
+    schema = outgoing[0].schema()
+    widths = []
+    for name, dtype in schema:
+        if dtype not in P.NP_DTYPE:
+            raise NotImplementedError(f"all_to_all_device: column {name} is {dtype}; use all_to_all_batches")
+        widths.append(np.dtype(P.NP_DTYPE[dtype]).itemsize)
+    for b in outgoing:
+        if any(b.column_info(i)[4] for i in range(b.num_columns)):
+            raise NotImplementedError("all_to_all_device: columns with NULLs; use all_to_all_batches")
+    ctx.synchronize()                                   # the partitions are complete before another stream reads them
+    counts = torch.tensor([b.num_rows for b in outgoing], dtype=torch.int64, device=device)
+    all_counts = [torch.empty_like(counts) for _ in range(world)]
+    dist.all_gather(all_counts, counts)
+    incoming = [int(all_counts[src][rank].item()) for src in range(world)]
+    total = sum(incoming)
+    recv_bufs = []
+    for ci, w in enumerate(widths):
+        send = []
+        for d in range(world):
+            n = outgoing[d].num_rows
+            ptr = outgoing[d].column_device(ci)[0]
+            send.append(torch.as_tensor(_DeviceBytes(ptr, n * w), device=device) if n else torch.empty(0, dtype=torch.uint8, device=device))
+        buf = torch.empty(max(total * w, 1), dtype=torch.uint8, device=device)
+        recv = list(buf[:total * w].split([n * w for n in incoming])) if total else [buf[:0] for _ in range(world)]
+        dist.all_to_all(recv, send)
+        recv_bufs.append(buf)
+    torch.cuda.synchronize(device)
+    cols = [(name, dtype, buf.data_ptr()) for (name, dtype), buf in zip(schema, recv_bufs)]
+    return P.RecordBatch.from_device_pointers(ctx, cols, total, keep=(recv_bufs, outgoing))
+
+
 def all_gather_batches(dist, batch, device="cpu", slot_bytes=SLOT_BYTES):
     """Every rank contributes one small pyarrow.RecordBatch and receives the batches of all ranks, in
     rank order (the order MergeExec concatenates partitions in, rust/scheduler/src/planner.rs:136-148).

@@ -289,6 +289,27 @@ class RecordBatch:
         return rb
 
     @staticmethod
+    def from_device_pointers(ctx: Context, columns, n_rows: int, keep=None) -> "RecordBatch":
+        """bhip_batch_from_device over caller-owned device memory: columns = [(name, dtype, data_ptr)], fixed-width
+        NULL-free columns (e.g. buffers an RCCL collective has just filled).  `keep`: whatever owns the memory."""
+        descs, names = [], []
+        for name, dtype, ptr in columns:
+            if dtype in (E.UTF8, E.BOOLEAN):
+                raise ValueError("from_device_pointers takes fixed-width columns")
+            d = L.ColumnDesc()
+            nb = name.encode()
+            names.append(nb)
+            d.name, d.dtype, d.nullable = nb, DTYPE_ID[dtype], 0
+            d.data, d.offsets, d.validity, d.data_bytes = ptr, None, None, 0
+            descs.append(d)
+        arr = (L.ColumnDesc * max(1, len(descs)))(*descs)
+        h = C.c_void_p()
+        L.check(L.lib().bhip_batch_from_device(ctx._h, len(descs), arr, n_rows, C.byref(h)))
+        rb = RecordBatch(h, ctx)
+        rb._owner = keep
+        return rb
+
+    @staticmethod
     def from_pyarrow(ctx: Context, batch) -> "RecordBatch":
         """through the Arrow C Data Interface (bhip_batch_import_arrow)"""
         import pyarrow as pa
