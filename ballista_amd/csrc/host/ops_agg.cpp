@@ -328,14 +328,15 @@ std::vector<BatchPtr> HashAggregateExec::run(int partition, const Exec& ex) cons
         for (int ci : pb.columns())
             if (b->cols[ci].validity) nullable = true;
 
-    // the fast path packs keys its own way, so it serves either every batch of the run or none
-    for (auto& b : inputs)
-        if (use_sop && !sop_columns_bindable(sop, *b)) use_sop = false;
-    // ... and its wide-load variant (lean_kernel.h) when the plan and the buffers allow
+    // the fast path packs keys its own way, so it serves either every batch of the run or none.
+    // Its wide-load variant (lean_kernel.h) also takes NULLs in the columns the predicate constrains.
     static const bool lean_disabled = [] { const char* v = getenv("BHIP_NO_LEAN"); return v && atoi(v) != 0; }();
     bool use_lean = use_sop && !lean_disabled && lean_eligible(sop.prog);
-    for (auto& b : inputs)
-        if (use_lean && !lean_bindable(sop, *b)) use_lean = false;
+    for (auto& b : inputs) {
+        if (use_lean && !(sop_columns_bindable(sop, *b, true) && lean_bindable(sop, *b))) use_lean = false;
+        if (use_sop && !sop_columns_bindable(sop, *b)) use_sop = false;
+    }
+    bool sop_layout = false;             // the pass that produced `table` packed keys the fast path's way
 
     Temp tmp(ex);
     const LaunchCfg cfg = ex.cfg();
@@ -352,7 +353,7 @@ std::vector<BatchPtr> HashAggregateExec::run(int partition, const Exec& ex) cons
     while (!inputs.empty()) {
         if (gmax == -1) {
             // ---- hash path: one device-wide table, atomics ----------------------------------------
-            use_sop = false;                 // the hash path packs keys with the VM's layout
+            sop_layout = false;              // the hash path packs keys with the VM's layout
             table = hash_aggregate(ex, tmp, P0, pb, inputs, nullable, &n_groups, status, timer);
             break;
         }
@@ -363,18 +364,20 @@ std::vector<BatchPtr> HashAggregateExec::run(int partition, const Exec& ex) cons
         uint32_t* partial_ng = tmp.get<uint32_t>(max_parts);
         HIP_CHECK(hipMemsetAsync(status, 0, sizeof(ScanStatus), ex.stream));
         int n_part = 0;
-        const bool lean_now = use_sop && use_lean && (gmax == 1 || gmax == 4);
+        const bool lean_now = use_lean && (gmax == 1 || gmax == 4);
+        const bool sop_now = !lean_now && use_sop;
+        sop_layout = lean_now || sop_now;
         for (auto& b : inputs) {
             ScanParams P = P0;
             ProgramBuilder::bind(P, pb.columns(), *b, nullable);
             int grid = 0;
             const bool timed = b->n_rows >= (1 << 16);   // the bench hook times the dominant (large) launches only
-            if (timed) { timer.begin(); timer.kernel = lean_now ? "scan_agg_lean_kernel" : use_sop ? "scan_agg_sop_kernel" : "scan_agg_lowcard_kernel"; }
+            if (timed) { timer.begin(); timer.kernel = lean_now ? "scan_agg_lean_kernel" : sop_now ? "scan_agg_sop_kernel" : "scan_agg_lowcard_kernel"; }
             if (lean_now) {
                 bind_sop(sop, *b);
                 HIP_CHECK(launch_scan_agg_lean(cfg, sop.prog, tmp.get<SopProgram>(1), gmax, partials + (size_t)n_part * gmax,
                                                partial_ng + n_part, max_grid, status, &grid));
-            } else if (use_sop) {
+            } else if (sop_now) {
                 bind_sop(sop, *b);
                 HIP_CHECK(launch_scan_agg_sop(cfg, sop.prog, tmp.get<SopProgram>(1), gmax, partials + (size_t)n_part * gmax,
                                               partial_ng + n_part, max_grid, status, &grid));
@@ -396,7 +399,7 @@ std::vector<BatchPtr> HashAggregateExec::run(int partition, const Exec& ex) cons
             use_lean = false;                // a string key longer than 3 bytes: the 7-byte variant next
             continue;
         }
-        if (use_sop && (st.flags & SCAN_ERR_KEY_TOO_LONG)) {
+        if (sop_now && (st.flags & SCAN_ERR_KEY_TOO_LONG)) {
             use_sop = false;                 // a string key longer than the fast path's 7 bytes: the VM packs up to 15
             continue;
         }
@@ -434,7 +437,7 @@ std::vector<BatchPtr> HashAggregateExec::run(int partition, const Exec& ex) cons
     out->schema = schema_;
     out->ctx = ex.ctx;
     out->n_rows = n_groups;
-    const auto& kinfo = use_sop ? sop.key_info : pb.key_info();
+    const auto& kinfo = sop_layout ? sop.key_info : pb.key_info();
     // Utf8 key columns: the value bytes have the packed key's bound (width - 1 per group), so the bytes are
     // written before their total is known (width bytes per group bounds them); the totals come back in ONE read after everything is queued
     uint64_t* totals = tmp.get<uint64_t>(group_.size() + 1);

@@ -264,7 +264,7 @@ int64_t filter_indices(const Exec& ex, const Batch& in, const ExprPtr& predicate
     // (kernels_range.hip) writes the same bitmap + tile counts as the expression VM
     static const bool range_disabled = [] { const char* v = getenv("BHIP_NO_RANGE_FILTER"); return v && atoi(v) != 0; }();
     SopPlan rp;
-    if (!range_disabled && build_sop(*in.schema, predicate, {}, {}, rp) && rp.prog.n_ranges >= 1 && sop_columns_bindable(rp, in) &&
+    if (!range_disabled && build_sop(*in.schema, predicate, {}, {}, rp) && rp.prog.n_ranges >= 1 && sop_columns_bindable(rp, in, true) &&
         lean_bindable(rp, in)) {
         bind_sop(rp, in);
         HIP_CHECK(launch_range_bitmap(ex.cfg(), rp.prog, tmp.get<SopProgram>(1), bitmap, tile_counts));

@@ -212,9 +212,15 @@ bool build_sop(const Schema& schema, const ExprPtr& predicate, const std::vector
     return true;
 }
 
-bool sop_columns_bindable(const SopPlan& plan, const Batch& b) {
-    for (int ci : plan.col_map)
-        if (b.cols[ci].validity) return false;          // NULLs present: the VM kernel handles them
+bool sop_columns_bindable(const SopPlan& plan, const Batch& b, bool range_nulls_ok) {
+    for (size_t i = 0; i < plan.col_map.size(); ++i) {
+        if (!b.cols[plan.col_map[i]].validity) continue;
+        // NULLs present.  A column the predicate constrains may have them where the kernel tests the bitmap: a NULL
+        // fails the range, so the row reaches neither a key nor an accumulator.  Anything else: the VM kernel.
+        bool ranged = false;
+        for (int r = 0; r < plan.prog.n_ranges; ++r) ranged = ranged || plan.prog.ranges[r].col == (uint8_t)i;
+        if (!(range_nulls_ok && ranged)) return false;
+    }
     return true;
 }
 
@@ -225,6 +231,7 @@ void bind_sop(SopPlan& plan, const Batch& b) {
         SopColumn& sc = plan.prog.cols[i];
         sc.data = c.data ? c.data->ptr() : nullptr;
         sc.offsets = c.offsets ? c.offsets->as<int32_t>() : nullptr;
+        sc.validity = c.validity ? c.validity->as<uint64_t>() : nullptr;
         sc.dtype = c.dtype;
         sc.data_bytes = (int32_t)c.data_bytes;
     }

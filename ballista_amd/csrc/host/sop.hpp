@@ -22,7 +22,8 @@ struct SopPlan {
 bool build_sop(const Schema& schema, const ExprPtr& predicate, const std::vector<ExprPtr>& keys,
                const std::vector<SopAccExpr>& accs, SopPlan& out);
 // false when a referenced column of the batch carries NULLs (then the VM kernel runs)
-bool sop_columns_bindable(const SopPlan& plan, const Batch& b);
+// range_nulls_ok: the kernel tests the validity bitmap of range (predicate) columns (lean_kernel.h, kernels_range.hip)
+bool sop_columns_bindable(const SopPlan& plan, const Batch& b, bool range_nulls_ok = false);
 void bind_sop(SopPlan& plan, const Batch& b);
 
 // the wide-load variant (lean_kernel.h): every chain factor a Float64 column, <= 2 key parts of 32 bits

@@ -43,14 +43,16 @@ range_bitmap_kernel(const SopProgram* __restrict__ Sp, uint64_t* bitmap, uint32_
     const int64_t grid = gridDim.x;
 
     const BHIP_GLOBAL char* rp[NRANGE];
+    const BHIP_GLOBAL uint64_t* rvp[NRANGE];   // validity bitmap or null: a NULL fails every comparison
     bool r32[NRANGE];
     double rlo[NRANGE], rhi[NRANGE];
 #pragma unroll
     for (int p = 0; p < NRANGE; ++p) {
-        rp[p] = nullptr; r32[p] = false; rlo[p] = -__builtin_huge_val(); rhi[p] = __builtin_huge_val();
+        rp[p] = nullptr; rvp[p] = nullptr; r32[p] = false; rlo[p] = -__builtin_huge_val(); rhi[p] = __builtin_huge_val();
         if (p < n_ranges) {
             r32[p] = S.ranges[p].is32 != 0;
             rp[p] = (const BHIP_GLOBAL char*)S.cols[S.ranges[p].col].data;
+            rvp[p] = (const BHIP_GLOBAL uint64_t*)S.cols[S.ranges[p].col].validity;
             rlo[p] = S.ranges[p].lo; rhi[p] = S.ranges[p].hi;
         }
     }
@@ -94,6 +96,15 @@ range_bitmap_kernel(const SopProgram* __restrict__ Sp, uint64_t* bitmap, uint32_
                         live[2 * u + 1] = live[2 * u + 1] && b >= rlo[p] && b <= rhi[p];
                     }
                 }
+                if (rvp[p]) {           // the word of rows [64k, 64k + 64) holding this lane's pair (32 lanes share it)
+                    const uint32_t bit = (2u * (uint32_t)tid) & 63u;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const uint64_t w = rvp[p][(row0 >> 6) + u * (RB_SUB / 64) + (tid >> 5)];
+                        live[2 * u] = live[2 * u] && ((w >> bit) & 1ull);
+                        live[2 * u + 1] = live[2 * u + 1] && ((w >> (bit + 1u)) & 1ull);
+                    }
+                }
             }
         // lane l holds rows 2l, 2l+1 of this wave's 128-row span: interleave the two ballots into row order
         uint32_t cnt = 0;
@@ -125,6 +136,7 @@ range_bitmap_kernel(const SopProgram* __restrict__ Sp, uint64_t* bitmap, uint32_
                     if (p < n_ranges) {
                         const double x = r32[p] ? (double)*(const BHIP_GLOBAL int32_t*)(rp[p] + i * 4) : *(const BHIP_GLOBAL double*)(rp[p] + i * 8);
                         ok = ok && x >= rlo[p] && x <= rhi[p];
+                        if (rvp[p]) ok = ok && ((rvp[p][i >> 6] >> (i & 63)) & 1ull);
                     }
             }
             const uint64_t word = __ballot(ok);

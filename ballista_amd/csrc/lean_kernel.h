@@ -103,14 +103,16 @@ scan_agg_lean_kernel(const SopProgram* __restrict__ Sp, GroupRec* partials, uint
     const int64_t stride = grid * LEAN_TILE;
 
     const BHIP_GLOBAL char* rp[NRANGE];
+    const BHIP_GLOBAL uint64_t* rvp[NRANGE];   // validity of a range column, or null (host: only range columns may have one)
     bool r32[NRANGE];
     double rlo[NRANGE], rhi[NRANGE];
 #pragma unroll
     for (int p = 0; p < NRANGE; ++p) {
-        rp[p] = nullptr; r32[p] = false; rlo[p] = -__builtin_huge_val(); rhi[p] = __builtin_huge_val();
+        rp[p] = nullptr; rvp[p] = nullptr; r32[p] = false; rlo[p] = -__builtin_huge_val(); rhi[p] = __builtin_huge_val();
         if (p < n_ranges) {
             r32[p] = S.ranges[p].is32 != 0;
             rp[p] = (const BHIP_GLOBAL char*)S.cols[S.ranges[p].col].data + row0 * (r32[p] ? 4 : 8);
+            if (S.cols[S.ranges[p].col].validity) rvp[p] = (const BHIP_GLOBAL uint64_t*)S.cols[S.ranges[p].col].validity + row0 / 64;
             rlo[p] = S.ranges[p].lo; rhi[p] = S.ranges[p].hi;
         }
     }
@@ -236,6 +238,7 @@ scan_agg_lean_kernel(const SopProgram* __restrict__ Sp, GroupRec* partials, uint
 
     // ---- registers of one tile (raw bits).  Row j of sub-tile u: tile row u*512 + 2*tid + j.
     LeanU4 rv[NRANGE][U];        // 32-bit column: .x .y = rows 0 1; 64-bit: (.x .y) (.z .w)
+    uint64_t rvw[NRANGE][U];    // validity word of this lane's row pair (range columns may carry NULLs: they fail the range)
     uint32_t kv[NKEY][U][2];    // Int32 key: the two values.  Utf8 key: lengths of the two strings
     uint64_t kb[NKEY][U];       // Utf8 key: 8 bytes at the first string's offset
     LeanU3 ko[NKEY][U];         // Utf8 key: the three offsets, ONE tile ahead of kv / kb
@@ -243,7 +246,7 @@ scan_agg_lean_kernel(const SopProgram* __restrict__ Sp, GroupRec* partials, uint
 #pragma unroll
     for (int u = 0; u < U; ++u) {
 #pragma unroll
-        for (int p = 0; p < NRANGE; ++p) rv[p][u] = LeanU4{0, 0, 0, 0};
+        for (int p = 0; p < NRANGE; ++p) { rv[p][u] = LeanU4{0, 0, 0, 0}; rvw[p][u] = ~0ull; }
 #pragma unroll
         for (int q = 0; q < NKEY; ++q) { kv[q][u][0] = kv[q][u][1] = 0; kb[q][u] = 0; ko[q][u] = LeanU3{0, 0, 0}; }
 #pragma unroll
@@ -264,6 +267,10 @@ scan_agg_lean_kernel(const SopProgram* __restrict__ Sp, GroupRec* partials, uint
                 } else {
 #pragma unroll
                     for (int u = 0; u < U; ++u) rv[p][u] = lean_ld4(rp[p] + u * (LEAN_SUB * 8) + t16);
+                }
+                if (rvp[p]) {           // word of rows [64k, 64k+64) that holds this lane's pair: 32 lanes share it
+#pragma unroll
+                    for (int u = 0; u < U; ++u) rvw[p][u] = rvp[p][u * (LEAN_SUB / 64) + (tid >> 5)];
                 }
             }
     };
@@ -317,7 +324,10 @@ scan_agg_lean_kernel(const SopProgram* __restrict__ Sp, GroupRec* partials, uint
     };
     auto advance_rest = [&]() {
 #pragma unroll
-        for (int p = 0; p < NRANGE; ++p) rp[p] += stride * (r32[p] ? 4 : 8);
+        for (int p = 0; p < NRANGE; ++p) {
+            rp[p] += stride * (r32[p] ? 4 : 8);
+            if (rvp[p]) rvp[p] += stride / 64;
+        }
 #pragma unroll
         for (int q = 0; q < NKEY; ++q)
             if (!kutf[q]) kp[q] += stride * 4;
@@ -345,6 +355,14 @@ scan_agg_lean_kernel(const SopProgram* __restrict__ Sp, GroupRec* partials, uint
                         const double a = u2d(((uint64_t)rv[p][u].y << 32) | rv[p][u].x), b = u2d(((uint64_t)rv[p][u].w << 32) | rv[p][u].z);
                         live[2 * u] = live[2 * u] && a >= rlo[p] && a <= rhi[p];
                         live[2 * u + 1] = live[2 * u + 1] && b >= rlo[p] && b <= rhi[p];
+                    }
+                }
+                if (rvp[p]) {           // a NULL fails every comparison
+                    const uint32_t bit = (2u * (uint32_t)tid) & 63u;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        live[2 * u] = live[2 * u] && ((rvw[p][u] >> bit) & 1ull);
+                        live[2 * u + 1] = live[2 * u + 1] && ((rvw[p][u] >> (bit + 1u)) & 1ull);
                     }
                 }
             }
@@ -461,6 +479,8 @@ scan_agg_lean_kernel(const SopProgram* __restrict__ Sp, GroupRec* partials, uint
                         const BHIP_GLOBAL char* base = (const BHIP_GLOBAL char*)S.cols[S.ranges[p].col].data;
                         const double x = r32[p] ? (double)*(const BHIP_GLOBAL int32_t*)(base + i * 4) : *(const BHIP_GLOBAL double*)(base + i * 8);
                         ok = ok && x >= rlo[p] && x <= rhi[p];
+                        const BHIP_GLOBAL uint64_t* vb = (const BHIP_GLOBAL uint64_t*)S.cols[S.ranges[p].col].validity;
+                        if (vb) ok = ok && ((vb[i >> 6] >> (i & 63)) & 1ull);
                     }
 #pragma unroll
                 for (int q = 0; q < NKEY; ++q)

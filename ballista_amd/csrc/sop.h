@@ -24,6 +24,7 @@ constexpr int SOP_NCOL = 16;
 struct SopColumn {
     const void* data;
     const int32_t* offsets;
+    const uint64_t* validity;   // only a column the predicate constrains may carry one (lean_kernel.h, kernels_range.hip)
     int32_t dtype;
     int32_t data_bytes;
 };

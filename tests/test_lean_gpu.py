@@ -171,6 +171,35 @@ def test_borrowed_device_buffers_take_the_other_path(ctx):
     helpers.assert_rows_equal(got, plan_eval.collect(part), ordered=False, float_rtol=RTOL, key_cols=["ks"])
 
 
+@pytest.mark.parametrize("n", [700, 1024, 70_001])
+def test_nulls_in_predicate_columns_stay_on_the_wide_load_kernels(n):
+    """a NULL fails every comparison, so a column the predicate constrains may carry NULLs: the kernels test its
+    validity bitmap (aggregate: lean_kernel.h; filter: kernels_range.hip).  NULLs elsewhere -> the general path."""
+    c = ba.Context(0)
+    rng = np.random.default_rng(n)
+    b = batch(n, 300 + n, vocab=("A", "N", "R"))
+    b["d"] = OCol("Date32", b["d"].values, rng.random(n) > 0.2)            # range only
+    b["y"] = OCol("Float64", b["y"].values, rng.random(n) > 0.3)           # range AND chain input
+    pred = E.coerce((col("d") <= E.date32("1998-09-02")).and_(col("y") <= lit(0.07)).and_(col("q") < lit(45.0)), SCHEMA)
+    g = [(col("ks"), "ks")]
+    src = helpers.memory_exec(c, [[b]])
+    part = ba.HashAggregateExec(ba.plan.PARTIAL, g, AGGS_Q1, ba.FilterExec(pred, src))
+    c.kernel_time(reset=True)
+    got = helpers.concat(helpers.collect_product(part))
+    if n >= 65536:
+        assert c.kernel_time(reset=True)[1] == 1 and c.kernel_name() == "scan_agg_lean_kernel"
+    helpers.assert_rows_equal(got, plan_eval.collect(part), ordered=False, float_rtol=RTOL, key_cols=["ks"])
+    # the same predicate as a standalone filter (row set and order exact)
+    flt = ba.FilterExec(pred, helpers.memory_exec(c, [[b]]))
+    helpers.assert_rows_equal(helpers.concat(helpers.collect_product(flt)), plan_eval.collect(flt), ordered=True)
+    # a NULL in an unconstrained input column: general path, same answer
+    b2 = OrderedDict(b)
+    b2["x"] = OCol("Float64", b["x"].values, rng.random(n) > 0.1)
+    part2 = ba.HashAggregateExec(ba.plan.PARTIAL, g, AGGS_Q1, ba.FilterExec(pred, helpers.memory_exec(c, [[b2]])))
+    helpers.assert_rows_equal(helpers.concat(helpers.collect_product(part2)), plan_eval.collect(part2), ordered=False,
+                              float_rtol=RTOL, key_cols=["ks"])
+
+
 def test_all_valid_bitmaps_are_dropped_at_import_and_take_the_fast_kernels():
     """Arrow producers often attach validity bitmaps with every bit set: such columns are imported without the
     bitmap (the schema stays nullable) and the NULL-free kernels serve them — same answer as the oracle"""
