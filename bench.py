@@ -80,13 +80,14 @@ def pmc_traffic(kernel, rows, query):
     by tools/profile_bench.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 runs of this command).
     FETCH_SIZE is doubled (gfx950 counts wide streaming reads at half, MI355X_MICROARCH.md §HBM).
     None when no pass exists for this kernel and launch size — counters cannot be read from inside."""
-    try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-    except (OSError, ValueError):
-        return None
-    if kernel not in rec.get("kernel", "") or rec.get("rows_per_launch") != rows or rec.get("query", "q1") != query:
-        return None
-    return (2.0 * rec["fetch_size_kb_per_launch"] + rec["write_size_kb_per_launch"]) * 1024.0
+    for name in ("pmc_traffic.json", f"pmc_traffic_{query}.json"):
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except (OSError, ValueError):
+            continue
+        if kernel in rec.get("kernel", "") and rec.get("rows_per_launch") == rows and rec.get("query", "q1") == query:
+            return (2.0 * rec["fetch_size_kb_per_launch"] + rec["write_size_kb_per_launch"]) * 1024.0
+    return None
 
 
 def main():
