@@ -157,3 +157,28 @@ def q5_plan(customer, orders, lineitem, supplier, nation, region) -> P.Execution
     part = P.HashAggregateExec(P.PARTIAL, group, [Sum(revenue, "revenue")], sup)
     fin = P.HashAggregateExec(P.FINAL, group, [E.AggregateExpr("SUM", col("n_name"), "revenue")], P.MergeExec(part))
     return P.SortExec([PhysicalSortExpr(col("revenue"), descending=True)], fin)
+
+
+def q12_plan(orders: P.ExecutionPlan, lineitem: P.ExecutionPlan) -> P.ExecutionPlan:
+    """TPC-H Q12 (rust/benchmarks/tpch/queries/q12.sql): lineitem(IN-list on l_shipmode, two column-vs-column date
+    comparisons, a receipt-date year) |x| orders, GROUP BY l_shipmode with two SUM(CASE WHEN ... THEN 1 ELSE 0 END).
+    The filtered lineitem side is the (small, non-unique) build side, as `FROM lineitem JOIN orders` plans it."""
+    ls, os_ = _schema_of(lineitem), _schema_of(orders)
+    pred = E.InListExpr(col("l_shipmode"), [lit("MAIL"), lit("SHIP")])
+    pred = pred.and_(col("l_commitdate") < col("l_receiptdate")).and_(col("l_shipdate") < col("l_commitdate"))
+    pred = pred.and_(col("l_receiptdate") >= date32("1994-01-01")).and_(col("l_receiptdate") < date32("1995-01-01"))
+    li = P.FilterExec(coerce(pred, ls), lineitem)
+    li = P.ProjectionExec([(col("l_orderkey"), "l_orderkey"), (col("l_shipmode"), "l_shipmode")], li)
+    od = P.ProjectionExec([(col("o_orderkey"), "o_orderkey"), (col("o_orderpriority"), "o_orderpriority")], orders)
+    j = P.HashJoinExec(li, od, [("l_orderkey", "o_orderkey")], P.INNER)
+    sj = _schema_of(j)
+    urgent = col("o_orderpriority").eq(lit("1-URGENT")).or_(col("o_orderpriority").eq(lit("2-HIGH")))
+    other = col("o_orderpriority").ne(lit("1-URGENT")).and_(col("o_orderpriority").ne(lit("2-HIGH")))
+    one, zero = lit(1, E.INT64), lit(0, E.INT64)
+    aggs = [Sum(coerce(E.CaseExpr(None, [(urgent, one)], zero), sj), "high_line_count"),
+            Sum(coerce(E.CaseExpr(None, [(other, one)], zero), sj), "low_line_count")]
+    group = [(col("l_shipmode"), "l_shipmode")]
+    part = P.HashAggregateExec(P.PARTIAL, group, aggs, j)
+    fin = P.HashAggregateExec(P.FINAL, group, [E.AggregateExpr("SUM", col("l_shipmode"), "high_line_count"),
+                                               E.AggregateExpr("SUM", col("l_shipmode"), "low_line_count")], P.MergeExec(part))
+    return P.SortExec([PhysicalSortExpr(col("l_shipmode"))], fin)
