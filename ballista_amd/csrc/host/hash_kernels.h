@@ -49,15 +49,16 @@ hipError_t launch_join_probe_match(const LaunchCfg& cfg, const JoinTable& T, con
                                    uint32_t* matched);
 // one Int32 / Date32 key column, unique build side: key and build row share the slot (kernels_hash.hip)
 struct NarrowJoinTable {
-    uint64_t* slots;          // [capacity] key | (build row + 1) << 32, 0 = empty
+    uint64_t* slots;          // key width 4: [capacity] key | (build row + 1) << 32, 0 = empty
+                              // key width 8: [capacity] {key, build row + 1 (low half of the second word)}, 16 bytes per slot
     uint64_t mask;
     uint32_t* dup_flag;       // set when two build rows share a key: the host falls back to JoinTable
 };
-hipError_t launch_join_build_narrow(const LaunchCfg& cfg, const NarrowJoinTable& T, const uint32_t* keys, const uint64_t* sel,
-                                    uint32_t n_left);
-hipError_t launch_join_probe_match_narrow(const LaunchCfg& cfg, const NarrowJoinTable& T, const uint32_t* rkeys, const uint64_t* rsel,
-                                          uint32_t n_right, bool right_outer, uint32_t* partner, uint64_t* bitmap,
-                                          uint32_t* tile_counts, uint32_t* matched);
+hipError_t launch_join_build_narrow(const LaunchCfg& cfg, const NarrowJoinTable& T, const void* keys, int key_width,
+                                    const uint64_t* sel, uint32_t n_left);
+hipError_t launch_join_probe_match_narrow(const LaunchCfg& cfg, const NarrowJoinTable& T, const void* rkeys, int key_width,
+                                          const uint64_t* rsel, uint32_t n_right, bool right_outer, uint32_t* partner,
+                                          uint64_t* bitmap, uint32_t* tile_counts, uint32_t* matched);
 hipError_t launch_join_unmatched_flags(const LaunchCfg& cfg, const uint32_t* matched, uint32_t n_left, uint32_t* flags);
 hipError_t launch_compact_flags(const LaunchCfg& cfg, const uint32_t* flags, const uint64_t* offsets, uint32_t n, uint32_t* out);
 

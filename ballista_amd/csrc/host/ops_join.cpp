@@ -20,7 +20,8 @@ struct JoinBuildSide {
     JoinTable table;
     bool has_sel = false;
     bool unique = false;            // no two build rows share a key: probe rows have at most one partner
-    bool narrow = false;            // ONE Int32 / Date32 key, unique: NarrowJoinTable instead of JoinTable
+    bool narrow = false;            // ONE integer key, unique: NarrowJoinTable instead of JoinTable
+    int narrow_width = 0;           // its key bytes (4: Int32 / Date32, 8: Int64 / UInt64)
     BufferPtr slots;
     NarrowJoinTable ntable;
 };
@@ -119,13 +120,15 @@ static void side_keys(const Exec& ex, const Batch& b, const std::vector<std::str
     check_scan_status(ex, st);
 }
 
-// ONE key pair, both sides Int32 / Date32 columns
-bool HashJoinExec::narrow_key_types() const {
-    if (on_.size() != 1) return false;
+// ONE key pair of integer columns of the same width on both sides: 4 (Int32 / Date32), 8 (Int64 / UInt64), else 0
+int HashJoinExec::narrow_key_width() const {
+    if (on_.size() != 1) return 0;
     const Schema &ls = *left_->schema(), &rs = *right_->schema();
     const int lt = ls.fields[ls.index_of(on_[0].first)].dtype, rt = rs.fields[rs.index_of(on_[0].second)].dtype;
     auto four = [](int t) { return t == DT_INT32 || t == DT_DATE32; };
-    return four(lt) && four(rt);
+    if (four(lt) && four(rt)) return 4;
+    if (lt == rt && (lt == DT_INT64 || lt == DT_UINT64)) return 8;
+    return 0;
 }
 
 std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) const {
@@ -160,15 +163,18 @@ std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) co
     uint64_t cap = 1024;
     while (cap < 2ull * (uint64_t)n) cap <<= 1;
     static const bool narrow_disabled = [] { const char* v = getenv("BHIP_NO_NARROW_JOIN"); return v && atoi(v) != 0; }();
-    if (!narrow_disabled && narrow_key_types()) {
+    const int nkw = narrow_disabled ? 0 : narrow_key_width();
+    if (nkw) {
         // optimistic: the build side of a key join is almost always unique
         const Column& kc = bs->batch->cols[bs->batch->schema->index_of(lcols[0])];
-        bs->slots = make_buffer(ex, cap * 8);
+        const size_t slot_bytes = nkw == 4 ? 8 : 16;
+        bs->slots = make_buffer(ex, cap * slot_bytes);
         bs->dup = make_buffer(ex, 8);
-        HIP_CHECK(hipMemsetAsync(bs->slots->ptr(), 0, cap * 8, ex.stream));
+        HIP_CHECK(hipMemsetAsync(bs->slots->ptr(), 0, cap * slot_bytes, ex.stream));
         HIP_CHECK(hipMemsetAsync(bs->dup->ptr(), 0, 8, ex.stream));
         bs->ntable = NarrowJoinTable{bs->slots->as<uint64_t>(), cap - 1, bs->dup->as<uint32_t>()};
-        HIP_CHECK(launch_join_build_narrow(ex.cfg(), bs->ntable, kc.data->as<uint32_t>(),
+        bs->narrow_width = nkw;
+        HIP_CHECK(launch_join_build_narrow(ex.cfg(), bs->ntable, kc.data->ptr(), nkw,
                                            kc.validity ? kc.validity->as<uint64_t>() : nullptr, (uint32_t)n));
         if (read_device(ex, bs->dup->as<uint32_t>()) == 0) {
             bs->narrow = bs->unique = true;
@@ -259,7 +265,7 @@ StreamPtr HashJoinExec::execute(int partition, const Exec& ex) const {
                 void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes(n_tiles));
                 if (bs->narrow) {
                     const Column& kc = probe.cols[probe.schema->index_of(rcols[0])];
-                    HIP_CHECK(launch_join_probe_match_narrow(cfg, bs->ntable, kc.data->as<uint32_t>(),
+                    HIP_CHECK(launch_join_probe_match_narrow(cfg, bs->ntable, kc.data->ptr(), bs->narrow_width,
                                                              kc.validity ? kc.validity->as<uint64_t>() : nullptr, (uint32_t)n_right,
                                                              right_outer, partner, bitmap, tile_counts,
                                                              left_outer ? matched->as<uint32_t>() : nullptr));

@@ -223,7 +223,7 @@ private:
     int join_type_;
     SchemaPtr schema_;
     std::vector<int> right_cols_;   // right columns kept in the output
-    bool narrow_key_types() const;
+    int narrow_key_width() const;
     // the build side (hash table over the whole left child) is built once and shared by every
     // partition's task, like DataFusion's collect-left build future
     struct BuildCache { std::mutex mu; std::shared_ptr<const JoinBuildSide> built; };

@@ -269,6 +269,61 @@ join_probe_match_narrow_kernel(NarrowJoinTable T, const uint32_t* rkeys, const u
     }
 }
 
+// ---- the same for ONE Int64 / UInt64 key (TPC-H at SF1000: l_orderkey / o_orderkey are Int64): 16-byte slots
+// {key, build row + 1}.  The build claims a slot with a 32-bit CAS on the row word and compares against the key
+// COLUMN of the claiming row (immutable input), so no reader ever depends on a half-written slot; the key word is
+// stored after the claim and is complete when the build kernel ends.  The probe reads a slot with one 16-byte load.
+struct alignas(16) NarrowSlot64 { uint64_t key; uint32_t row1; uint32_t pad; };
+
+__global__ void __launch_bounds__(BLOCK)
+join_build_narrow64_kernel(NarrowJoinTable T, const uint64_t* keys, const uint64_t* sel, uint32_t n_left) {
+    NarrowSlot64* slots = reinterpret_cast<NarrowSlot64*>(T.slots);
+    for (uint32_t row = blockIdx.x * BLOCK + threadIdx.x; row < n_left; row += gridDim.x * BLOCK) {
+        if (!bit_at(sel, row)) continue;
+        const uint64_t key = keys[row];
+        uint64_t slot = mix64(key) & T.mask;
+        for (;;) {
+            uint32_t r = slots[slot].row1;
+            if (r == 0) {
+                r = atomicCAS(&slots[slot].row1, 0u, row + 1u);
+                if (r == 0) { slots[slot].key = key; break; }      // claimed
+            }
+            if (keys[r - 1u] == key) { *T.dup_flag = 1u; break; }
+            slot = (slot + 1) & T.mask;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK)
+join_probe_match_narrow64_kernel(NarrowJoinTable T, const uint64_t* rkeys, const uint64_t* rsel, uint32_t n_right, int right_outer,
+                                 uint32_t* partner, uint64_t* bitmap, uint32_t* tile_counts, uint32_t* matched) {
+    const ulonglong2* slots = reinterpret_cast<const ulonglong2*>(T.slots);
+    const uint64_t n_round = ((uint64_t)n_right + 63u) & ~(uint64_t)63;
+    for (uint64_t row64 = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; row64 < n_round; row64 += (uint64_t)gridDim.x * BLOCK) {
+        const uint32_t row = (uint32_t)row64;
+        uint32_t m = 0xFFFFFFFFu;
+        const bool in = row64 < n_right;
+        if (in && bit_at(rsel, row)) {
+            const uint64_t key = rkeys[row];
+            uint64_t slot = mix64(key) & T.mask;
+            for (;;) {
+                const ulonglong2 v = slots[slot];                    // {key, row1 | pad << 32}
+                const uint32_t r = (uint32_t)v.y;
+                if (r == 0) break;
+                if (v.x == key) { m = r - 1u; break; }
+                slot = (slot + 1) & T.mask;
+            }
+            if (matched && m != 0xFFFFFFFFu) atomicOr(&matched[m >> 5], 1u << (m & 31));
+        }
+        if (in) partner[row] = m;
+        const uint64_t word = __ballot(in && (right_outer || m != 0xFFFFFFFFu));
+        if ((threadIdx.x & 63) == 0) {
+            bitmap[row64 >> 6] = word;
+            if (word) atomicAdd(&tile_counts[row64 / SEL_TILE], (uint32_t)__popcll(word));
+        }
+    }
+}
+
 __global__ void __launch_bounds__(BLOCK)
 join_unmatched_flags_kernel(const uint32_t* matched, uint32_t n_left, uint32_t* flags) {
     for (uint32_t row = blockIdx.x * BLOCK + threadIdx.x; row < n_left; row += gridDim.x * BLOCK)
@@ -320,21 +375,28 @@ hipError_t launch_join_probe_match(const LaunchCfg& cfg, const JoinTable& T, con
                        n_right, right_outer ? 1 : 0, partner, bitmap, tile_counts, matched);
     return hipGetLastError();
 }
-hipError_t launch_join_build_narrow(const LaunchCfg& cfg, const NarrowJoinTable& T, const uint32_t* keys, const uint64_t* sel,
-                                    uint32_t n_left) {
+hipError_t launch_join_build_narrow(const LaunchCfg& cfg, const NarrowJoinTable& T, const void* keys, int key_width,
+                                    const uint64_t* sel, uint32_t n_left) {
     if (n_left == 0) return hipSuccess;
-    hipLaunchKernelGGL(join_build_narrow_kernel, dim3(grid_rows(cfg, n_left)), dim3(BLOCK), 0, cfg.stream, T, keys, sel, n_left);
+    if (key_width == 4)
+        hipLaunchKernelGGL(join_build_narrow_kernel, dim3(grid_rows(cfg, n_left)), dim3(BLOCK), 0, cfg.stream, T, (const uint32_t*)keys, sel, n_left);
+    else
+        hipLaunchKernelGGL(join_build_narrow64_kernel, dim3(grid_rows(cfg, n_left)), dim3(BLOCK), 0, cfg.stream, T, (const uint64_t*)keys, sel, n_left);
     return hipGetLastError();
 }
-hipError_t launch_join_probe_match_narrow(const LaunchCfg& cfg, const NarrowJoinTable& T, const uint32_t* rkeys, const uint64_t* rsel,
-                                          uint32_t n_right, bool right_outer, uint32_t* partner, uint64_t* bitmap,
-                                          uint32_t* tile_counts, uint32_t* matched) {
+hipError_t launch_join_probe_match_narrow(const LaunchCfg& cfg, const NarrowJoinTable& T, const void* rkeys, int key_width,
+                                          const uint64_t* rsel, uint32_t n_right, bool right_outer, uint32_t* partner,
+                                          uint64_t* bitmap, uint32_t* tile_counts, uint32_t* matched) {
     if (n_right == 0) return hipSuccess;
     const size_t n_tiles = ((size_t)n_right + SEL_TILE - 1) / SEL_TILE;
     hipError_t e = hipMemsetAsync(tile_counts, 0, n_tiles * 4, cfg.stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(join_probe_match_narrow_kernel, dim3(grid_rows(cfg, n_right)), dim3(BLOCK), 0, cfg.stream, T, rkeys, rsel,
-                       n_right, right_outer ? 1 : 0, partner, bitmap, tile_counts, matched);
+    if (key_width == 4)
+        hipLaunchKernelGGL(join_probe_match_narrow_kernel, dim3(grid_rows(cfg, n_right)), dim3(BLOCK), 0, cfg.stream, T,
+                           (const uint32_t*)rkeys, rsel, n_right, right_outer ? 1 : 0, partner, bitmap, tile_counts, matched);
+    else
+        hipLaunchKernelGGL(join_probe_match_narrow64_kernel, dim3(grid_rows(cfg, n_right)), dim3(BLOCK), 0, cfg.stream, T,
+                           (const uint64_t*)rkeys, rsel, n_right, right_outer ? 1 : 0, partner, bitmap, tile_counts, matched);
     return hipGetLastError();
 }
 hipError_t launch_join_unmatched_flags(const LaunchCfg& cfg, const uint32_t* matched, uint32_t n_left, uint32_t* flags) {

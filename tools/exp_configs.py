@@ -57,8 +57,9 @@ sf = float(os.environ.get("Q3_SF", "10"))
 n_li = int(round(6_000_379.02 * sf)) if sf != 100 else 600_037_902
 n_ord, n_cust = int(1_500_000 * sf), int(150_000 * sf)
 t0 = time.perf_counter()
-li = ba.plan.tpch_lineitem(ctx, sf, tpch.SEED, 0, n_li)
-od = ba.plan.tpch_orders(ctx, sf, tpch.SEED, 0, n_ord)
+key64 = os.environ.get("KEY64", "0") == "1"          # Int64 order keys, as TPC-H needs at SF1000
+li = ba.plan.tpch_lineitem(ctx, sf, tpch.SEED, 0, n_li, key64=key64)
+od = ba.plan.tpch_orders(ctx, sf, tpch.SEED, 0, n_ord, key64=key64)
 rng = np.random.default_rng(7)
 segs = np.array(["AUTOMOBILE", "BUILDING", "FURNITURE", "MACHINERY", "HOUSEHOLD"])
 seg_id = rng.integers(0, 5, n_cust)
