@@ -139,37 +139,41 @@ hipError_t exclusive_scan_u32_u32(hipStream_t st, const uint32_t* in, int64_t n,
 // =============================================================================================
 // selection bitmap -> ascending row indices (FilterExec keeps row order)
 // =============================================================================================
+// One wave per 1024-row tile, no LDS, no barrier: lanes 0..15 load the tile's 16 words, a shuffle prefix sum of
+// their popcounts gives each word's first output position, then word by word every lane tests its own bit and
+// writes its row index at (tile offset + word offset + rank among the lower set bits).  All-zero words are skipped.
 __global__ void __launch_bounds__(BLOCK)
 select_indices_kernel(const uint64_t* bitmap, const uint64_t* tile_offsets, int64_t n_rows, uint32_t* indices) {
-    __shared__ uint32_t s_word_off[SEL_TILE / 64 + 1];
-    const int tid = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int64_t n_tiles = (n_rows + SEL_TILE - 1) / SEL_TILE;
-    for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const int64_t n_words = (n_rows + 63) / 64;
+    const int64_t wave_global = (int64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * (BLOCK / 64);
+    for (int64_t t = wave_global; t < n_tiles; t += n_waves) {
         const int64_t base = t * SEL_TILE;
-        const int64_t n_words = (n_rows + 63) / 64;
-        if (tid == 0) {
-            uint32_t run = 0;
-            for (int w = 0; w < SEL_TILE / 64; ++w) {
-                s_word_off[w] = run;
-                const int64_t wi = (base >> 6) + w;
-                run += wi < n_words ? (uint32_t)__popcll(bitmap[wi]) : 0u;
-            }
-        }
-        __syncthreads();
-        const uint64_t out_base = tile_offsets[t];
+        const int64_t wi = (base >> 6) + lane;
+        uint64_t word = (lane < SEL_TILE / 64 && wi < n_words) ? bitmap[wi] : 0ull;
+        // rows beyond n_rows are clear by construction of the producers; mask them anyway
+        if (wi == n_words - 1 && (n_rows & 63)) word &= (1ull << (n_rows & 63)) - 1ull;
+        uint32_t incl = (uint32_t)__popcll(word);
 #pragma unroll
-        for (int r = 0; r < SEL_TILE / BLOCK; ++r) {
-            const int64_t row = base + r * BLOCK + tid;
-            if (row < n_rows) {
-                const uint64_t word = bitmap[row >> 6];
-                const int lane = (int)(row & 63);
-                if ((word >> lane) & 1ull) {
-                    const uint32_t rank = (uint32_t)__popcll(word & ((1ull << lane) - 1ull));
-                    indices[out_base + s_word_off[(row - base) >> 6] + rank] = (uint32_t)row;
-                }
+        for (int d = 1; d < SEL_TILE / 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += up;
+        }
+        const uint32_t excl = incl - (uint32_t)__popcll(word);
+        const uint64_t out_base = tile_offsets[t];
+        const uint32_t lo = (uint32_t)word, hi = (uint32_t)(word >> 32);
+#pragma unroll
+        for (int w = 0; w < SEL_TILE / 64; ++w) {
+            const uint64_t ww = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hi, w) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)lo, w);
+            if (ww == 0) continue;                                   // wave-uniform
+            const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)excl, w);
+            if ((ww >> lane) & 1ull) {
+                const uint32_t rank = (uint32_t)__popcll(ww & ((1ull << lane) - 1ull));
+                indices[out_base + off + rank] = (uint32_t)(base + w * 64 + lane);
             }
         }
-        __syncthreads();
     }
 }
 
