@@ -56,9 +56,11 @@ struct NarrowJoinTable {
 };
 hipError_t launch_join_build_narrow(const LaunchCfg& cfg, const NarrowJoinTable& T, const void* keys, int key_width,
                                     const uint64_t* sel, uint32_t n_left);
+// gather (may be null): probe row i reads key / validity row gather[i] — the probe runs over a selection of the key
+// column without materialising it
 hipError_t launch_join_probe_match_narrow(const LaunchCfg& cfg, const NarrowJoinTable& T, const void* rkeys, int key_width,
-                                          const uint64_t* rsel, uint32_t n_right, bool right_outer, uint32_t* partner,
-                                          uint64_t* bitmap, uint32_t* tile_counts, uint32_t* matched);
+                                          const uint64_t* rsel, const uint32_t* gather, uint32_t n_right, bool right_outer,
+                                          uint32_t* partner, uint64_t* bitmap, uint32_t* tile_counts, uint32_t* matched);
 hipError_t launch_join_unmatched_flags(const LaunchCfg& cfg, const uint32_t* matched, uint32_t n_left, uint32_t* flags);
 hipError_t launch_compact_flags(const LaunchCfg& cfg, const uint32_t* flags, const uint64_t* offsets, uint32_t n, uint32_t* out);
 

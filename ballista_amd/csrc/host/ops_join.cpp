@@ -244,8 +244,10 @@ StreamPtr HashJoinExec::execute(int partition, const Exec& ex) const {
 
         // probe: `probe` holds the key columns of the probe rows; output columns are gathered from `outsrc`, whose
         // row of probe row i is remap[i] (nullptr: the same row)
-        auto process = [&](const Batch& probe, const Batch* outsrc, const uint32_t* remap) {
-            const int64_t n_right = probe.n_rows;
+        // keysrc (narrow tables only): the UNFILTERED key column, read through `remap` by the probe itself
+        auto process = [&](const Batch& probe, const Batch* outsrc, const uint32_t* remap, const Column* keysrc = nullptr,
+                           int64_t n_probe = -1) {
+            const int64_t n_right = keysrc ? n_probe : probe.n_rows;
             if (n_right == 0) return;
             BufferPtr rkeys, rsel;
             bool has_rsel = false;
@@ -264,9 +266,10 @@ StreamPtr HashJoinExec::execute(int partition, const Exec& ex) const {
                 uint64_t* tile_off = tmp.get<uint64_t>((size_t)n_tiles + 1);
                 void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes(n_tiles));
                 if (bs->narrow) {
-                    const Column& kc = probe.cols[probe.schema->index_of(rcols[0])];
+                    const Column& kc = keysrc ? *keysrc : probe.cols[probe.schema->index_of(rcols[0])];
                     HIP_CHECK(launch_join_probe_match_narrow(cfg, bs->ntable, kc.data->ptr(), bs->narrow_width,
-                                                             kc.validity ? kc.validity->as<uint64_t>() : nullptr, (uint32_t)n_right,
+                                                             kc.validity ? kc.validity->as<uint64_t>() : nullptr,
+                                                             keysrc ? remap : nullptr, (uint32_t)n_right,
                                                              right_outer, partner, bitmap, tile_counts,
                                                              left_outer ? matched->as<uint32_t>() : nullptr));
                 } else
@@ -331,16 +334,20 @@ StreamPtr HashJoinExec::execute(int partition, const Exec& ex) const {
                 BufferPtr sel;
                 const int64_t n_sel = filter_indices(ex, *b, flt->predicate(), sel);
                 if (n_sel == 0) continue;
-                auto kb = std::make_shared<Batch>();
-                kb->schema = key_schema;
-                kb->ctx = b->ctx;
-                kb->n_rows = n_sel;
-                for (int ci : key_src) kb->cols.push_back(take_batch_column(ex, b->cols[ci], sel->as<uint32_t>(), n_sel));
                 Batch pv;                                  // the projection's view of the unfiltered batch
                 pv.schema = out_schema;
                 pv.ctx = b->ctx;
                 pv.n_rows = b->n_rows;
                 for (int ci : src_of) pv.cols.push_back(b->cols[ci]);
+                if (bs->narrow) {                          // the probe reads the key column through the selection
+                    process(pv, &pv, sel->as<uint32_t>(), &b->cols[key_src[0]], n_sel);
+                    continue;
+                }
+                auto kb = std::make_shared<Batch>();
+                kb->schema = key_schema;
+                kb->ctx = b->ctx;
+                kb->n_rows = n_sel;
+                for (int ci : key_src) kb->cols.push_back(take_batch_column(ex, b->cols[ci], sel->as<uint32_t>(), n_sel));
                 process(*kb, &pv, sel->as<uint32_t>());
             }
         } else {

@@ -242,15 +242,17 @@ join_build_narrow_kernel(NarrowJoinTable T, const uint32_t* keys, const uint64_t
 }
 
 __global__ void __launch_bounds__(BLOCK)
-join_probe_match_narrow_kernel(NarrowJoinTable T, const uint32_t* rkeys, const uint64_t* rsel, uint32_t n_right, int right_outer,
-                               uint32_t* partner, uint64_t* bitmap, uint32_t* tile_counts, uint32_t* matched) {
+join_probe_match_narrow_kernel(NarrowJoinTable T, const uint32_t* rkeys, const uint64_t* rsel, const uint32_t* gather,
+                               uint32_t n_right, int right_outer, uint32_t* partner, uint64_t* bitmap, uint32_t* tile_counts,
+                               uint32_t* matched) {
     const uint64_t n_round = ((uint64_t)n_right + 63u) & ~(uint64_t)63;
     for (uint64_t row64 = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; row64 < n_round; row64 += (uint64_t)gridDim.x * BLOCK) {
         const uint32_t row = (uint32_t)row64;
         uint32_t m = 0xFFFFFFFFu;
         const bool in = row64 < n_right;
-        if (in && bit_at(rsel, row)) {
-            const uint32_t key = rkeys[row];
+        const uint32_t src = (in && gather) ? gather[row] : row;      // probe row -> row of the (unfiltered) key column
+        if (in && bit_at(rsel, src)) {
+            const uint32_t key = rkeys[src];
             uint64_t slot = narrow_hash(key) & T.mask;
             for (;;) {
                 const uint64_t v = T.slots[slot];
@@ -295,16 +297,18 @@ join_build_narrow64_kernel(NarrowJoinTable T, const uint64_t* keys, const uint64
 }
 
 __global__ void __launch_bounds__(BLOCK)
-join_probe_match_narrow64_kernel(NarrowJoinTable T, const uint64_t* rkeys, const uint64_t* rsel, uint32_t n_right, int right_outer,
-                                 uint32_t* partner, uint64_t* bitmap, uint32_t* tile_counts, uint32_t* matched) {
+join_probe_match_narrow64_kernel(NarrowJoinTable T, const uint64_t* rkeys, const uint64_t* rsel, const uint32_t* gather,
+                                 uint32_t n_right, int right_outer, uint32_t* partner, uint64_t* bitmap, uint32_t* tile_counts,
+                                 uint32_t* matched) {
     const ulonglong2* slots = reinterpret_cast<const ulonglong2*>(T.slots);
     const uint64_t n_round = ((uint64_t)n_right + 63u) & ~(uint64_t)63;
     for (uint64_t row64 = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; row64 < n_round; row64 += (uint64_t)gridDim.x * BLOCK) {
         const uint32_t row = (uint32_t)row64;
         uint32_t m = 0xFFFFFFFFu;
         const bool in = row64 < n_right;
-        if (in && bit_at(rsel, row)) {
-            const uint64_t key = rkeys[row];
+        const uint32_t src = (in && gather) ? gather[row] : row;
+        if (in && bit_at(rsel, src)) {
+            const uint64_t key = rkeys[src];
             uint64_t slot = mix64(key) & T.mask;
             for (;;) {
                 const ulonglong2 v = slots[slot];                    // {key, row1 | pad << 32}
@@ -385,18 +389,18 @@ hipError_t launch_join_build_narrow(const LaunchCfg& cfg, const NarrowJoinTable&
     return hipGetLastError();
 }
 hipError_t launch_join_probe_match_narrow(const LaunchCfg& cfg, const NarrowJoinTable& T, const void* rkeys, int key_width,
-                                          const uint64_t* rsel, uint32_t n_right, bool right_outer, uint32_t* partner,
-                                          uint64_t* bitmap, uint32_t* tile_counts, uint32_t* matched) {
+                                          const uint64_t* rsel, const uint32_t* gather, uint32_t n_right, bool right_outer,
+                                          uint32_t* partner, uint64_t* bitmap, uint32_t* tile_counts, uint32_t* matched) {
     if (n_right == 0) return hipSuccess;
     const size_t n_tiles = ((size_t)n_right + SEL_TILE - 1) / SEL_TILE;
     hipError_t e = hipMemsetAsync(tile_counts, 0, n_tiles * 4, cfg.stream);
     if (e != hipSuccess) return e;
     if (key_width == 4)
         hipLaunchKernelGGL(join_probe_match_narrow_kernel, dim3(grid_rows(cfg, n_right)), dim3(BLOCK), 0, cfg.stream, T,
-                           (const uint32_t*)rkeys, rsel, n_right, right_outer ? 1 : 0, partner, bitmap, tile_counts, matched);
+                           (const uint32_t*)rkeys, rsel, gather, n_right, right_outer ? 1 : 0, partner, bitmap, tile_counts, matched);
     else
         hipLaunchKernelGGL(join_probe_match_narrow64_kernel, dim3(grid_rows(cfg, n_right)), dim3(BLOCK), 0, cfg.stream, T,
-                           (const uint64_t*)rkeys, rsel, n_right, right_outer ? 1 : 0, partner, bitmap, tile_counts, matched);
+                           (const uint64_t*)rkeys, rsel, gather, n_right, right_outer ? 1 : 0, partner, bitmap, tile_counts, matched);
     return hipGetLastError();
 }
 hipError_t launch_join_unmatched_flags(const LaunchCfg& cfg, const uint32_t* matched, uint32_t n_left, uint32_t* flags) {
