@@ -74,6 +74,7 @@ SYMBOLS = {
     "bhip_ctx_kernel_name": (C.c_char_p, [_P]),
     "bhip_batch_from_host": (C.c_int32, [_P, C.c_int32, C.POINTER(ColumnDesc), C.c_int64, _PP]),
     "bhip_batch_from_device": (C.c_int32, [_P, C.c_int32, C.POINTER(ColumnDesc), C.c_int64, _PP]),
+    "bhip_batch_from_tbl": (C.c_int32, [_P, _P, C.c_int64, C.c_int32, C.POINTER(ColumnDesc), C.c_int32, C.POINTER(C.c_int32), _PP]),
     "bhip_batch_import_arrow": (C.c_int32, [_P, _P, _P, _PP]),
     "bhip_batch_export_arrow": (C.c_int32, [_P, _P, _P]),
     "bhip_batch_retain": (None, [_P]),

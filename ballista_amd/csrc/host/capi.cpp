@@ -105,6 +105,14 @@ bhip_status bhip_batch_from_device(bhip_ctx* ctx, int32_t n_cols, const bhip_col
     BHIP_API_END
 }
 
+bhip_status bhip_batch_from_tbl(bhip_ctx* ctx, const void* text, int64_t n_bytes, int32_t n_fields, const bhip_column_desc* fields,
+                                int32_t n_projection, const int32_t* projection, bhip_batch** out) {
+    BHIP_API_BEGIN
+    need(ctx, "ctx"); need(out, "out"); need(fields, "fields");
+    *out = wrap_batch(batch_from_tbl(ctx->p, text, n_bytes, n_fields, fields, n_projection, projection));
+    BHIP_API_END
+}
+
 void bhip_batch_retain(bhip_batch* b) { if (b) b->rc.fetch_add(1); }
 void bhip_batch_release(bhip_batch* b) {
     if (b && b->rc.fetch_sub(1) == 1) delete b;

@@ -186,6 +186,9 @@ using BatchPtr = std::shared_ptr<const Batch>;
 // host <-> device movement
 BatchPtr batch_from_host(const ContextPtr& ctx, int n_cols, const bhip_column_desc* cols, int64_t n_rows, bool device_ptrs);
 void column_to_host(const Batch& b, int i, void* data, int32_t* offsets, uint8_t* validity);
+// '|'-separated TPC-H text (host memory) -> device batch of the projected fields (tbl.cpp, kernels_tbl.hip)
+BatchPtr batch_from_tbl(const ContextPtr& ctx, const void* text_host, int64_t n_bytes, int n_fields, const bhip_column_desc* fields,
+                        int n_proj, const int32_t* projection);
 
 // whole-batch operations (ops_basic.cpp)
 // permutation: `indices` holds every input row exactly once (Utf8 value bytes are then known without a read-back)

@@ -1,0 +1,207 @@
+// kernels_tbl.hip — TPC-H `.tbl` text (dbgen: '|'-separated fields, '|' before the newline) -> Arrow columns on the
+// device.  Stands where the reference's scan leaf stands: CsvExec with delimiter '|', no header, explicit schema
+// (rust/benchmarks/tpch/src/main.rs:129-150, schemas :267-360; rust/core/src/serde/physical_plan/from_proto.rs:93-110).
+// with `--format tbl` the CPU spends its time here, upstream of every operator.
+//
+// Byte work, three passes over the text:
+//   1. newlines per 16 KiB chunk                          (count)  -> exclusive scan
+//   2. start offset of every line                          (stable ranks inside a chunk: thread-local counts + LDS scan)
+//   3. one thread per line walks its fields; projected fields are converted in place:
+//        Int32 / Int64   [-]digits
+//        Float64         [-]digits[.digits]  =  M / 10^k with M < 2^53 and k <= 22: both exact in double, so the one
+//                        division is the correctly rounded value of the decimal text (what str::parse::<f64> returns)
+//        Date32          YYYY-MM-DD -> days since 1970-01-01 (proleptic Gregorian)
+//        Utf8            (offset, length) of the field; a second pass copies the bytes behind an exclusive scan
+// Anything else in the text (exponents, > 15 significant digits, missing fields, blank lines) raises a flag and the
+// host reports BHIP_EEXEC / BHIP_ENOTIMPL: the caller keeps its CPU reader for that file.
+#include <hip/hip_runtime.h>
+#include "kernels.h"
+#include "tbl_kernels.h"
+#include "vm_device.h"
+#include "vm_isa.h"
+
+namespace bhip {
+
+constexpr int TBL_THREAD_BYTES = TBL_CHUNK / BLOCK;      // 64 bytes per thread and chunk
+
+__global__ void __launch_bounds__(BLOCK)
+tbl_count_kernel(const uint8_t* text, int64_t n_bytes, uint32_t* chunk_lines) {
+    __shared__ uint32_t s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * TBL_CHUNK + (int64_t)threadIdx.x * TBL_THREAD_BYTES;
+    uint32_t c = 0;
+    for (int b = 0; b < TBL_THREAD_BYTES; ++b) {
+        const int64_t p = base + b;
+        if (p < n_bytes && text[p] == '\n') ++c;
+    }
+    if (c) atomicAdd(&s_cnt, c);
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_lines[blockIdx.x] = s_cnt;
+}
+
+// starts[i] = offset of the first byte of line i (starts[0] = 0 is written by the host side of the launcher)
+__global__ void __launch_bounds__(BLOCK)
+tbl_starts_kernel(const uint8_t* text, int64_t n_bytes, const uint64_t* chunk_base, uint64_t* starts) {
+    __shared__ uint32_t s_scan[BLOCK];
+    const int tid = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * TBL_CHUNK + (int64_t)tid * TBL_THREAD_BYTES;
+    uint32_t c = 0;
+    for (int b = 0; b < TBL_THREAD_BYTES; ++b) {
+        const int64_t p = base + b;
+        if (p < n_bytes && text[p] == '\n') ++c;
+    }
+    s_scan[tid] = c;
+    __syncthreads();
+    for (int d = 1; d < BLOCK; d <<= 1) {                 // inclusive Hillis-Steele scan of the thread counts
+        const uint32_t v = tid >= d ? s_scan[tid - d] : 0;
+        __syncthreads();
+        s_scan[tid] += v;
+        __syncthreads();
+    }
+    uint64_t rank = chunk_base[blockIdx.x] + (s_scan[tid] - c);
+    for (int b = 0; b < TBL_THREAD_BYTES; ++b) {
+        const int64_t p = base + b;
+        if (p < n_bytes && text[p] == '\n') starts[++rank] = (uint64_t)p + 1;
+    }
+}
+
+__device__ inline int64_t days_from_civil(int64_t y, unsigned m, unsigned d) {
+    y -= m <= 2;
+    const int64_t era = (y >= 0 ? y : y - 399) / 400;
+    const unsigned yoe = (unsigned)(y - era * 400);
+    const unsigned doy = (153 * (m + (m > 2 ? -3 : 9)) + 2) / 5 + d - 1;
+    const unsigned doe = yoe * 365 + yoe / 4 - yoe / 100 + doy;
+    return era * 146097 + (int64_t)doe - 719468;
+}
+
+__constant__ double TBL_POW10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15,
+                                     1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+
+__global__ void __launch_bounds__(BLOCK)
+tbl_parse_kernel(const uint8_t* text, const uint64_t* starts, int64_t n_lines, TblPlan plan, uint32_t* flags) {
+    uint32_t err = 0;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n_lines; i += (int64_t)gridDim.x * BLOCK) {
+        int64_t p = (int64_t)starts[i];
+        int64_t e = (int64_t)starts[i + 1] - 1;              // the newline (or one past the text for an unterminated last line)
+        if (e > p && text[e - 1] == '\r') --e;
+        if (e <= p) { err |= TBL_ERR_BLANK_LINE; continue; }
+        for (int f = 0; f < plan.n_fields; ++f) {
+            if (p > e) { err |= TBL_ERR_MISSING_FIELD; break; }
+            int64_t q = p;
+            while (q < e && text[q] != '|') ++q;              // field = [p, q)
+            const int out = plan.out[f];
+            if (out >= 0) {
+                const int dt = plan.dtype[f];
+                if (dt == DT_UTF8) {
+                    plan.str_start[out][i] = (uint32_t)p;
+                    plan.str_len[out][i] = (uint32_t)(q - p);
+                } else if (dt == DT_DATE32) {
+                    // YYYY-MM-DD
+                    bool ok = (q - p) == 10 && text[p + 4] == '-' && text[p + 7] == '-';
+                    int v[8];
+                    const int pos[8] = {0, 1, 2, 3, 5, 6, 8, 9};
+                    for (int k = 0; k < 8 && ok; ++k) {
+                        const int c = (int)text[p + pos[k]] - '0';
+                        ok = c >= 0 && c <= 9;
+                        v[k] = c;
+                    }
+                    int32_t days = 0;
+                    if (ok) {
+                        const int y = v[0] * 1000 + v[1] * 100 + v[2] * 10 + v[3], m = v[4] * 10 + v[5], d = v[6] * 10 + v[7];
+                        ok = m >= 1 && m <= 12 && d >= 1 && d <= 31;
+                        days = (int32_t)days_from_civil(y, (unsigned)m, (unsigned)d);
+                    }
+                    if (!ok) err |= TBL_ERR_BAD_VALUE;
+                    reinterpret_cast<int32_t*>(plan.data[out])[i] = days;
+                } else {
+                    int64_t r = p;
+                    bool neg = false;
+                    if (r < q && (text[r] == '-' || text[r] == '+')) { neg = text[r] == '-'; ++r; }
+                    uint64_t m = 0;
+                    int digits = 0, frac = 0;
+                    bool seen_dot = false, ok = r < q;
+                    for (; r < q; ++r) {
+                        const uint8_t ch = text[r];
+                        if (ch >= '0' && ch <= '9') {
+                            if (digits >= 19) {                                  // 19 digits still fit 64 bits
+                                if (dt == DT_FLOAT64) { err |= TBL_ERR_PRECISION; m = 0; frac = 0; r = q; break; }
+                                ok = false;
+                                break;
+                            }
+                            m = m * 10 + (uint64_t)(ch - '0');
+                            if (m != 0 || seen_dot) ++digits;             // leading zeros of the integer part are free
+                            if (seen_dot) ++frac;
+                        } else if (ch == '.' && !seen_dot && dt == DT_FLOAT64) {
+                            seen_dot = true;
+                        } else { ok = false; break; }
+                    }
+                    if (dt == DT_FLOAT64) {
+                        if (!ok) err |= TBL_ERR_BAD_VALUE;
+                        else if (m >= (1ull << 53) || frac > 22) { err |= TBL_ERR_PRECISION; ok = false; }
+                        double v = ok ? (double)m / TBL_POW10[frac] : 0.0;
+                        reinterpret_cast<double*>(plan.data[out])[i] = neg ? -v : v;
+                    } else {
+                        if (!ok || seen_dot) err |= TBL_ERR_BAD_VALUE;
+                        if (m > (neg ? (1ull << 63) : (1ull << 63) - 1ull)) err |= TBL_ERR_BAD_VALUE;      // beyond Int64
+                        const int64_t v = neg ? (int64_t)(0ull - m) : (int64_t)m;
+                        if (dt == DT_INT32) {
+                            if (v > 2147483647ll || v < -2147483648ll) err |= TBL_ERR_BAD_VALUE;
+                            reinterpret_cast<int32_t*>(plan.data[out])[i] = (int32_t)v;
+                        } else {
+                            reinterpret_cast<int64_t*>(plan.data[out])[i] = v;
+                        }
+                    }
+                }
+            }
+            p = q + 1;
+        }
+    }
+    if (err) atomicOr(flags, err);
+}
+
+__global__ void __launch_bounds__(BLOCK)
+tbl_copy_strings_kernel(const uint8_t* text, const uint32_t* str_start, const uint32_t* str_len, const int32_t* offsets, int64_t n,
+                        uint8_t* out) {
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+        const uint8_t* s = text + str_start[i];
+        uint8_t* d = out + offsets[i];
+        const uint32_t len = str_len[i];
+        for (uint32_t b = 0; b < len; ++b) d[b] = s[b];
+    }
+}
+
+static int grid_rows(const LaunchCfg& cfg, int64_t n) {
+    int64_t g = (n + BLOCK - 1) / BLOCK;
+    const int64_t cap = (int64_t)cfg.device_cus * 16;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+hipError_t launch_tbl_count(const LaunchCfg& cfg, const uint8_t* text, int64_t n_bytes, uint32_t* chunk_lines) {
+    const int64_t n_chunks = (n_bytes + TBL_CHUNK - 1) / TBL_CHUNK;
+    if (n_chunks == 0) return hipSuccess;
+    hipLaunchKernelGGL(tbl_count_kernel, dim3((unsigned)n_chunks), dim3(BLOCK), 0, cfg.stream, text, n_bytes, chunk_lines);
+    return hipGetLastError();
+}
+hipError_t launch_tbl_starts(const LaunchCfg& cfg, const uint8_t* text, int64_t n_bytes, const uint64_t* chunk_base, uint64_t* starts) {
+    const int64_t n_chunks = (n_bytes + TBL_CHUNK - 1) / TBL_CHUNK;
+    if (n_chunks == 0) return hipSuccess;
+    hipLaunchKernelGGL(tbl_starts_kernel, dim3((unsigned)n_chunks), dim3(BLOCK), 0, cfg.stream, text, n_bytes, chunk_base, starts);
+    return hipGetLastError();
+}
+hipError_t launch_tbl_parse(const LaunchCfg& cfg, const uint8_t* text, const uint64_t* starts, int64_t n_lines, const TblPlan& plan,
+                            uint32_t* flags) {
+    if (n_lines == 0) return hipSuccess;
+    hipLaunchKernelGGL(tbl_parse_kernel, dim3(grid_rows(cfg, n_lines)), dim3(BLOCK), 0, cfg.stream, text, starts, n_lines, plan, flags);
+    return hipGetLastError();
+}
+hipError_t launch_tbl_copy_strings(const LaunchCfg& cfg, const uint8_t* text, const uint32_t* str_start, const uint32_t* str_len,
+                                   const int32_t* offsets, int64_t n, uint8_t* out) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(tbl_copy_strings_kernel, dim3(grid_rows(cfg, n)), dim3(BLOCK), 0, cfg.stream, text, str_start, str_len, offsets, n, out);
+    return hipGetLastError();
+}
+
+}  // namespace bhip

@@ -289,6 +289,35 @@ class RecordBatch:
         return rb
 
     @staticmethod
+    def from_tbl(ctx: Context, text, schema, columns=None) -> "RecordBatch":
+        """bhip_batch_from_tbl: TPC-H `.tbl` text ('|'-separated, bytes or a path) parsed on the device — the scan
+        leaf the reference builds as CsvExec(delimiter '|', no header, schema)
+        (rust/benchmarks/tpch/src/main.rs:129-150).  schema: [(name, dtype)] of the file's fields in order;
+        columns: names to materialise, in output order (None: all)."""
+        if isinstance(text, str):
+            with open(text, "rb") as f:
+                text = f.read()
+        text = bytes(text)
+        descs, keep = [], []
+        for name, dtype in schema:
+            d = L.ColumnDesc()
+            nb = name.encode()
+            keep.append(nb)
+            d.name, d.dtype, d.nullable = nb, DTYPE_ID[dtype], 0
+            descs.append(d)
+        arr = (L.ColumnDesc * max(1, len(descs)))(*descs)
+        proj, n_proj = None, 0
+        if columns is not None:
+            names = [n for n, _ in schema]
+            idx = [names.index(c) for c in columns]
+            proj = (C.c_int32 * max(1, len(idx)))(*idx)
+            n_proj = len(idx)
+        buf = C.create_string_buffer(text, len(text)) if text else None
+        h = C.c_void_p()
+        L.check(L.lib().bhip_batch_from_tbl(ctx._h, buf, len(text), len(descs), arr, n_proj, proj, C.byref(h)))
+        return RecordBatch(h, ctx)
+
+    @staticmethod
     def from_device_pointers(ctx: Context, columns, n_rows: int, keep=None) -> "RecordBatch":
         """bhip_batch_from_device over caller-owned device memory: columns = [(name, dtype, data_ptr)], fixed-width
         NULL-free columns (e.g. buffers an RCCL collective has just filled).  `keep`: whatever owns the memory."""

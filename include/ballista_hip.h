@@ -131,6 +131,16 @@ bhip_status bhip_batch_from_host(bhip_ctx* ctx, int32_t n_cols, const bhip_colum
                                  bhip_batch** out);
 bhip_status bhip_batch_from_device(bhip_ctx* ctx, int32_t n_cols, const bhip_column_desc* cols, int64_t n_rows,
                                    bhip_batch** out);
+/* Scan leaf for TPC-H `.tbl` text — where the reference has CsvExec(delimiter '|', no header, explicit schema):
+ * rust/benchmarks/tpch/src/main.rs:129-150, rust/core/src/serde/physical_plan/from_proto.rs:93-110.
+ * `text` (host memory, < 4 GiB, whole lines) is copied to the device once; lines, fields and values are found
+ * there.  fields[i].name / .dtype / .nullable describe the file's fields in order (data pointers unused);
+ * `projection` = indices of the fields to materialise, in output order (NULL: all).  Int32, Int64, Float64
+ * ([-]digits[.digits], converted exactly), Date32 (YYYY-MM-DD) and Utf8 columns.  Malformed text -> BHIP_EEXEC;
+ * decimals beyond 15 significant digits or other column types -> BHIP_ENOTIMPL (keep the CPU reader). */
+bhip_status bhip_batch_from_tbl(bhip_ctx* ctx, const void* text, int64_t n_bytes, int32_t n_fields,
+                                const bhip_column_desc* fields, int32_t n_projection, const int32_t* projection,
+                                bhip_batch** out);
 /* Arrow C Data Interface: `array` is a struct array (one child per column) as produced by
  * RecordBatch export; it is consumed (released) on success. */
 bhip_status bhip_batch_import_arrow(bhip_ctx* ctx, struct ArrowArray* array, struct ArrowSchema* schema,
