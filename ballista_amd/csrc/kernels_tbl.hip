@@ -24,33 +24,68 @@ namespace bhip {
 
 constexpr int TBL_THREAD_BYTES = TBL_CHUNK / BLOCK;      // 64 bytes per thread and chunk
 
+// newlines among the four bytes of `w` (byte by byte: the subtract-and-mask zero-byte trick can flag a 0x0B byte that
+// sits right above a newline, and these counts must equal the line count exactly)
+__device__ inline uint32_t newlines_exact(uint32_t w) {
+    uint32_t c = 0;
+    c += (w & 0xFFu) == 0x0Au;
+    c += ((w >> 8) & 0xFFu) == 0x0Au;
+    c += ((w >> 16) & 0xFFu) == 0x0Au;
+    c += (w >> 24) == 0x0Au;
+    return c;
+}
+
+// pass 1: newlines per chunk.  Lanes read adjacent 16-byte pieces (coalesced), order does not matter for a count.
 __global__ void __launch_bounds__(BLOCK)
 tbl_count_kernel(const uint8_t* text, int64_t n_bytes, uint32_t* chunk_lines) {
     __shared__ uint32_t s_cnt;
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * TBL_CHUNK + (int64_t)threadIdx.x * TBL_THREAD_BYTES;
+    const int64_t chunk0 = (int64_t)blockIdx.x * TBL_CHUNK;
     uint32_t c = 0;
-    for (int b = 0; b < TBL_THREAD_BYTES; ++b) {
-        const int64_t p = base + b;
-        if (p < n_bytes && text[p] == '\n') ++c;
+#pragma unroll
+    for (int k = 0; k < TBL_CHUNK / (BLOCK * 16); ++k) {
+        const int64_t p = chunk0 + ((int64_t)k * BLOCK + threadIdx.x) * 16;
+        if (p + 16 <= n_bytes) {
+            const uint4 v = *reinterpret_cast<const uint4*>(text + p);            // text is 256-byte aligned, p a multiple of 16
+            c += newlines_exact(v.x) + newlines_exact(v.y) + newlines_exact(v.z) + newlines_exact(v.w);
+        } else {
+            for (int64_t q = p; q < n_bytes && q < p + 16; ++q) c += text[q] == '\n';
+        }
     }
     if (c) atomicAdd(&s_cnt, c);
     __syncthreads();
     if (threadIdx.x == 0) chunk_lines[blockIdx.x] = s_cnt;
 }
 
-// starts[i] = offset of the first byte of line i (starts[0] = 0 is written by the host side of the launcher)
+// pass 2: starts[i] = offset of the first byte of line i (starts[0] = 0 is written by the host).  The chunk is staged
+// in LDS with coalesced 16-byte loads; each thread then owns 64 CONSECUTIVE bytes (rows of 16 dwords padded to 17,
+// so the 64 lanes of a wave read 64 different banks), which keeps the newline ranks in text order.
 __global__ void __launch_bounds__(BLOCK)
 tbl_starts_kernel(const uint8_t* text, int64_t n_bytes, const uint64_t* chunk_base, uint64_t* starts) {
+    __shared__ uint32_t s_text[BLOCK * 17];
     __shared__ uint32_t s_scan[BLOCK];
     const int tid = threadIdx.x;
-    const int64_t base = (int64_t)blockIdx.x * TBL_CHUNK + (int64_t)tid * TBL_THREAD_BYTES;
-    uint32_t c = 0;
-    for (int b = 0; b < TBL_THREAD_BYTES; ++b) {
-        const int64_t p = base + b;
-        if (p < n_bytes && text[p] == '\n') ++c;
+    const int64_t chunk0 = (int64_t)blockIdx.x * TBL_CHUNK;
+#pragma unroll
+    for (int k = 0; k < TBL_CHUNK / (BLOCK * 16); ++k) {
+        const int piece = k * BLOCK + tid;                       // 16-byte piece of the chunk
+        const int64_t p = chunk0 + (int64_t)piece * 16;
+        uint4 v = make_uint4(0, 0, 0, 0);                        // bytes past the text read as 0: never a newline
+        if (p + 16 <= n_bytes) v = *reinterpret_cast<const uint4*>(text + p);
+        else {
+            uint32_t w[4] = {0, 0, 0, 0};
+            for (int64_t q = p; q < n_bytes && q < p + 16; ++q) w[(q - p) >> 2] |= (uint32_t)text[q] << (8 * ((q - p) & 3));
+            v = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        const int row = piece >> 2, col = (piece & 3) * 4;       // row = owning thread (64 bytes = 4 pieces)
+        s_text[row * 17 + col + 0] = v.x; s_text[row * 17 + col + 1] = v.y;
+        s_text[row * 17 + col + 2] = v.z; s_text[row * 17 + col + 3] = v.w;
     }
+    __syncthreads();
+    uint32_t c = 0;
+#pragma unroll
+    for (int d = 0; d < 16; ++d) c += newlines_exact(s_text[tid * 17 + d]);
     s_scan[tid] = c;
     __syncthreads();
     for (int d = 1; d < BLOCK; d <<= 1) {                 // inclusive Hillis-Steele scan of the thread counts
@@ -59,10 +94,14 @@ tbl_starts_kernel(const uint8_t* text, int64_t n_bytes, const uint64_t* chunk_ba
         s_scan[tid] += v;
         __syncthreads();
     }
+    if (c == 0) return;
     uint64_t rank = chunk_base[blockIdx.x] + (s_scan[tid] - c);
-    for (int b = 0; b < TBL_THREAD_BYTES; ++b) {
-        const int64_t p = base + b;
-        if (p < n_bytes && text[p] == '\n') starts[++rank] = (uint64_t)p + 1;
+    const int64_t base = chunk0 + (int64_t)tid * TBL_THREAD_BYTES;
+    for (int d = 0; d < 16; ++d) {
+        const uint32_t w = s_text[tid * 17 + d];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            if (((w >> (8 * b)) & 0xFFu) == 0x0Au) starts[++rank] = (uint64_t)(base + d * 4 + b) + 1;
     }
 }
 

@@ -312,9 +312,10 @@ class RecordBatch:
             idx = [names.index(c) for c in columns]
             proj = (C.c_int32 * max(1, len(idx)))(*idx)
             n_proj = len(idx)
-        buf = C.create_string_buffer(text, len(text)) if text else None
         h = C.c_void_p()
-        L.check(L.lib().bhip_batch_from_tbl(ctx._h, buf, len(text), len(descs), arr, n_proj, proj, C.byref(h)))
+        # the bytes object itself is the text buffer (no copy on the Python side)
+        L.check(L.lib().bhip_batch_from_tbl(ctx._h, C.c_char_p(text) if text else None, len(text), len(descs), arr, n_proj, proj,
+                                            C.byref(h)))
         return RecordBatch(h, ctx)
 
     @staticmethod
