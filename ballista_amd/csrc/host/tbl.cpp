@@ -104,7 +104,7 @@ BatchPtr batch_from_tbl(const ContextPtr& ctx, const void* text_host, int64_t n_
         }
         batch->cols.push_back(std::move(c));
     }
-    HIP_CHECK(launch_tbl_parse(cfg, text, starts, n_lines, plan, flags));
+    HIP_CHECK(launch_tbl_parse(cfg, text, starts, n_lines, n_bytes, plan, flags));
 
     // ---- strings: lengths -> offsets -> bytes; all totals in one read-back
     uint64_t* totals = tmp.get<uint64_t>(proj.size() + 1);

@@ -117,84 +117,128 @@ __device__ inline int64_t days_from_civil(int64_t y, unsigned m, unsigned d) {
 __constant__ double TBL_POW10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15,
                                      1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
 
-__global__ void __launch_bounds__(BLOCK)
-tbl_parse_kernel(const uint8_t* text, const uint64_t* starts, int64_t n_lines, TblPlan plan, uint32_t* flags) {
+// byte sources of the field walk: the text in HBM, or the lines of one workgroup staged in LDS
+struct TblGlobalReader {
+    const uint8_t* text;
+    __device__ uint8_t operator()(int64_t pos) const { return text[pos]; }
+};
+struct TblLdsReader {
+    const uint8_t* buf;          // LDS copy of text[origin, origin + ...)
+    int64_t origin;
+    __device__ uint8_t operator()(int64_t pos) const { return buf[pos - origin]; }
+};
+
+// one line [p, e): walk the fields, convert the projected ones.  Returns the error flags.
+template <class R>
+__device__ inline uint32_t tbl_parse_line(const R& rd, int64_t p, int64_t e, int64_t i, const TblPlan& plan) {
     uint32_t err = 0;
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n_lines; i += (int64_t)gridDim.x * BLOCK) {
-        int64_t p = (int64_t)starts[i];
-        int64_t e = (int64_t)starts[i + 1] - 1;              // the newline (or one past the text for an unterminated last line)
-        if (e > p && text[e - 1] == '\r') --e;
-        if (e <= p) { err |= TBL_ERR_BLANK_LINE; continue; }
-        for (int f = 0; f < plan.n_fields; ++f) {
-            if (p > e) { err |= TBL_ERR_MISSING_FIELD; break; }
-            int64_t q = p;
-            while (q < e && text[q] != '|') ++q;              // field = [p, q)
-            const int out = plan.out[f];
-            if (out >= 0) {
-                const int dt = plan.dtype[f];
-                if (dt == DT_UTF8) {
-                    plan.str_start[out][i] = (uint32_t)p;
-                    plan.str_len[out][i] = (uint32_t)(q - p);
-                } else if (dt == DT_DATE32) {
-                    // YYYY-MM-DD
-                    bool ok = (q - p) == 10 && text[p + 4] == '-' && text[p + 7] == '-';
-                    int v[8];
-                    const int pos[8] = {0, 1, 2, 3, 5, 6, 8, 9};
-                    for (int k = 0; k < 8 && ok; ++k) {
-                        const int c = (int)text[p + pos[k]] - '0';
-                        ok = c >= 0 && c <= 9;
-                        v[k] = c;
-                    }
-                    int32_t days = 0;
-                    if (ok) {
-                        const int y = v[0] * 1000 + v[1] * 100 + v[2] * 10 + v[3], m = v[4] * 10 + v[5], d = v[6] * 10 + v[7];
-                        ok = m >= 1 && m <= 12 && d >= 1 && d <= 31;
-                        days = (int32_t)days_from_civil(y, (unsigned)m, (unsigned)d);
-                    }
-                    if (!ok) err |= TBL_ERR_BAD_VALUE;
-                    reinterpret_cast<int32_t*>(plan.data[out])[i] = days;
-                } else {
-                    int64_t r = p;
-                    bool neg = false;
-                    if (r < q && (text[r] == '-' || text[r] == '+')) { neg = text[r] == '-'; ++r; }
-                    uint64_t m = 0;
-                    int digits = 0, frac = 0;
-                    bool seen_dot = false, ok = r < q;
-                    for (; r < q; ++r) {
-                        const uint8_t ch = text[r];
-                        if (ch >= '0' && ch <= '9') {
-                            if (digits >= 19) {                                  // 19 digits still fit 64 bits
-                                if (dt == DT_FLOAT64) { err |= TBL_ERR_PRECISION; m = 0; frac = 0; r = q; break; }
-                                ok = false;
-                                break;
-                            }
-                            m = m * 10 + (uint64_t)(ch - '0');
-                            if (m != 0 || seen_dot) ++digits;             // leading zeros of the integer part are free
-                            if (seen_dot) ++frac;
-                        } else if (ch == '.' && !seen_dot && dt == DT_FLOAT64) {
-                            seen_dot = true;
-                        } else { ok = false; break; }
-                    }
-                    if (dt == DT_FLOAT64) {
-                        if (!ok) err |= TBL_ERR_BAD_VALUE;
-                        else if (m >= (1ull << 53) || frac > 22) { err |= TBL_ERR_PRECISION; ok = false; }
-                        double v = ok ? (double)m / TBL_POW10[frac] : 0.0;
-                        reinterpret_cast<double*>(plan.data[out])[i] = neg ? -v : v;
-                    } else {
-                        if (!ok || seen_dot) err |= TBL_ERR_BAD_VALUE;
-                        if (m > (neg ? (1ull << 63) : (1ull << 63) - 1ull)) err |= TBL_ERR_BAD_VALUE;      // beyond Int64
-                        const int64_t v = neg ? (int64_t)(0ull - m) : (int64_t)m;
-                        if (dt == DT_INT32) {
-                            if (v > 2147483647ll || v < -2147483648ll) err |= TBL_ERR_BAD_VALUE;
-                            reinterpret_cast<int32_t*>(plan.data[out])[i] = (int32_t)v;
-                        } else {
-                            reinterpret_cast<int64_t*>(plan.data[out])[i] = v;
+    if (e > p && rd(e - 1) == '\r') --e;
+    if (e <= p) return TBL_ERR_BLANK_LINE;
+    for (int f = 0; f < plan.n_fields; ++f) {
+        if (p > e) { err |= TBL_ERR_MISSING_FIELD; break; }
+        int64_t q = p;
+        while (q < e && rd(q) != '|') ++q;              // field = [p, q)
+        const int out = plan.out[f];
+        if (out >= 0) {
+            const int dt = plan.dtype[f];
+            if (dt == DT_UTF8) {
+                plan.str_start[out][i] = (uint32_t)p;
+                plan.str_len[out][i] = (uint32_t)(q - p);
+            } else if (dt == DT_DATE32) {
+                // YYYY-MM-DD
+                bool ok = (q - p) == 10 && rd(p + 4) == '-' && rd(p + 7) == '-';
+                int v[8];
+                const int pos[8] = {0, 1, 2, 3, 5, 6, 8, 9};
+                for (int k = 0; k < 8 && ok; ++k) {
+                    const int c = (int)rd(p + pos[k]) - '0';
+                    ok = c >= 0 && c <= 9;
+                    v[k] = c;
+                }
+                int32_t days = 0;
+                if (ok) {
+                    const int y = v[0] * 1000 + v[1] * 100 + v[2] * 10 + v[3], m = v[4] * 10 + v[5], d = v[6] * 10 + v[7];
+                    ok = m >= 1 && m <= 12 && d >= 1 && d <= 31;
+                    days = (int32_t)days_from_civil(y, (unsigned)m, (unsigned)d);
+                }
+                if (!ok) err |= TBL_ERR_BAD_VALUE;
+                reinterpret_cast<int32_t*>(plan.data[out])[i] = days;
+            } else {
+                int64_t r = p;
+                bool neg = false;
+                if (r < q && (rd(r) == '-' || rd(r) == '+')) { neg = rd(r) == '-'; ++r; }
+                uint64_t m = 0;
+                int digits = 0, frac = 0;
+                bool seen_dot = false, ok = r < q;
+                for (; r < q; ++r) {
+                    const uint8_t ch = rd(r);
+                    if (ch >= '0' && ch <= '9') {
+                        if (digits >= 19) {                                  // 19 digits still fit 64 bits
+                            if (dt == DT_FLOAT64) { err |= TBL_ERR_PRECISION; m = 0; frac = 0; r = q; break; }
+                            ok = false;
+                            break;
                         }
+                        m = m * 10 + (uint64_t)(ch - '0');
+                        if (m != 0 || seen_dot) ++digits;             // leading zeros of the integer part are free
+                        if (seen_dot) ++frac;
+                    } else if (ch == '.' && !seen_dot && dt == DT_FLOAT64) {
+                        seen_dot = true;
+                    } else { ok = false; break; }
+                }
+                if (dt == DT_FLOAT64) {
+                    if (!ok) err |= TBL_ERR_BAD_VALUE;
+                    else if (m >= (1ull << 53) || frac > 22) { err |= TBL_ERR_PRECISION; ok = false; }
+                    double v = ok ? (double)m / TBL_POW10[frac] : 0.0;
+                    reinterpret_cast<double*>(plan.data[out])[i] = neg ? -v : v;
+                } else {
+                    if (!ok || seen_dot) err |= TBL_ERR_BAD_VALUE;
+                    if (m > (neg ? (1ull << 63) : (1ull << 63) - 1ull)) err |= TBL_ERR_BAD_VALUE;      // beyond Int64
+                    const int64_t v = neg ? (int64_t)(0ull - m) : (int64_t)m;
+                    if (dt == DT_INT32) {
+                        if (v > 2147483647ll || v < -2147483648ll) err |= TBL_ERR_BAD_VALUE;
+                        reinterpret_cast<int32_t*>(plan.data[out])[i] = (int32_t)v;
+                    } else {
+                        reinterpret_cast<int64_t*>(plan.data[out])[i] = v;
                     }
                 }
             }
-            p = q + 1;
         }
+        p = q + 1;
+    }
+    return err;
+}
+
+// pass 3: a workgroup takes 256 consecutive lines.  Their text is one contiguous span: it is staged in LDS with
+// coalesced 16-byte loads (a thread walking its line byte by byte in HBM issues one dependent load per byte), and
+// every thread then walks its own line in LDS.  A span that does not fit (very long lines) is walked in HBM.
+constexpr int TBL_STAGE = 48 * 1024;
+__global__ void __launch_bounds__(BLOCK)
+tbl_parse_kernel(const uint8_t* text, const uint64_t* starts, int64_t n_lines, int64_t n_bytes, TblPlan plan, uint32_t* flags) {
+    __shared__ __align__(16) uint8_t s_buf[TBL_STAGE];
+    uint32_t err = 0;
+    const int tid = threadIdx.x;
+    for (int64_t i0 = (int64_t)blockIdx.x * BLOCK; i0 < n_lines; i0 += (int64_t)gridDim.x * BLOCK) {
+        const int64_t n_here = n_lines - i0 < BLOCK ? n_lines - i0 : BLOCK;
+        const int64_t span0 = (int64_t)starts[i0] & ~(int64_t)15;                 // 16-byte aligned (the text buffer is)
+        int64_t span1 = (int64_t)starts[i0 + n_here];
+        if (span1 > n_bytes) span1 = n_bytes;
+        const bool staged = span1 - span0 <= TBL_STAGE - 16;       // the copy below moves whole 16-byte pieces
+        if (staged) {
+            for (int64_t k = (int64_t)tid * 16; k < span1 - span0; k += BLOCK * 16) {
+                const int64_t g = span0 + k;
+                if (g + 16 <= n_bytes) *reinterpret_cast<uint4*>(s_buf + k) = *reinterpret_cast<const uint4*>(text + g);
+                else
+                    for (int64_t b = g; b < n_bytes; ++b) s_buf[b - span0] = text[b];
+            }
+        }
+        __syncthreads();
+        if (tid < n_here) {
+            const int64_t i = i0 + tid;
+            const int64_t p = (int64_t)starts[i];
+            const int64_t e = (int64_t)starts[i + 1] - 1;       // the newline (or one past the text for an unterminated last line)
+            if (staged) err |= tbl_parse_line(TblLdsReader{s_buf, span0}, p, e, i, plan);
+            else err |= tbl_parse_line(TblGlobalReader{text}, p, e, i, plan);
+        }
+        __syncthreads();
     }
     if (err) atomicOr(flags, err);
 }
@@ -230,10 +274,11 @@ hipError_t launch_tbl_starts(const LaunchCfg& cfg, const uint8_t* text, int64_t 
     hipLaunchKernelGGL(tbl_starts_kernel, dim3((unsigned)n_chunks), dim3(BLOCK), 0, cfg.stream, text, n_bytes, chunk_base, starts);
     return hipGetLastError();
 }
-hipError_t launch_tbl_parse(const LaunchCfg& cfg, const uint8_t* text, const uint64_t* starts, int64_t n_lines, const TblPlan& plan,
-                            uint32_t* flags) {
+hipError_t launch_tbl_parse(const LaunchCfg& cfg, const uint8_t* text, const uint64_t* starts, int64_t n_lines, int64_t n_bytes,
+                            const TblPlan& plan, uint32_t* flags) {
     if (n_lines == 0) return hipSuccess;
-    hipLaunchKernelGGL(tbl_parse_kernel, dim3(grid_rows(cfg, n_lines)), dim3(BLOCK), 0, cfg.stream, text, starts, n_lines, plan, flags);
+    hipLaunchKernelGGL(tbl_parse_kernel, dim3(grid_rows(cfg, n_lines)), dim3(BLOCK), 0, cfg.stream, text, starts, n_lines, n_bytes, plan,
+                       flags);
     return hipGetLastError();
 }
 hipError_t launch_tbl_copy_strings(const LaunchCfg& cfg, const uint8_t* text, const uint32_t* str_start, const uint32_t* str_len,

@@ -28,8 +28,8 @@ struct TblPlan {
 
 hipError_t launch_tbl_count(const LaunchCfg& cfg, const uint8_t* text, int64_t n_bytes, uint32_t* chunk_lines);
 hipError_t launch_tbl_starts(const LaunchCfg& cfg, const uint8_t* text, int64_t n_bytes, const uint64_t* chunk_base, uint64_t* starts);
-hipError_t launch_tbl_parse(const LaunchCfg& cfg, const uint8_t* text, const uint64_t* starts, int64_t n_lines, const TblPlan& plan,
-                            uint32_t* flags);
+hipError_t launch_tbl_parse(const LaunchCfg& cfg, const uint8_t* text, const uint64_t* starts, int64_t n_lines, int64_t n_bytes,
+                            const TblPlan& plan, uint32_t* flags);
 hipError_t launch_tbl_copy_strings(const LaunchCfg& cfg, const uint8_t* text, const uint32_t* str_start, const uint32_t* str_len,
                                    const int32_t* offsets, int64_t n, uint8_t* out);
 
