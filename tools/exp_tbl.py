@@ -25,3 +25,17 @@ for name, cols in (("q1 projection (7 of 16 fields)", list(tpch.LINEITEM_SCHEMA)
         dt = time.perf_counter() - t0
     print(json.dumps(dict(scan=name, text_mb=len(text) / 2 ** 20, rows=rb.num_rows, ms=dt * 1e3, text_gbs=len(text) / dt / 1e9,
                           rows_per_s=rb.num_rows / dt)), flush=True)
+
+# ---- end to end: text in host memory -> scan (Q1 projection) -> Q1 plan, at the size of an SF1 lineitem.tbl (~724 MB)
+sf1 = unit * (724 * (1 << 20) // len(unit))
+cols = list(tpch.LINEITEM_SCHEMA)
+for it in range(3):
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    rb = ba.RecordBatch.from_tbl(ctx, sf1, LINEITEM, cols)
+    t1 = time.perf_counter()
+    res = tpch.q1_plan(ba.MemoryExec([[rb]], ctx)).collect()
+    ctx.synchronize()
+    t2 = time.perf_counter()
+print(json.dumps(dict(run="Q1 from .tbl text in host memory", text_mb=len(sf1) / 2 ** 20, rows=rb.num_rows, scan_ms=(t1 - t0) * 1e3,
+                      q1_ms=(t2 - t1) * 1e3, total_ms=(t2 - t0) * 1e3, groups=res[0].num_rows)), flush=True)
