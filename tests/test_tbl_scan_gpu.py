@@ -96,6 +96,21 @@ def test_generated_text_with_awkward_values(ctx):
     check(ctx, text.replace(b"\n", b"\r\n"), schema, ["f", "c", "e"])    # CRLF line ends
 
 
+def test_long_lines_walk_the_text_in_hbm(ctx):
+    """256 lines of ~300 bytes do not fit the 48 KB LDS stage of a workgroup: that tile is walked in HBM instead;
+    short and long tiles alternate here"""
+    rng = np.random.default_rng(5)
+    lines = []
+    for i in range(3000):
+        long_tile = (i // 256) % 2 == 1
+        s = "".join(chr(int(c)) for c in rng.integers(97, 123, int(rng.integers(250, 400)) if long_tile else int(rng.integers(0, 20))))
+        lines.append(f"{i}|{s}|{i * 0.25:.2f}|{s[::-1][:7]}|")
+    text = ("\n".join(lines) + "\n").encode()
+    schema = [("a", E.INT32), ("s", E.UTF8), ("x", E.FLOAT64), ("t", E.UTF8)]
+    check(ctx, text, schema)
+    check(ctx, text, schema, ["x", "t"])
+
+
 def test_empty_and_single_line(ctx):
     schema = [("a", E.INT32), ("s", E.UTF8)]
     rb = ba.RecordBatch.from_tbl(ctx, b"", schema)
