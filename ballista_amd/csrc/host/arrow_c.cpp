@@ -259,6 +259,11 @@ bhip_status bhip_batch_import_arrow(bhip_ctx* ctx, struct ArrowArray* array, str
             const int dt = dtype_from_format(cs->format);
             if (!dt) fail(BHIP_ENOTIMPL, std::string("unsupported Arrow type '") + cs->format + "' for column " + (cs->name ? cs->name : ""));
             if (ca->dictionary) fail(BHIP_ENOTIMPL, "dictionary arrays are not supported");
+            // the array must have the buffers its declared format implies (a producer whose batches do not match
+            // the stream's schema would otherwise be read out of bounds)
+            const int64_t need_buffers = dt == DT_UTF8 ? 3 : 2;
+            if (ca->n_buffers < need_buffers || ca->length != n_rows)
+                fail(BHIP_EINVAL, std::string("Arrow array of column ") + (cs->name ? cs->name : "") + " does not match its schema");
             const int64_t off = ca->offset + array->offset;
             bhip_column_desc& d = descs[i];
             memset(&d, 0, sizeof(d));
@@ -298,6 +303,98 @@ bhip_status bhip_batch_import_arrow(bhip_ctx* ctx, struct ArrowArray* array, str
         h->p = nb;
         *out = h;
         if (array->release) array->release(array);
+        return BHIP_OK;
+    } catch (const bhip::Error& e) { set_last_error(e.what()); return e.code; }
+    catch (const std::exception& e) { set_last_error(e.what()); return BHIP_EINVAL; }
+}
+
+}  // extern "C"
+
+namespace {
+
+// Leaf over a host-side Arrow C stream (the C image of a DataFusion child operator's RecordBatchStream): the stream
+// is drained on the first execute, each batch imported to the device; later executes replay the device batches.
+class ArrowStreamExec : public bhip::ExecutionPlan {
+public:
+    ArrowStreamExec(bhip::ContextPtr ctx, ArrowArrayStream* stream, bhip::SchemaPtr schema) : schema_(std::move(schema)) {
+        ctx_ = std::move(ctx);
+        own_.p = ctx_;                  // a context handle of its own for the batch import
+        stream_ = *stream;              // the stream is moved into the plan (C stream interface ownership)
+        stream->release = nullptr;
+    }
+    ~ArrowStreamExec() override {
+        if (stream_.release) stream_.release(&stream_);
+    }
+    const char* name() const override { return "ArrowStreamExec"; }
+    bhip::SchemaPtr schema() const override { return schema_; }
+    bhip::Partitioning output_partitioning() const override { return bhip::Partitioning{BHIP_PART_UNKNOWN, 1, {}}; }
+    std::vector<bhip::PlanPtr> children() const override { return {}; }
+    bhip::PlanPtr with_new_children(const std::vector<bhip::PlanPtr>& c) const override {
+        if (!c.empty()) fail(BHIP_EINVAL, "ArrowStreamExec has no children");
+        return shared_from_this();
+    }
+    std::string describe() const override { return "ArrowStreamExec"; }
+    bhip::StreamPtr execute(int partition, const bhip::Exec&) const override {
+        if (partition != 0) fail(BHIP_EINVAL, "ArrowStreamExec invalid partition " + std::to_string(partition));
+        std::lock_guard<std::mutex> g(mu_);
+        if (!drained_) {
+            for (;;) {
+                ArrowArray arr;
+                memset(&arr, 0, sizeof(arr));
+                if (stream_.get_next(&stream_, &arr) != 0) {
+                    const char* m = stream_.get_last_error ? stream_.get_last_error(&stream_) : nullptr;
+                    fail(BHIP_EEXEC, std::string("Arrow stream: ") + (m ? m : "get_next failed"));
+                }
+                if (!arr.release) break;                       // end of stream
+                ArrowSchema sch;
+                memset(&sch, 0, sizeof(sch));
+                if (stream_.get_schema(&stream_, &sch) != 0) { arr.release(&arr); fail(BHIP_EEXEC, "Arrow stream: get_schema failed"); }
+                bhip_batch* b = nullptr;
+                const bhip_status st = bhip_batch_import_arrow(&own_, &arr, &sch, &b);
+                if (sch.release) sch.release(&sch);
+                if (st != BHIP_OK) { if (arr.release) arr.release(&arr); fail(st, bhip_last_error()); }
+                batches_.push_back(b->p);
+                bhip_batch_release(b);
+            }
+            drained_ = true;
+            stream_.release(&stream_);                         // the producer is done with: let it go now
+            stream_.release = nullptr;
+        }
+        return bhip::StreamPtr(new bhip::VecStream(schema_, batches_));
+    }
+private:
+    mutable bhip_ctx own_;
+    bhip::SchemaPtr schema_;
+    mutable ArrowArrayStream stream_;
+    mutable std::mutex mu_;
+    mutable bool drained_ = false;
+    mutable std::vector<bhip::BatchPtr> batches_;
+};
+
+}  // namespace
+
+extern "C" {
+
+bhip_status bhip_plan_arrow_stream(bhip_ctx* ctx, struct ArrowArrayStream* stream, bhip_plan** out) {
+    try {
+        if (!ctx || !stream || !out || !stream->get_schema) fail(BHIP_EINVAL, "null argument");
+        ArrowSchema sch;
+        memset(&sch, 0, sizeof(sch));
+        if (stream->get_schema(stream, &sch) != 0) fail(BHIP_EEXEC, "Arrow stream: get_schema failed");
+        auto schema = std::make_shared<bhip::Schema>();
+        std::string err;
+        if (!sch.format || strcmp(sch.format, "+s") != 0) err = "expected a struct schema (RecordBatch stream)";
+        for (int64_t i = 0; err.empty() && i < sch.n_children; ++i) {
+            const ArrowSchema* cs = sch.children[i];
+            const int dt = dtype_from_format(cs->format);
+            if (!dt) err = std::string("unsupported Arrow type '") + cs->format + "' for column " + (cs->name ? cs->name : "");
+            else schema->fields.push_back(bhip::Field{cs->name ? cs->name : "", dt, (cs->flags & ARROW_FLAG_NULLABLE) != 0});
+        }
+        if (sch.release) sch.release(&sch);
+        if (!err.empty()) fail(strncmp(err.c_str(), "unsupported", 11) == 0 ? BHIP_ENOTIMPL : BHIP_EINVAL, err);
+        auto* h = new bhip_plan();
+        h->p = std::make_shared<ArrowStreamExec>(ctx->p, stream, schema);
+        *out = h;
         return BHIP_OK;
     } catch (const bhip::Error& e) { set_last_error(e.what()); return e.code; }
     catch (const std::exception& e) { set_last_error(e.what()); return BHIP_EINVAL; }

@@ -569,6 +569,23 @@ class MemoryExec(ExecutionPlan):
         self.partitions = [list(p) for p in partitions]
 
 
+class ArrowStreamExec(ExecutionPlan):
+    """bhip_plan_arrow_stream: leaf over a host-side Arrow C stream (e.g. a pyarrow.RecordBatchReader) — the C image
+    of a CPU child operator's RecordBatchStream (rust/core/src/memory_stream.rs:57-92).  The stream is moved into the
+    plan, drained on the first execute and replayed afterwards; one output partition."""
+
+    def __init__(self, reader, ctx: Context):
+        c_stream = _ArrowArrayStream()
+        reader._export_to_c(C.addressof(c_stream))
+        h = C.c_void_p()
+        try:
+            L.check(L.lib().bhip_plan_arrow_stream(ctx._h, C.addressof(c_stream), C.byref(h)))
+        finally:
+            if c_stream.release:                       # not taken over (an error): release our export
+                C.CFUNCTYPE(None, C.c_void_p)(c_stream.release)(C.addressof(c_stream))
+        super().__init__(h, ctx)
+
+
 class FilterExec(ExecutionPlan):
     """FilterExec::try_new(predicate, input)  (from_proto.rs:81-92)"""
 

@@ -229,6 +229,10 @@ typedef enum {                                                                /*
 bhip_status bhip_plan_memory(bhip_ctx* ctx, int32_t n_partitions, const int32_t* offsets, bhip_batch* const* batches,
                              bhip_plan** out);
 /* EmptyExec :287-290 — schema given as column descs with NULL data */
+/* leaf over a host-side Arrow C stream — the C image of a CPU child operator's RecordBatchStream
+ * (rust/core/src/memory_stream.rs:57-92): the stream is MOVED into the plan, drained on the first execute (each batch
+ * imported to the device) and replayed on later executes.  One output partition. */
+bhip_status bhip_plan_arrow_stream(bhip_ctx* ctx, struct ArrowArrayStream* stream, bhip_plan** out);
 bhip_status bhip_plan_empty(bhip_ctx* ctx, int32_t n_cols, const bhip_column_desc* schema, int32_t produce_one_row,
                             bhip_plan** out);
 bhip_status bhip_plan_filter(bhip_plan* input, const bhip_expr* predicate, bhip_plan** out);          /* :81-92  */

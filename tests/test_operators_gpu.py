@@ -387,3 +387,36 @@ def test_full_q1_plan_sorted(ctx):
     plan = tpch.q1_plan(helpers.memory_exec(ctx, parts))
     got = run_both(plan, ordered=True, float_rtol=1e-6)
     assert list(zip(got["l_returnflag"].values, got["l_linestatus"].values)) == [("A", "F"), ("N", "F"), ("N", "O"), ("R", "F")]
+
+
+def test_arrow_stream_leaf(ctx):
+    """bhip_plan_arrow_stream: a pyarrow RecordBatchReader (Arrow C stream) as the input of GPU operators"""
+    import pyarrow as pa
+    rng = np.random.default_rng(17)
+    batches = []
+    for n in (1000, 1, 2500):
+        batches.append(pa.RecordBatch.from_arrays(
+            [pa.array(rng.integers(0, 5, n).astype(np.int32)), pa.array([None if i % 5 == 0 else float(v) for i, v in enumerate(rng.random(n))], type=pa.float64()),
+             pa.array([None if i % 7 == 0 else f"s{i % 3}" for i in range(n)], type=pa.string())], names=["k", "x", "s"]))
+    schema = batches[0].schema
+    leaf = ba.ArrowStreamExec(pa.RecordBatchReader.from_batches(schema, batches), ctx)
+    assert [(n, t) for n, t, _ in leaf.schema()] == [("k", "Int32"), ("x", "Float64"), ("s", "Utf8")]
+    assert leaf.output_partitioning().partition_count() == 1
+    plan = ba.HashAggregateExec(ba.plan.PARTIAL, [(col("k"), "k")], [E.Sum(col("x"), "sx"), E.Count(col("x"), "cx")],
+                                ba.FilterExec(E.IsNotNullExpr(col("s")), leaf))
+    for _ in range(2):                                     # the second execute replays the drained stream
+        got = helpers.concat(helpers.collect_product(plan))
+        t = pa.Table.from_batches(batches)
+        tab = t.filter(__import__("pyarrow.compute").compute.is_valid(t["s"])).group_by("k").aggregate([("x", "sum"), ("x", "count")]).sort_by("k").to_pydict()
+        order = np.argsort(got["k"].values)
+        assert [int(got["k"].values[i]) for i in order] == tab["k"]
+        assert [int(got["cx[count]"].values[i]) for i in order] == tab["x_count"]
+        assert np.allclose([got["sx[sum]"].values[i] for i in order], tab["x_sum"], rtol=1e-12)
+    # a producer whose batch does not match the stream's schema is reported, not read out of bounds
+    liar = pa.RecordBatch.from_arrays([pa.array([1], type=pa.int32()), pa.array([None]), pa.array([None])], names=["k", "x", "s"])
+    with pytest.raises(ba.BallistaError):
+        ba.ArrowStreamExec(pa.RecordBatchReader.from_batches(schema, [batches[0], liar]), ctx).collect()
+    # an unsupported column type is refused at plan time
+    bad = pa.RecordBatchReader.from_batches(pa.schema([("f", pa.float32())]), [])
+    with pytest.raises(ba.NotImplementedOnGpu):
+        ba.ArrowStreamExec(bad, ctx)
