@@ -272,9 +272,25 @@ std::vector<BatchPtr> HashAggregateExec::run(int partition, const Exec& ex) cons
                 } break;
                 case BHIP_AGG_COUNT: {
                     if (lit_nonnull || !expr_nullable(arg, src_schema)) { emit(EMIT_ROWS, 0, 0, DT_UINT64); break; }
-                    Operand x = pb.compile(arg);
-                    if (x.is_utf8_col) fail(BHIP_ENOTIMPL, "COUNT over a nullable Utf8 column");
-                    const int acc = add_acc(x.vclass == VC_BOOL ? ACC_COUNT_VALID_B : ACC_COUNT_VALID, arg);
+                    ExprPtr carg = arg;
+                    if (t == DT_UTF8) {
+                        // COUNT(s) counts the non-NULL strings: count CASE WHEN s IS NOT NULL THEN 1 END instead,
+                        // an Int64 value with the same validity (the VM keeps no per-row Utf8 values)
+                        auto nn = std::make_shared<Expr>();
+                        nn->kind = BHIP_EXPR_IS_NOT_NULL;
+                        nn->args = {arg};
+                        auto one = std::make_shared<Expr>();
+                        one->kind = BHIP_EXPR_LITERAL;
+                        one->dtype = DT_INT64;
+                        one->i64 = 1;
+                        auto cs = std::make_shared<Expr>();
+                        cs->kind = BHIP_EXPR_CASE;
+                        cs->args = {ExprPtr(nn), ExprPtr(one)};
+                        carg = cs;
+                    }
+                    Operand x = pb.compile(carg);
+                    if (x.is_utf8_col) fail(BHIP_ENOTIMPL, "COUNT over a Utf8-valued expression");
+                    const int acc = add_acc(x.vclass == VC_BOOL ? ACC_COUNT_VALID_B : ACC_COUNT_VALID, carg);
                     emit(EMIT_RAW, acc, 0, DT_UINT64);
                 } break;
                 default: {

@@ -420,3 +420,16 @@ def test_arrow_stream_leaf(ctx):
     bad = pa.RecordBatchReader.from_batches(pa.schema([("f", pa.float32())]), [])
     with pytest.raises(ba.NotImplementedOnGpu):
         ba.ArrowStreamExec(bad, ctx)
+
+
+@pytest.mark.parametrize("grouped", [False, True])
+def test_count_of_a_nullable_utf8_column(ctx, grouped):
+    """COUNT(s) = number of non-NULL strings (compiled as COUNT(CASE WHEN s IS NOT NULL THEN 1 END))"""
+    b = random_batch(5000, seed=77, long_strings=False)
+    m = helpers.memory_exec(ctx, [[helpers.slice_batch(b, 0, 3000)], [helpers.slice_batch(b, 3000, 5000)]])
+    group = [(col("i32"), "i32")] if grouped else []
+    aggs = [E.Count(col("s"), "cs"), E.Count(lit(1, E.UINT8), "n"), E.Sum(col("g"), "sg")]
+    part = ba.HashAggregateExec(ba.plan.PARTIAL, group, aggs, m)
+    fin = ba.HashAggregateExec(ba.plan.FINAL, group, aggs, ba.MergeExec(part))
+    got = run_both(fin, ordered=False, float_rtol=1e-9, key_cols=[n for _, n in group])
+    assert sum(int(v) for v in got["cs"].values) == int(np.sum(b["s"].valid))
