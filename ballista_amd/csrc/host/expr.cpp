@@ -436,12 +436,17 @@ Operand ProgramBuilder::to_bool(const Operand& o) {
 }
 
 static bool classify_like(const std::string& pat, int& kind, std::string& needle) {
-    // supported shapes: literal, lit%, %lit, %lit%  (no '_' and no inner '%')
-    if (pat.find('_') != std::string::npos) return false;
+    // fast shapes: literal, lit%, %lit, %lit%; anything with '_' or an inner '%' runs the general matcher on the whole
+    // pattern (at most 255 bytes: the instruction carries the length in one byte)
     const bool lead = !pat.empty() && pat.front() == '%';
     const bool trail = pat.size() > (lead ? 1u : 0u) && pat.back() == '%';
     needle = pat.substr(lead ? 1 : 0, pat.size() - (lead ? 1 : 0) - (trail ? 1 : 0));
-    if (needle.find('%') != std::string::npos) return false;
+    if (pat.find('_') != std::string::npos || needle.find('%') != std::string::npos) {
+        if (pat.size() > 255) return false;
+        kind = LIKE_GENERAL;
+        needle = pat;
+        return true;
+    }
     if (pat == "%") { kind = LIKE_PREFIX; needle = ""; return true; }
     kind = lead && trail ? LIKE_CONTAINS : (lead ? LIKE_SUFFIX : (trail ? LIKE_PREFIX : LIKE_EXACT));
     return true;

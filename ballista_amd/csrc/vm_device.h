@@ -211,8 +211,32 @@ __device__ inline bool cmp3_to_bool(int c, int kind) {
     }
 }
 
+// general LIKE: '%' = any sequence of characters, '_' = exactly one (UTF-8) character; iterative matching with one
+// backtrack point (the last '%'), which is complete for this pattern language
+template <class PA, class PB>
+__device__ inline bool str_like_general(PA s, int len, PB p, int plen) {
+    int si = 0, pi = 0, star_p = -1, star_s = 0;
+    while (si < len) {
+        if (pi < plen && p[pi] == '%') { star_p = ++pi; star_s = si; continue; }
+        if (pi < plen && p[pi] == '_') {
+            ++pi; ++si;
+            while (si < len && (s[si] & 0xC0) == 0x80) ++si;                  // the rest of a multi-byte character
+            continue;
+        }
+        if (pi < plen && p[pi] == s[si]) { ++pi; ++si; continue; }
+        if (star_p < 0) return false;
+        pi = star_p;                                                        // let the last '%' take one more character
+        ++star_s;
+        while (star_s < len && (s[star_s] & 0xC0) == 0x80) ++star_s;
+        si = star_s;
+    }
+    while (pi < plen && p[pi] == '%') ++pi;
+    return pi == plen;
+}
+
 template <class PA, class PB>
 __device__ inline bool str_like(PA s, int len, PB p, int plen, int kind) {
+    if (kind == LIKE_GENERAL) return str_like_general(s, len, p, plen);
     if (kind == LIKE_EXACT) return len == plen && str_cmp3(s, len, p, plen) == 0;
     if (len < plen) return false;
     if (kind == LIKE_PREFIX) return str_cmp3(s, plen, p, plen) == 0;

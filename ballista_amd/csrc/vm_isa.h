@@ -59,7 +59,7 @@ enum MathFn : uint8_t {
 };
 
 // LIKE pattern shapes the device handles (anything else -> BHIP_ENOTIMPL at compile time)
-enum LikeKind : uint8_t { LIKE_EXACT = 0, LIKE_PREFIX = 1, LIKE_SUFFIX = 2, LIKE_CONTAINS = 3 };
+enum LikeKind : uint8_t { LIKE_EXACT = 0, LIKE_PREFIX = 1, LIKE_SUFFIX = 2, LIKE_CONTAINS = 3, LIKE_GENERAL = 4 };
 
 struct VmInstr {            // 8 bytes, read with scalar loads
     uint8_t op;

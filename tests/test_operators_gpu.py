@@ -154,7 +154,7 @@ def test_plan_errors(ctx):
     with pytest.raises(ba.PlanError, match="invalid partition"):
         ba.FilterExec(col("b"), m).execute(3)
     with pytest.raises(ba.NotImplementedOnGpu):
-        ba.FilterExec(E.BinaryExpr(col("s"), "Like", lit("a_c")), m)
+        ba.FilterExec(E.BinaryExpr(col("s"), "Like", lit("a_c" + "x" * 300)), m)      # pattern longer than 255 bytes
 
 
 def test_trait_methods(ctx):
@@ -433,3 +433,19 @@ def test_count_of_a_nullable_utf8_column(ctx, grouped):
     fin = ba.HashAggregateExec(ba.plan.FINAL, group, aggs, ba.MergeExec(part))
     got = run_both(fin, ordered=False, float_rtol=1e-9, key_cols=[n for _, n in group])
     assert sum(int(v) for v in got["cs"].values) == int(np.sum(b["s"].valid))
+
+
+@pytest.mark.parametrize("pattern", ["a_c", "_", "__", "%", "%%", "a%c", "%a%c%", "_b%", "%b_", "a%b%c_d", "%é_", "_é%", "日_語", "%語",
+                                      "ab", "", "a__%__z", "%ab%ab%"])
+def test_like_general_patterns(ctx, pattern):
+    """'%' = any sequence, '_' = exactly one character (UTF-8 aware), anywhere in the pattern"""
+    from collections import OrderedDict
+    words = ["", "a", "ab", "abc", "aXc", "ac", "abbc", "abcabc", "aébc", "é", "日本語", "日x語", "bb", "ab\ncd", "a1b2c3d", "xaby", "abab",
+             "a__z", "aqwertz", "a12z"]
+    rng = np.random.default_rng(len(pattern))
+    n = 3000
+    vals = [words[k] for k in rng.integers(0, len(words), n)]
+    b = OrderedDict([("s", OCol("Utf8", vals, rng.random(n) > 0.1)), ("i", OCol("Int32", np.arange(n, dtype=np.int32)))])
+    m = helpers.memory_exec(ctx, [[b]])
+    for op in ("Like", "NotLike"):
+        run_both(ba.FilterExec(E.BinaryExpr(col("s"), op, lit(pattern)), m), ordered=True)
