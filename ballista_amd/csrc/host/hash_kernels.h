@@ -53,7 +53,14 @@ struct NarrowJoinTable {
                               // key width 8: [capacity] {key, build row + 1 (low half of the second word)}, 16 bytes per slot
     uint64_t mask;
     uint32_t* dup_flag;       // set when two build rows share a key: the host falls back to JoinTable
+    // key width 4, optional: the exact set of build keys, one bit per value of [kmin, kmin + krange] (null: absent)
+    const uint32_t* present;
+    uint32_t kmin, krange;
 };
+// signed min / max of the build keys (mm[0], mm[1] seeded with INT32_MAX / INT32_MIN), then the presence bits
+hipError_t launch_join_key_minmax(const LaunchCfg& cfg, const int32_t* keys, const uint64_t* sel, uint32_t n, int32_t* mm);
+hipError_t launch_join_key_present(const LaunchCfg& cfg, const uint32_t* keys, const uint64_t* sel, uint32_t n, uint32_t kmin,
+                                   uint32_t* present);
 hipError_t launch_join_build_narrow(const LaunchCfg& cfg, const NarrowJoinTable& T, const void* keys, int key_width,
                                     const uint64_t* sel, uint32_t n_left);
 // gather (may be null): probe row i reads key / validity row gather[i] — the probe runs over a selection of the key

@@ -253,12 +253,21 @@ join_probe_match_narrow_kernel(NarrowJoinTable T, const uint32_t* rkeys, const u
         const uint32_t src = (in && gather) ? gather[row] : row;      // probe row -> row of the (unfiltered) key column
         if (in && bit_at(rsel, src)) {
             const uint32_t key = rkeys[src];
-            uint64_t slot = narrow_hash(key) & T.mask;
-            for (;;) {
-                const uint64_t v = T.slots[slot];
-                if (v == 0) break;
-                if ((uint32_t)v == key) { m = (uint32_t)(v >> 32) - 1u; break; }
-                slot = (slot + 1) & T.mask;
+            // the exact set of build keys as one bit per value of [kmin, kmin + krange]: a probe that cannot match stops
+            // at a 32x smaller, mostly cache-resident structure and never touches the table
+            bool maybe = true;
+            if (T.present) {
+                const uint32_t d = key - T.kmin;
+                maybe = d <= T.krange && ((T.present[d >> 5] >> (d & 31)) & 1u);
+            }
+            if (maybe) {
+                uint64_t slot = narrow_hash(key) & T.mask;
+                for (;;) {
+                    const uint64_t v = T.slots[slot];
+                    if (v == 0) break;
+                    if ((uint32_t)v == key) { m = (uint32_t)(v >> 32) - 1u; break; }
+                    slot = (slot + 1) & T.mask;
+                }
             }
             if (matched && m != 0xFFFFFFFFu) atomicOr(&matched[m >> 5], 1u << (m & 31));
         }
@@ -269,6 +278,27 @@ join_probe_match_narrow_kernel(NarrowJoinTable T, const uint32_t* rkeys, const u
             if (word) atomicAdd(&tile_counts[row64 / SEL_TILE], (uint32_t)__popcll(word));
         }
     }
+}
+
+// signed minimum / maximum of the build keys (mm[0] = min, mm[1] = max; the host seeds them with INT_MAX / INT_MIN)
+__global__ void __launch_bounds__(BLOCK)
+join_key_minmax_kernel(const int32_t* keys, const uint64_t* sel, uint32_t n, int32_t* mm) {
+    int32_t lo = 2147483647, hi = -2147483647 - 1;
+    for (uint32_t row = blockIdx.x * BLOCK + threadIdx.x; row < n; row += gridDim.x * BLOCK)
+        if (bit_at(sel, row)) { const int32_t k = keys[row]; lo = k < lo ? k : lo; hi = k > hi ? k : hi; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const int32_t l2 = __shfl_down(lo, d, 64), h2 = __shfl_down(hi, d, 64);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&mm[0], lo); atomicMax(&mm[1], hi); }
+}
+
+__global__ void __launch_bounds__(BLOCK)
+join_key_present_kernel(const uint32_t* keys, const uint64_t* sel, uint32_t n, uint32_t kmin, uint32_t* present) {
+    for (uint32_t row = blockIdx.x * BLOCK + threadIdx.x; row < n; row += gridDim.x * BLOCK)
+        if (bit_at(sel, row)) { const uint32_t d = keys[row] - kmin; atomicOr(&present[d >> 5], 1u << (d & 31)); }
 }
 
 // ---- the same for ONE Int64 / UInt64 key (TPC-H at SF1000: l_orderkey / o_orderkey are Int64): 16-byte slots
@@ -386,6 +416,17 @@ hipError_t launch_join_build_narrow(const LaunchCfg& cfg, const NarrowJoinTable&
         hipLaunchKernelGGL(join_build_narrow_kernel, dim3(grid_rows(cfg, n_left)), dim3(BLOCK), 0, cfg.stream, T, (const uint32_t*)keys, sel, n_left);
     else
         hipLaunchKernelGGL(join_build_narrow64_kernel, dim3(grid_rows(cfg, n_left)), dim3(BLOCK), 0, cfg.stream, T, (const uint64_t*)keys, sel, n_left);
+    return hipGetLastError();
+}
+hipError_t launch_join_key_minmax(const LaunchCfg& cfg, const int32_t* keys, const uint64_t* sel, uint32_t n, int32_t* mm) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(join_key_minmax_kernel, dim3(grid_rows(cfg, n)), dim3(BLOCK), 0, cfg.stream, keys, sel, n, mm);
+    return hipGetLastError();
+}
+hipError_t launch_join_key_present(const LaunchCfg& cfg, const uint32_t* keys, const uint64_t* sel, uint32_t n, uint32_t kmin,
+                                   uint32_t* present) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(join_key_present_kernel, dim3(grid_rows(cfg, n)), dim3(BLOCK), 0, cfg.stream, keys, sel, n, kmin, present);
     return hipGetLastError();
 }
 hipError_t launch_join_probe_match_narrow(const LaunchCfg& cfg, const NarrowJoinTable& T, const void* rkeys, int key_width,
