@@ -53,10 +53,16 @@ struct NarrowJoinTable {
                               // key width 8: [capacity] {key, build row + 1 (low half of the second word)}, 16 bytes per slot
     uint64_t mask;
     uint32_t* dup_flag;       // set when two build rows share a key: the host falls back to JoinTable
-    // key width 4, optional: the exact set of build keys, one bit per value of [kmin, kmin + krange] (null: absent)
+    // optional: the exact set of build keys, one bit per value of [kmin, kmin + krange] (null: absent);
+    // kmin for key width 4, kmin64 for key width 8
     const uint32_t* present;
     uint32_t kmin, krange;
+    uint64_t kmin64;
 };
+// the same for 64-bit keys: mm[] holds min / max of key ^ 2^63 (seeded with ~0 / 0)
+hipError_t launch_join_key_minmax64(const LaunchCfg& cfg, const uint64_t* keys, const uint64_t* sel, uint32_t n, uint64_t* mm);
+hipError_t launch_join_key_present64(const LaunchCfg& cfg, const uint64_t* keys, const uint64_t* sel, uint32_t n, uint64_t kmin,
+                                     uint32_t* present);
 // signed min / max of the build keys (mm[0], mm[1] seeded with INT32_MAX / INT32_MIN), then the presence bits
 hipError_t launch_join_key_minmax(const LaunchCfg& cfg, const int32_t* keys, const uint64_t* sel, uint32_t n, int32_t* mm);
 hipError_t launch_join_key_present(const LaunchCfg& cfg, const uint32_t* keys, const uint64_t* sel, uint32_t n, uint32_t kmin,

@@ -172,39 +172,54 @@ std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) co
         bs->dup = make_buffer(ex, 8);
         HIP_CHECK(hipMemsetAsync(bs->slots->ptr(), 0, cap * slot_bytes, ex.stream));
         HIP_CHECK(hipMemsetAsync(bs->dup->ptr(), 0, 8, ex.stream));
-        bs->ntable = NarrowJoinTable{bs->slots->as<uint64_t>(), cap - 1, bs->dup->as<uint32_t>(), nullptr, 0, 0};
+        bs->ntable = NarrowJoinTable{bs->slots->as<uint64_t>(), cap - 1, bs->dup->as<uint32_t>(), nullptr, 0, 0, 0};
         bs->narrow_width = nkw;
         HIP_CHECK(launch_join_build_narrow(ex.cfg(), bs->ntable, kc.data->ptr(), nkw,
                                            kc.validity ? kc.validity->as<uint64_t>() : nullptr, (uint32_t)n));
         if (read_device(ex, bs->dup->as<uint32_t>()) == 0) {
             bs->narrow = bs->unique = true;
             bs->ntable.dup_flag = nullptr;
-            // a table that outgrows the caches gets the exact key set as a bitmap in front of it (32-bit keys whose
-            // value range fits 128 MB of bits): probes without a partner stop there
+            // a table that outgrows the caches gets the exact key set as a bitmap in front of it (keys whose value window
+            // is at most 2^30 wide = 128 MB of bits): probes without a partner stop there
             static const bool present_disabled = [] { const char* v = getenv("BHIP_NO_JOIN_BITMAP"); return v && atoi(v) != 0; }();
-            if (!present_disabled && nkw == 4 && n >= (1 << 18)) {
+            if (!present_disabled && n >= (1 << 18)) {
                 const uint64_t* ksel = kc.validity ? kc.validity->as<uint64_t>() : nullptr;
                 Temp tmp(ex);
-                int32_t* mm = tmp.get<int32_t>(2);
-                const int32_t seed[2] = {2147483647, -2147483647 - 1};
-                HIP_CHECK(hipMemcpyAsync(mm, seed, 8, hipMemcpyHostToDevice, ex.stream));
-                HIP_CHECK(launch_join_key_minmax(ex.cfg(), kc.data->as<int32_t>(), ksel, (uint32_t)n, mm));
-                int32_t host_mm[2];
-                HIP_CHECK(hipMemcpyAsync(host_mm, mm, 8, hipMemcpyDeviceToHost, ex.stream));
-                HIP_CHECK(hipStreamSynchronize(ex.stream));
-                if (host_mm[0] <= host_mm[1]) {
-                    const uint32_t range = (uint32_t)host_mm[1] - (uint32_t)host_mm[0];
-                    if ((uint64_t)range / 8 <= (128ull << 20)) {
-                        const size_t words = (size_t)range / 32 + 2;
-                        bs->present = make_buffer(ex, words * 4);
-                        HIP_CHECK(hipMemsetAsync(bs->present->ptr(), 0, words * 4, ex.stream));
-                        HIP_CHECK(launch_join_key_present(ex.cfg(), kc.data->as<uint32_t>(), ksel, (uint32_t)n, (uint32_t)host_mm[0],
+                uint64_t* mm = tmp.get<uint64_t>(2);
+                uint64_t host_mm[2];                                 // min / max of the keys with the sign bit flipped
+                if (nkw == 4) {
+                    const int32_t seed[2] = {2147483647, -2147483647 - 1};
+                    HIP_CHECK(hipMemcpyAsync(mm, seed, 8, hipMemcpyHostToDevice, ex.stream));
+                    HIP_CHECK(launch_join_key_minmax(ex.cfg(), kc.data->as<int32_t>(), ksel, (uint32_t)n, reinterpret_cast<int32_t*>(mm)));
+                    int32_t got[2];
+                    HIP_CHECK(hipMemcpyAsync(got, mm, 8, hipMemcpyDeviceToHost, ex.stream));
+                    HIP_CHECK(hipStreamSynchronize(ex.stream));
+                    host_mm[0] = (uint64_t)(int64_t)got[0] ^ (1ull << 63);
+                    host_mm[1] = (uint64_t)(int64_t)got[1] ^ (1ull << 63);
+                } else {
+                    const uint64_t seed[2] = {~0ull, 0};
+                    HIP_CHECK(hipMemcpyAsync(mm, seed, 16, hipMemcpyHostToDevice, ex.stream));
+                    HIP_CHECK(launch_join_key_minmax64(ex.cfg(), kc.data->as<uint64_t>(), ksel, (uint32_t)n, mm));
+                    HIP_CHECK(hipMemcpyAsync(host_mm, mm, 16, hipMemcpyDeviceToHost, ex.stream));
+                    HIP_CHECK(hipStreamSynchronize(ex.stream));
+                }
+                if (host_mm[0] <= host_mm[1] && host_mm[1] - host_mm[0] <= (1ull << 30)) {
+                    const uint64_t range = host_mm[1] - host_mm[0];
+                    const uint64_t kmin = host_mm[0] ^ (1ull << 63);
+                    const size_t words = (size_t)range / 32 + 2;
+                    bs->present = make_buffer(ex, words * 4);
+                    HIP_CHECK(hipMemsetAsync(bs->present->ptr(), 0, words * 4, ex.stream));
+                    if (nkw == 4)
+                        HIP_CHECK(launch_join_key_present(ex.cfg(), kc.data->as<uint32_t>(), ksel, (uint32_t)n, (uint32_t)kmin,
                                                           bs->present->as<uint32_t>()));
-                        HIP_CHECK(hipStreamSynchronize(ex.stream));
-                        bs->ntable.present = bs->present->as<uint32_t>();
-                        bs->ntable.kmin = (uint32_t)host_mm[0];
-                        bs->ntable.krange = range;
-                    }
+                    else
+                        HIP_CHECK(launch_join_key_present64(ex.cfg(), kc.data->as<uint64_t>(), ksel, (uint32_t)n, kmin,
+                                                            bs->present->as<uint32_t>()));
+                    HIP_CHECK(hipStreamSynchronize(ex.stream));
+                    bs->ntable.present = bs->present->as<uint32_t>();
+                    bs->ntable.kmin = (uint32_t)kmin;
+                    bs->ntable.kmin64 = kmin;
+                    bs->ntable.krange = (uint32_t)range;
                 }
             }
             cache_->built = bs;

@@ -295,6 +295,28 @@ join_key_minmax_kernel(const int32_t* keys, const uint64_t* sel, uint32_t n, int
     if ((threadIdx.x & 63) == 0) { atomicMin(&mm[0], lo); atomicMax(&mm[1], hi); }
 }
 
+// 64-bit keys: mm[0] = min, mm[1] = max of key ^ 2^63 (signed order as unsigned; seeded with ~0 / 0)
+__global__ void __launch_bounds__(BLOCK)
+join_key_minmax64_kernel(const uint64_t* keys, const uint64_t* sel, uint32_t n, unsigned long long* mm) {
+    const uint64_t bias = 1ull << 63;
+    uint64_t lo = ~0ull, hi = 0;
+    for (uint32_t row = blockIdx.x * BLOCK + threadIdx.x; row < n; row += gridDim.x * BLOCK)
+        if (bit_at(sel, row)) { const uint64_t k = keys[row] ^ bias; lo = k < lo ? k : lo; hi = k > hi ? k : hi; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint64_t l2 = __shfl_down((unsigned long long)lo, d, 64), h2 = __shfl_down((unsigned long long)hi, d, 64);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&mm[0], (unsigned long long)lo); atomicMax(&mm[1], (unsigned long long)hi); }
+}
+
+__global__ void __launch_bounds__(BLOCK)
+join_key_present64_kernel(const uint64_t* keys, const uint64_t* sel, uint32_t n, uint64_t kmin, uint32_t* present) {
+    for (uint32_t row = blockIdx.x * BLOCK + threadIdx.x; row < n; row += gridDim.x * BLOCK)
+        if (bit_at(sel, row)) { const uint64_t d = keys[row] - kmin; atomicOr(&present[d >> 5], 1u << (d & 31)); }
+}
+
 __global__ void __launch_bounds__(BLOCK)
 join_key_present_kernel(const uint32_t* keys, const uint64_t* sel, uint32_t n, uint32_t kmin, uint32_t* present) {
     for (uint32_t row = blockIdx.x * BLOCK + threadIdx.x; row < n; row += gridDim.x * BLOCK)
@@ -339,13 +361,20 @@ join_probe_match_narrow64_kernel(NarrowJoinTable T, const uint64_t* rkeys, const
         const uint32_t src = (in && gather) ? gather[row] : row;
         if (in && bit_at(rsel, src)) {
             const uint64_t key = rkeys[src];
-            uint64_t slot = mix64(key) & T.mask;
-            for (;;) {
-                const ulonglong2 v = slots[slot];                    // {key, row1 | pad << 32}
-                const uint32_t r = (uint32_t)v.y;
-                if (r == 0) break;
-                if (v.x == key) { m = r - 1u; break; }
-                slot = (slot + 1) & T.mask;
+            bool maybe = true;
+            if (T.present) {
+                const uint64_t d = key - T.kmin64;
+                maybe = d <= T.krange && ((T.present[d >> 5] >> (d & 31)) & 1u);
+            }
+            if (maybe) {
+                uint64_t slot = mix64(key) & T.mask;
+                for (;;) {
+                    const ulonglong2 v = slots[slot];                    // {key, row1 | pad << 32}
+                    const uint32_t r = (uint32_t)v.y;
+                    if (r == 0) break;
+                    if (v.x == key) { m = r - 1u; break; }
+                    slot = (slot + 1) & T.mask;
+                }
             }
             if (matched && m != 0xFFFFFFFFu) atomicOr(&matched[m >> 5], 1u << (m & 31));
         }
@@ -421,6 +450,18 @@ hipError_t launch_join_build_narrow(const LaunchCfg& cfg, const NarrowJoinTable&
 hipError_t launch_join_key_minmax(const LaunchCfg& cfg, const int32_t* keys, const uint64_t* sel, uint32_t n, int32_t* mm) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(join_key_minmax_kernel, dim3(grid_rows(cfg, n)), dim3(BLOCK), 0, cfg.stream, keys, sel, n, mm);
+    return hipGetLastError();
+}
+hipError_t launch_join_key_minmax64(const LaunchCfg& cfg, const uint64_t* keys, const uint64_t* sel, uint32_t n, uint64_t* mm) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(join_key_minmax64_kernel, dim3(grid_rows(cfg, n)), dim3(BLOCK), 0, cfg.stream, keys, sel, n,
+                       reinterpret_cast<unsigned long long*>(mm));
+    return hipGetLastError();
+}
+hipError_t launch_join_key_present64(const LaunchCfg& cfg, const uint64_t* keys, const uint64_t* sel, uint32_t n, uint64_t kmin,
+                                     uint32_t* present) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(join_key_present64_kernel, dim3(grid_rows(cfg, n)), dim3(BLOCK), 0, cfg.stream, keys, sel, n, kmin, present);
     return hipGetLastError();
 }
 hipError_t launch_join_key_present(const LaunchCfg& cfg, const uint32_t* keys, const uint64_t* sel, uint32_t n, uint32_t kmin,

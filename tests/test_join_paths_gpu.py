@@ -99,26 +99,32 @@ def test_negative_and_extreme_keys(ctx):
 
 @pytest.mark.parametrize("jt", JOIN_TYPES)
 @pytest.mark.parametrize("shape", ["dense", "sparse", "full_range"])
-def test_build_key_set_bitmap(ctx, jt, shape):
-    """a unique Int32 build side of >= 2^18 rows gets its exact key set as a bitmap in front of the table (ops_join.cpp);
+@pytest.mark.parametrize("key_type", ["Int32", "Int64"])
+def test_build_key_set_bitmap(ctx, jt, shape, key_type):
+    """a unique integer build side of >= 2^18 rows gets its exact key set as a bitmap in front of the table (ops_join.cpp);
     dense: keys in a window around 0 with NULLs; sparse: a window of 2^29 values; full_range: the window exceeds the
     bitmap budget and the table alone answers. Probe keys fall inside, below and above the window."""
     rng = np.random.default_rng({"dense": 1, "sparse": 2, "full_range": 3}[shape])
     n_left, n_right = 300_000, 500_000
+    top = 63 if key_type == "Int64" else 31                  # full_range spans the whole key type
+    base = 10 ** 12 if key_type == "Int64" else 0            # Int64 windows sit far outside the Int32 values
     if shape == "dense":
         lk = rng.permutation(400_000)[:n_left].astype(np.int64) - 150_000
     elif shape == "sparse":
         lk = rng.choice(np.unique(rng.integers(-2 ** 28, 2 ** 28, 2 * n_left)), n_left, replace=False)
     else:
-        lk = rng.choice(np.unique(rng.integers(-2 ** 31 + 1, 2 ** 31 - 1, 2 * n_left)), n_left - 2, replace=False)
-        lk = np.concatenate([lk[:1000], [-2 ** 31, 2 ** 31 - 1], lk[1000:]])
+        lk = rng.choice(np.unique(rng.integers(-2 ** top + 1, 2 ** top - 1, 2 * n_left)), n_left - 2, replace=False)
+        lk = np.concatenate([lk[:1000], [-2 ** top, 2 ** top - 1], lk[1000:]])
+        base = 0
+    lk = lk.astype(np.int64) + base
     n_left = len(lk)
     lo, hi = int(lk.min()), int(lk.max())
     rk = np.where(rng.random(n_right) < 0.5, lk[rng.integers(0, n_left, n_right)],
-                  rng.integers(max(lo - 1000, -2 ** 31), min(hi + 1000, 2 ** 31 - 1), n_right))
-    rk[:4] = [max(lo - 1, -2 ** 31), min(hi + 1, 2 ** 31 - 1), lo, hi]
+                  rng.integers(max(lo - 1000, -2 ** top), min(hi + 1000, 2 ** top - 1), n_right))
+    rk[:4] = [max(lo - 1, -2 ** top), min(hi + 1, 2 ** top - 1), lo, hi]
     lv = (rng.random(n_left) > 0.05) if shape == "dense" else None
-    left = OrderedDict([("lk", OCol("Int32", lk.astype(np.int32), lv)), ("lx", OCol("Float64", rng.random(n_left)))])
-    right = OrderedDict([("rk", OCol("Int32", rk.astype(np.int32))), ("ry", OCol("Int64", rng.integers(0, 10 ** 9, n_right)))])
+    np_t = np.int64 if key_type == "Int64" else np.int32
+    left = OrderedDict([("lk", OCol(key_type, lk.astype(np_t), lv)), ("lx", OCol("Float64", rng.random(n_left)))])
+    right = OrderedDict([("rk", OCol(key_type, rk.astype(np_t))), ("ry", OCol("Int64", rng.integers(0, 10 ** 9, n_right)))])
     plan = ba.HashJoinExec(helpers.memory_exec(ctx, [[left]]), helpers.memory_exec(ctx, [[right]]), [("lk", "rk")], jt)
     check(plan, ["lk", "rk", "ry", "lx"])
