@@ -27,6 +27,12 @@ hipError_t launch_hash_agg_flags(const LaunchCfg& cfg, const HashAggTable& T, ui
 hipError_t launch_hash_agg_compact(const LaunchCfg& cfg, const HashAggTable& T, const uint64_t* dense_index, bool nulls,
                                    GroupRec* out);
 
+// group keys of any width: rep[row] = a row of the same batch whose key columns equal row's (NULL == NULL);
+// table = zeroed [mask + 1] words, mask + 1 a power of two >= 2 n; hashes = 64-bit row hashes of the key columns
+struct WideKeyCols { ColumnRef col[VM_MAX_COLS]; int32_t n; int32_t pad; };
+hipError_t launch_wide_key_assign(const LaunchCfg& cfg, const WideKeyCols& K, const uint64_t* hashes, uint32_t* table, uint64_t mask,
+                                  uint32_t n, uint32_t* rep);
+
 // ---- join -------------------------------------------------------------------------------------
 struct JoinTable {
     uint32_t* owner;          // [capacity] id+1 of the build row whose key defines the slot

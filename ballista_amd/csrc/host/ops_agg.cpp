@@ -216,7 +216,7 @@ GroupRec* hash_aggregate(const Exec& ex, Temp& tmp, const ScanParams& P0, const 
 
 }  // namespace
 
-std::vector<BatchPtr> HashAggregateExec::run(int partition, const Exec& ex) const {
+std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& ex) const {
     const Schema& in_schema = *input_->schema();
     // ---- expressions over the (fused) source ---------------------------------------------------
     std::vector<ExprPtr> group, args;

@@ -1,0 +1,126 @@
+// ops_agg_wide.cpp — HashAggregateExec over group keys that do not fit the 16-byte packed key (several Utf8 columns,
+// long strings: TPC-H Q10 groups by c_name, c_address, c_phone, c_comment ...).  Reference operator:
+// rust/core/src/serde/physical_plan/from_proto.rs:173-252 (HashAggregateExec, any group expressions).
+//
+// Two steps on top of the packed-key machinery:
+//   1. wide_key_assign_kernel (kernels_hash.hip) gives every input row a representative row with an equal key
+//      (hash table of row ids over 64-bit row hashes; equality on the key columns themselves, NULL == NULL);
+//   2. the ordinary aggregate runs with that ONE Int32 column as its key, and the key columns of the result are
+//      gathered from the input at the representative rows.
+#include "hash_kernels.h"
+#include "plan.hpp"
+
+namespace bhip {
+
+namespace {
+const char* const kRepName = "__group_rep";
+
+bool key_width_error(const Error& e) {
+    if (e.code != BHIP_ENOTIMPL) return false;
+    const std::string m = e.what();
+    return m.find("packed key") != std::string::npos || m.find("packed-key") != std::string::npos;
+}
+}  // namespace
+
+std::vector<BatchPtr> HashAggregateExec::run(int partition, const Exec& ex) const {
+    if (!group_.empty() && wide_keys_.load()) return run_wide(partition, ex);
+    try {
+        return run_packed(partition, ex);
+    } catch (const Error& e) {
+        if (group_.empty() || !key_width_error(e)) throw;
+    }
+    wide_keys_.store(true);
+    return run_wide(partition, ex);
+}
+
+std::vector<BatchPtr> HashAggregateExec::run_wide(int partition, const Exec& ex) const {
+    const SchemaPtr in_schema = input_->schema();
+    if (in_schema->index_of(kRepName) >= 0) fail(BHIP_EINVAL, std::string("column name '") + kRepName + "' is reserved");
+    if (group_.size() > (size_t)VM_MAX_COLS) fail(BHIP_ENOTIMPL, "more than 16 group expressions");
+    std::vector<BatchPtr> parts;
+    {
+        auto s = input_->execute(partition, ex);
+        while (BatchPtr b = s->next())
+            if (b->n_rows > 0) parts.push_back(b);
+    }
+    if (parts.empty()) return {};
+    const BatchPtr in = parts.size() == 1 ? parts[0] : concat_batches(ex, in_schema, parts);
+    parts.clear();
+    const int64_t n = in->n_rows;
+    if (n > 0x7FFFFFF0ll) fail(BHIP_ENOTIMPL, "wide-key aggregate over more than 2^31 input rows per partition");
+    const LaunchCfg cfg = ex.cfg();
+
+    // ---- key columns, their row hashes, the representative of every row -------------------------------------
+    std::vector<Column> keys;
+    for (auto& g : group_) keys.push_back(evaluate_column(ex, *in, g.first));
+    BufferPtr rep = make_buffer(ex, (size_t)n * 4 + 8);
+    {
+        Temp tmp(ex);
+        ProgramBuilder pb(*in_schema);
+        pb.set_hash_only();
+        for (auto& g : group_) pb.add_key(g.first);
+        ScanParams P;
+        pb.finish(P);
+        ProgramBuilder::bind(P, pb.columns(), *in, pb.creates_nulls());
+        uint64_t* hashes = tmp.get<uint64_t>((size_t)n);
+        ScanStatus* st = tmp.get<ScanStatus>(1);
+        HIP_CHECK(hipMemsetAsync(st, 0, sizeof(ScanStatus), ex.stream));
+        HIP_CHECK(launch_scan_keys(cfg, P, nullptr, hashes, nullptr, st));
+        check_scan_status(ex, st);
+        uint64_t cap = 1024;
+        while (cap < 2ull * (uint64_t)n) cap <<= 1;
+        uint32_t* table = tmp.get<uint32_t>(cap);
+        HIP_CHECK(hipMemsetAsync(table, 0, cap * 4, ex.stream));
+        WideKeyCols K;
+        memset(&K, 0, sizeof(K));
+        K.n = (int32_t)keys.size();
+        for (size_t i = 0; i < keys.size(); ++i) K.col[i] = keys[i].ref();
+        HIP_CHECK(launch_wide_key_assign(cfg, K, hashes, table, cap - 1, (uint32_t)n, rep->as<uint32_t>()));
+        HIP_CHECK(hipStreamSynchronize(ex.stream));                  // the scratch is released here
+    }
+
+    // ---- the ordinary aggregate, keyed by the representative row ---------------------------------------------
+    auto s2 = std::make_shared<Schema>();
+    auto aug = std::make_shared<Batch>();
+    aug->ctx = ex.ctx;
+    aug->n_rows = n;
+    s2->fields.push_back(Field{kRepName, DT_INT32, false});
+    {
+        Column c;
+        c.dtype = DT_INT32;
+        c.length = n;
+        c.data = rep;
+        aug->cols.push_back(std::move(c));
+    }
+    // Partial: the arguments are expressions over the input's names; Final: the state columns follow the key by position
+    const size_t first = mode_ == BHIP_AGG_PARTIAL ? 0 : group_.size();
+    for (size_t i = first; i < in_schema->fields.size(); ++i) {
+        s2->fields.push_back(in_schema->fields[i]);
+        aug->cols.push_back(in->cols[i]);
+    }
+    aug->schema = s2;
+    auto src = std::make_shared<MemoryExec>(ex.ctx, s2, std::vector<std::vector<BatchPtr>>{{BatchPtr(aug)}});
+    auto inner = std::make_shared<HashAggregateExec>(
+        mode_, std::vector<std::pair<ExprPtr, std::string>>{{make_column(kRepName), kRepName}}, aggr_, src);
+    if (n >= 4096) inner->path_hint_.store(-1);                     // many rows: straight to the device-wide table
+    std::vector<BatchPtr> res = inner->run_packed(0, ex);
+
+    // ---- key columns of the groups: the input's, at the representative rows ----------------------------------
+    std::vector<BatchPtr> outv;
+    for (auto& r : res) {
+        auto out = std::make_shared<Batch>();
+        out->schema = schema_;
+        out->ctx = ex.ctx;
+        out->n_rows = r->n_rows;
+        std::vector<const Column*> kp;
+        for (auto& k : keys) kp.push_back(&k);
+        std::vector<Column> got = take_columns(ex, kp, r->cols[0].data->as<uint32_t>(), r->n_rows, false);
+        for (auto& c : got) out->cols.push_back(std::move(c));
+        for (size_t i = 1; i < r->cols.size(); ++i) out->cols.push_back(r->cols[i]);
+        outv.push_back(out);
+    }
+    HIP_CHECK(hipStreamSynchronize(ex.stream));
+    return outv;
+}
+
+}  // namespace bhip

@@ -198,11 +198,14 @@ public:
     std::string describe() const override;
 private:
     std::vector<BatchPtr> run(int partition, const Exec& ex) const;
+    std::vector<BatchPtr> run_packed(int partition, const Exec& ex) const;   // keys packed into 16 bytes (every fast path)
+    std::vector<BatchPtr> run_wide(int partition, const Exec& ex) const;     // keys of any width (ops_agg_wide.cpp)
     int mode_;
     std::vector<std::pair<ExprPtr, std::string>> group_;
     std::vector<AggregateDesc> aggr_;
     SchemaPtr schema_;
     mutable std::atomic<int> path_hint_{0};    // 0 = unknown, 4/8 = register path with that many groups, -1 = hash path
+    mutable std::atomic<bool> wide_keys_{false};   // a run found key values the packed key cannot hold
 };
 
 struct JoinBuildSide;

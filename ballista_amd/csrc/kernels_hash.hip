@@ -323,6 +323,60 @@ join_key_present_kernel(const uint32_t* keys, const uint64_t* sel, uint32_t n, u
         if (bit_at(sel, row)) { const uint32_t d = keys[row] - kmin; atomicOr(&present[d >> 5], 1u << (d & 31)); }
 }
 
+// ---- group keys of any width: every row gets a REPRESENTATIVE row with an equal key -------------------------------
+// (HashAggregateExec over keys that do not fit the 16-byte packed key: c_name, c_address, c_comment ... of TPC-H Q10.)
+// The table holds row ids claimed by one 32-bit CAS; equality is decided on the immutable key COLUMNS of the two rows
+// (NULL == NULL, as GROUP BY wants), so nothing a prober reads besides the CAS word changes during the kernel.
+// Which of the equal rows becomes the representative is decided by the race; the groups are the same either way.
+__device__ inline bool wide_keys_equal(const WideKeyCols& K, uint32_t a, uint32_t b) {
+    for (int c = 0; c < K.n; ++c) {
+        const ColumnRef& r = K.col[c];
+        const bool va = bit_at(r.validity, a), vb = bit_at(r.validity, b);
+        if (va != vb) return false;
+        if (!va) continue;
+        switch (r.dtype) {
+            case DT_UTF8: {
+                const int32_t a0 = r.offsets[a], a1 = r.offsets[a + 1], b0 = r.offsets[b], b1 = r.offsets[b + 1];
+                if (a1 - a0 != b1 - b0) return false;
+                const uint8_t* d = static_cast<const uint8_t*>(r.data);
+                for (int32_t i = 0; i < a1 - a0; ++i)
+                    if (d[a0 + i] != d[b0 + i]) return false;
+            } break;
+            case DT_BOOLEAN: {
+                const uint8_t* d = static_cast<const uint8_t*>(r.data);
+                if (((d[a >> 3] >> (a & 7)) & 1) != ((d[b >> 3] >> (b & 7)) & 1)) return false;
+            } break;
+            case DT_UINT8:
+                if (static_cast<const uint8_t*>(r.data)[a] != static_cast<const uint8_t*>(r.data)[b]) return false;
+                break;
+            case DT_INT32:
+            case DT_DATE32:
+                if (static_cast<const uint32_t*>(r.data)[a] != static_cast<const uint32_t*>(r.data)[b]) return false;
+                break;
+            default:                                                  // Int64 / UInt64 / Float64 (by bits)
+                if (static_cast<const uint64_t*>(r.data)[a] != static_cast<const uint64_t*>(r.data)[b]) return false;
+                break;
+        }
+    }
+    return true;
+}
+
+__global__ void __launch_bounds__(BLOCK)
+wide_key_assign_kernel(const WideKeyCols K, const uint64_t* hashes, uint32_t* table, uint64_t mask, uint32_t n, uint32_t* rep) {
+    for (uint32_t row = blockIdx.x * BLOCK + threadIdx.x; row < n; row += gridDim.x * BLOCK) {
+        uint64_t slot = mix64(hashes[row]) & mask;
+        for (;;) {
+            uint32_t o = table[slot];
+            if (o == 0) {
+                o = atomicCAS(&table[slot], 0u, row + 1u);
+                if (o == 0) { rep[row] = row; break; }
+            }
+            if (wide_keys_equal(K, o - 1u, row)) { rep[row] = o - 1u; break; }
+            slot = (slot + 1) & mask;
+        }
+    }
+}
+
 // ---- the same for ONE Int64 / UInt64 key (TPC-H at SF1000: l_orderkey / o_orderkey are Int64): 16-byte slots
 // {key, build row + 1}.  The build claims a slot with a 32-bit CAS on the row word and compares against the key
 // COLUMN of the claiming row (immutable input), so no reader ever depends on a half-written slot; the key word is
@@ -445,6 +499,12 @@ hipError_t launch_join_build_narrow(const LaunchCfg& cfg, const NarrowJoinTable&
         hipLaunchKernelGGL(join_build_narrow_kernel, dim3(grid_rows(cfg, n_left)), dim3(BLOCK), 0, cfg.stream, T, (const uint32_t*)keys, sel, n_left);
     else
         hipLaunchKernelGGL(join_build_narrow64_kernel, dim3(grid_rows(cfg, n_left)), dim3(BLOCK), 0, cfg.stream, T, (const uint64_t*)keys, sel, n_left);
+    return hipGetLastError();
+}
+hipError_t launch_wide_key_assign(const LaunchCfg& cfg, const WideKeyCols& K, const uint64_t* hashes, uint32_t* table, uint64_t mask,
+                                  uint32_t n, uint32_t* rep) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(wide_key_assign_kernel, dim3(grid_rows(cfg, n)), dim3(BLOCK), 0, cfg.stream, K, hashes, table, mask, n, rep);
     return hipGetLastError();
 }
 hipError_t launch_join_key_minmax(const LaunchCfg& cfg, const int32_t* keys, const uint64_t* sel, uint32_t n, int32_t* mm) {

@@ -221,12 +221,83 @@ def test_aggregate_over_projection_and_filter_fuses(ctx):
     run_both(agg, ordered=False, float_rtol=1e-9, key_cols=["kk"])
 
 
-def test_group_key_too_long_is_not_implemented(ctx):
-    b = random_batch(100, seed=5, nulls=False)
-    m = helpers.memory_exec(ctx, [[b]])
-    agg = ba.HashAggregateExec(ba.plan.PARTIAL, [(col("s"), "s")], [E.Count(lit(1, E.UINT8), "n")], m)
-    with pytest.raises(ba.NotImplementedOnGpu):
-        agg.collect()       # "a much longer string value" does not fit the 16-byte packed key
+def test_group_key_longer_than_the_packed_key(ctx):
+    """ "a much longer string value" does not fit the 16-byte packed key: the run falls over to the wide-key path
+    (representative rows, ops_agg_wide.cpp) and the operator remembers it"""
+    b = random_batch(3000, seed=5)
+    m = helpers.memory_exec(ctx, [[helpers.slice_batch(b, 0, 1000)], [helpers.slice_batch(b, 1000, 3000)]])
+    aggs = [E.Count(lit(1, E.UINT8), "n"), E.Sum(col("f"), "sf"), E.Avg(col("i32"), "ai"), E.Min(col("d"), "md")]
+    part = ba.HashAggregateExec(ba.plan.PARTIAL, [(col("s"), "s")], aggs, m)
+    for _ in range(2):
+        run_both(part, ordered=False, float_rtol=1e-9, key_cols=["s"])
+    fin = ba.HashAggregateExec(ba.plan.FINAL, [(col("s"), "s")], aggs, ba.MergeExec(part))
+    got = run_both(fin, ordered=False, float_rtol=1e-9, key_cols=["s"])
+    assert len(got["s"].values) == 9                       # 8 words + NULL
+
+
+WIDE_GROUPINGS = [
+    [("s", "s"), ("k", "k"), ("i64", "i64"), ("d", "d")],               # Utf8 + 16 fixed bytes
+    [("i64", "i64"), ("u64", "u64"), ("f", "f")],                       # 24 fixed bytes, NULLs in every part
+    [("s", "s1"), ("s", "s2"), ("b", "b"), ("u8", "u8"), ("i32", "i32"), ("d", "d"), ("k", "k")],
+]
+
+
+@pytest.mark.parametrize("gi", range(len(WIDE_GROUPINGS)))
+def test_hash_aggregate_wide_group_keys(ctx, gi):
+    names = WIDE_GROUPINGS[gi]
+    rng = np.random.default_rng(gi)
+    bs = [random_batch(6000, seed=140 + gi), random_batch(2500, seed=150 + gi)]
+    for b in bs:                                           # few distinct values per column, so that groups repeat
+        for name, mod in (("i64", 5), ("u64", 3), ("d", 4)):
+            c = b[name]
+            b[name] = OCol(c.dtype, (c.values % mod).astype(c.values.dtype), c.valid)
+        b["f"] = OCol("Float64", np.round(b["f"].values / 100) + 0.0, b["f"].valid)       # + 0.0: no -0.0 among the keys
+    m = helpers.memory_exec(ctx, [[bs[0]], [bs[1]]])
+    group = [(col(a), n) for a, n in names]
+    aggs = [E.Sum(col("g"), "sg"), E.Avg(col("f"), "af"), E.Count(col("f"), "cf"), E.Count(lit(1, E.UINT8), "n"),
+            E.Max(col("i32"), "mx"), E.Min(col("g"), "mn")]
+    keys = [n for _, n in names]
+    part = ba.HashAggregateExec(ba.plan.PARTIAL, group, aggs, m)
+    run_both(part, ordered=False, float_rtol=1e-9, key_cols=keys)
+    fin = ba.HashAggregateExec(ba.plan.FINAL, [(col(n), n) for n in keys], aggs, ba.MergeExec(part))
+    run_both(fin, ordered=False, float_rtol=1e-9, key_cols=keys)
+
+
+def test_wide_group_keys_q10_shape(ctx):
+    """TPC-H Q10's GROUP BY: c_custkey, c_name, c_acctbal, c_phone, n_name, c_address, c_comment"""
+    from collections import OrderedDict
+    rng = np.random.default_rng(10)
+    n_cust, n = 3000, 40_000
+    def text(lo, hi):
+        return ["".join(chr(int(c)) for c in rng.integers(97, 123, int(rng.integers(lo, hi)))) for _ in range(n_cust)]
+    cust = dict(name=[f"Customer#{i:09d}" for i in range(n_cust)], acctbal=np.round(rng.uniform(-999, 9999, n_cust), 2),
+                phone=[f"{i % 25 + 10}-{i % 900 + 100}-{i % 9000 + 1000}" for i in range(n_cust)],
+                nation=[["FRANCE", "GERMANY", "UNITED STATES", "UNITED KINGDOM"][i % 4] for i in range(n_cust)],
+                address=text(10, 41), comment=text(29, 117))
+    pick = rng.integers(0, n_cust, n)
+    b = OrderedDict([("c_custkey", OCol("Int32", pick.astype(np.int32))),
+                     ("c_name", OCol("Utf8", [cust["name"][i] for i in pick])),
+                     ("c_acctbal", OCol("Float64", cust["acctbal"][pick])),
+                     ("c_phone", OCol("Utf8", [cust["phone"][i] for i in pick])),
+                     ("n_name", OCol("Utf8", [cust["nation"][i] for i in pick])),
+                     ("c_address", OCol("Utf8", [cust["address"][i] for i in pick])),
+                     ("c_comment", OCol("Utf8", [cust["comment"][i] for i in pick])),
+                     ("l_extendedprice", OCol("Float64", np.round(rng.uniform(900, 100000, n), 2))),
+                     ("l_discount", OCol("Float64", rng.integers(0, 11, n) / 100.0))])
+    keys = list(b)[:7]
+    m = helpers.memory_exec(ctx, [[helpers.slice_batch(b, 0, 15_000), helpers.slice_batch(b, 15_000, 25_000)], [helpers.slice_batch(b, 25_000, n)]])
+    aggs = [E.Sum(col("l_extendedprice") * (lit(1.0) - col("l_discount")), "revenue")]
+    part = ba.HashAggregateExec(ba.plan.PARTIAL, [(col(k), k) for k in keys], aggs, m)
+    fin = ba.HashAggregateExec(ba.plan.FINAL, [(col(k), k) for k in keys], aggs, ba.MergeExec(part))
+    got = run_both(fin, ordered=False, float_rtol=1e-9, key_cols=["c_custkey"])
+    assert len(got["c_custkey"].values) == len(np.unique(pick))
+
+
+def test_wide_group_keys_over_an_empty_input(ctx):
+    b = random_batch(100, seed=5)
+    flt = ba.FilterExec(col("g") > lit(2.0), helpers.memory_exec(ctx, [[b]]))
+    agg = ba.HashAggregateExec(ba.plan.PARTIAL, [(col("i64"), "i64"), (col("u64"), "u64"), (col("f"), "f")], [E.Count(lit(1, E.UINT8), "n")], flt)
+    assert sum(x.num_rows for x in agg.collect()) == 0
 
 
 @pytest.mark.parametrize("jt", [ba.plan.INNER, ba.plan.LEFT, ba.plan.RIGHT])
