@@ -199,7 +199,6 @@ GroupRec* hash_aggregate(const Exec& ex, Temp& tmp, const ScanParams& P0, const 
         HIP_CHECK(launch_scan_agg_hash(cfg, P, T, row_base, status));
         row_base += (uint32_t)b->n_rows;
     }
-    check_scan_status(ex, status);
     // used slots -> dense records (slot order: deterministic for a given input)
     uint32_t* flags = tmp.get<uint32_t>(cap);
     uint64_t* dense = tmp.get<uint64_t>(cap + 1);
@@ -208,6 +207,7 @@ GroupRec* hash_aggregate(const Exec& ex, Temp& tmp, const ScanParams& P0, const 
     HIP_CHECK(launch_hash_agg_flags(cfg, T, flags));
     HIP_CHECK(exclusive_scan_u32_u64(ex.stream, flags, (int64_t)cap, dense, false, total, scan_tmp));
     const uint64_t ng = read_device(ex, total);
+    check_scan_status(ex, status);                   // after the one wait above: the stream is idle, this read is immediate
     GroupRec* table = tmp.get<GroupRec>(ng ? ng : 1);
     if (ng) HIP_CHECK(launch_hash_agg_compact(cfg, T, dense, nullable, table));
     *n_groups = (int64_t)ng;
@@ -419,7 +419,7 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
             use_sop = false;                 // a string key longer than the fast path's 7 bytes: the VM packs up to 15
             continue;
         }
-        check_scan_status(ex, status, &st);
+        check_scan_flags(st);
         if (st.flags & SCAN_OVERFLOW_GROUPS) {
             gmax = gmax == 4 ? 8 : -1;       // more groups than the register path holds: widen, then hash
             path_hint_.store(gmax);
@@ -466,13 +466,18 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
         if (kinfo[gi].nullable) c.validity = make_buffer(ex, bitmap_bytes(n_groups) + 8);
         uint64_t* vptr = c.validity ? c.validity->as<uint64_t>() : nullptr;
         if (c.dtype == DT_UTF8) {
-            uint32_t* lengths = tmp.get<uint32_t>((size_t)n_groups + 1);
             c.offsets = make_buffer(ex, (size_t)(n_groups + 1) * 4);
-            void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes(n_groups));
-            if (n_groups) HIP_CHECK(launch_emit_group_key(cfg, table, n_groups, ks, nullptr, vptr, lengths));
-            HIP_CHECK(exclusive_scan_u32_i32(ex.stream, lengths, n_groups, c.offsets->as<int32_t>(), true, totals + gi, scan_tmp));
             c.data = make_buffer(ex, (size_t)n_groups * (size_t)kinfo[gi].width + 8);
-            if (n_groups) HIP_CHECK(launch_emit_group_utf8(cfg, table, n_groups, ks, c.offsets->as<int32_t>(), c.data->as<uint8_t>()));
+            if (n_groups > 0 && n_groups <= EMIT_UTF8_SMALL_MAX) {
+                HIP_CHECK(launch_emit_group_utf8_small(cfg, table, n_groups, ks, vptr, c.offsets->as<int32_t>(), c.data->as<uint8_t>(),
+                                                       totals + gi));
+            } else {
+                uint32_t* lengths = tmp.get<uint32_t>((size_t)n_groups + 1);
+                void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes(n_groups));
+                if (n_groups) HIP_CHECK(launch_emit_group_key(cfg, table, n_groups, ks, nullptr, vptr, lengths));
+                HIP_CHECK(exclusive_scan_u32_i32(ex.stream, lengths, n_groups, c.offsets->as<int32_t>(), true, totals + gi, scan_tmp));
+                if (n_groups) HIP_CHECK(launch_emit_group_utf8(cfg, table, n_groups, ks, c.offsets->as<int32_t>(), c.data->as<uint8_t>()));
+            }
             utf8_cols.push_back(gi);
         } else {
             const size_t bytes = c.dtype == DT_BOOLEAN ? bitmap_bytes(n_groups) : (size_t)n_groups * dtype_width(c.dtype);

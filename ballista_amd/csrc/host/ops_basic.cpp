@@ -38,6 +38,10 @@ std::string display_plan(const PlanPtr& p) {
 void check_scan_status(const Exec& ex, const ScanStatus* dev_status, ScanStatus* host_out) {
     ScanStatus st = read_device(ex, dev_status);
     if (host_out) *host_out = st;
+    check_scan_flags(st);
+}
+
+void check_scan_flags(const ScanStatus& st) {
     if (st.flags & SCAN_ERR_DIV_ZERO) fail(BHIP_EEXEC, "Arrow error: Divide by zero error");
     if (st.flags & SCAN_ERR_KEY_TOO_LONG)
         fail(BHIP_ENOTIMPL, "a Utf8 key value is longer than the packed-key path supports");

@@ -268,6 +268,7 @@ int64_t filter_indices(const Exec& ex, const Batch& in, const ExprPtr& predicate
 // split a batch by hash(exprs) % n, keeping input order inside each part
 std::vector<BatchPtr> hash_partition_batch(const Exec& ex, const BatchPtr& in, const std::vector<ExprPtr>& exprs, int n);
 void check_scan_status(const Exec& ex, const ScanStatus* dev_status, ScanStatus* host_out = nullptr);
+void check_scan_flags(const ScanStatus& host_status);   // the same checks on a status already read back
 // value of `e` over `in` as a column (a plain Column reference shares the input buffers)
 Column evaluate_column(const Exec& ex, const Batch& in, const ExprPtr& e);
 // gather of one column incl. its validity bitmap

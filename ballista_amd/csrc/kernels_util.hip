@@ -100,6 +100,33 @@ scan_apply_kernel(const uint32_t* in, int64_t n, const uint64_t* chunk_offsets, 
     }
 }
 
+// n <= SCAN_CHUNK: the whole scan in one workgroup and one launch (group tables, small gathers: a Q1 step runs eight of these)
+template <class OutT>
+__global__ void __launch_bounds__(SCAN_BLOCK)
+scan_one_chunk_kernel(const uint32_t* in, int64_t n, OutT* out, int write_total, uint64_t* total_out) {
+    __shared__ uint64_t s_wave[4];
+    uint32_t x[SCAN_ITEMS];
+    uint64_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        const int64_t j = (int64_t)threadIdx.x * SCAN_ITEMS + i;
+        x[i] = j < n ? in[j] : 0;
+        sum += x[i];
+    }
+    uint64_t tot;
+    uint64_t run = block_exclusive_scan(sum, s_wave, &tot);
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        const int64_t j = (int64_t)threadIdx.x * SCAN_ITEMS + i;
+        if (j < n) out[j] = (OutT)run;
+        run += x[i];
+    }
+    if (threadIdx.x == 0) {
+        if (write_total) out[n] = (OutT)tot;
+        if (total_out) *total_out = tot;
+    }
+}
+
 size_t exclusive_scan_temp_bytes(int64_t n) {
     const int64_t n_chunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
     return (size_t)(n_chunks > 0 ? n_chunks : 1) * sizeof(uint64_t);
@@ -115,6 +142,10 @@ static hipError_t exclusive_scan_t(hipStream_t st, const uint32_t* in, int64_t n
         if (total_out) e = hipMemsetAsync(total_out, 0, sizeof(uint64_t), st);
         if (e == hipSuccess && write_total) e = hipMemsetAsync(out, 0, sizeof(OutT), st);
         return e;
+    }
+    if (n_chunks == 1) {
+        hipLaunchKernelGGL((scan_one_chunk_kernel<OutT>), dim3(1), dim3(SCAN_BLOCK), 0, st, in, n, out, write_total ? 1 : 0, total_out);
+        return hipGetLastError();
     }
     hipLaunchKernelGGL(scan_chunk_sums_kernel, dim3((unsigned)n_chunks), dim3(SCAN_BLOCK), 0, st, in, n, sums);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, st, sums, n_chunks, total_out);
@@ -432,6 +463,52 @@ emit_group_key_kernel(const GroupRec* table, int64_t n_groups, EmitKeySpec spec,
     }
 }
 
+// a Utf8 key column of at most SCAN_CHUNK groups in ONE launch of one workgroup: lengths, their prefix sum, offsets, the
+// bytes, the validity words and the byte total (a thread owns SCAN_ITEMS consecutive groups, so four lanes make a word)
+__global__ void __launch_bounds__(SCAN_BLOCK)
+emit_group_utf8_small_kernel(const GroupRec* table, int64_t n_groups, EmitKeySpec spec, uint64_t* validity, int32_t* offsets,
+                             uint8_t* bytes, uint64_t* total_out) {
+    static_assert(SCAN_ITEMS == 16, "four lanes x 16 groups = one validity word");
+    __shared__ uint64_t s_wave[4];
+    uint32_t len[SCAN_ITEMS];
+    uint64_t sum = 0;
+    uint32_t vmask = 0;
+    const int pos = spec.pos + (spec.nullable ? 1 : 0);
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        const int64_t j = (int64_t)threadIdx.x * SCAN_ITEMS + i;
+        len[i] = 0;
+        if (j < n_groups) {
+            const GroupRec& g = table[j];
+            const bool valid = !spec.nullable || key_get(g, spec.pos, 1) != 0;
+            if (valid) { len[i] = (uint32_t)key_get(g, pos, 1); vmask |= 1u << i; }
+        }
+        sum += len[i];
+    }
+    if (validity != nullptr) {
+        const uint64_t m0 = vmask;
+        const uint64_t m1 = __shfl_down(vmask, 1, 64), m2 = __shfl_down(vmask, 2, 64), m3 = __shfl_down(vmask, 3, 64);
+        const int64_t word = threadIdx.x >> 2;
+        if ((threadIdx.x & 3) == 0 && word < (n_groups + 63) / 64) validity[word] = m0 | (m1 << 16) | (m2 << 32) | (m3 << 48);
+    }
+    uint64_t tot;
+    uint64_t run = block_exclusive_scan(sum, s_wave, &tot);
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        const int64_t j = (int64_t)threadIdx.x * SCAN_ITEMS + i;
+        if (j < n_groups) {
+            offsets[j] = (int32_t)run;
+            const GroupRec& g = table[j];
+            for (uint32_t b = 0; b < len[i]; ++b) bytes[run + b] = (uint8_t)key_get(g, pos + 1 + (int)b, 1);
+        }
+        run += len[i];
+    }
+    if (threadIdx.x == 0) {
+        offsets[n_groups] = (int32_t)tot;
+        if (total_out) *total_out = tot;
+    }
+}
+
 __global__ void __launch_bounds__(BLOCK)
 emit_group_utf8_kernel(const GroupRec* table, int64_t n_groups, EmitKeySpec spec, const int32_t* offsets, uint8_t* bytes) {
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n_groups; i += (int64_t)gridDim.x * BLOCK) {
@@ -528,6 +605,13 @@ hipError_t launch_emit_group_key(const LaunchCfg& cfg, const GroupRec* table, in
     if (n_groups == 0) return hipSuccess;
     hipLaunchKernelGGL(emit_group_key_kernel, dim3(grid_for(cfg, n_groups)), dim3(BLOCK), 0, cfg.stream, table, n_groups,
                        spec, data, validity, utf8_lengths);
+    return hipGetLastError();
+}
+hipError_t launch_emit_group_utf8_small(const LaunchCfg& cfg, const GroupRec* table, int64_t n_groups, const EmitKeySpec& spec,
+                                        uint64_t* validity, int32_t* offsets, uint8_t* bytes, uint64_t* total_out) {
+    if (n_groups <= 0 || n_groups > EMIT_UTF8_SMALL_MAX) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(emit_group_utf8_small_kernel, dim3(1), dim3(SCAN_BLOCK), 0, cfg.stream, table, n_groups, spec, validity,
+                       offsets, bytes, total_out);
     return hipGetLastError();
 }
 hipError_t launch_emit_group_utf8(const LaunchCfg& cfg, const GroupRec* table, int64_t n_groups, const EmitKeySpec& spec,

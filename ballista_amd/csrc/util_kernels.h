@@ -87,6 +87,10 @@ struct EmitValueBatch {
 hipError_t launch_emit_group_values(const LaunchCfg& cfg, const GroupRec* table, int64_t n_groups, const EmitValueBatch& batch);
 hipError_t launch_emit_group_key(const LaunchCfg& cfg, const GroupRec* table, int64_t n_groups, const EmitKeySpec& spec,
                                  void* data, uint64_t* validity, uint32_t* utf8_lengths);
+// n_groups <= EMIT_UTF8_SMALL_MAX: lengths + prefix sum + offsets (n + 1) + bytes + validity + byte total in one launch
+constexpr int64_t EMIT_UTF8_SMALL_MAX = 4096;
+hipError_t launch_emit_group_utf8_small(const LaunchCfg& cfg, const GroupRec* table, int64_t n_groups, const EmitKeySpec& spec,
+                                        uint64_t* validity, int32_t* offsets, uint8_t* bytes, uint64_t* total_out);
 hipError_t launch_emit_group_utf8(const LaunchCfg& cfg, const GroupRec* table, int64_t n_groups, const EmitKeySpec& spec,
                                   const int32_t* offsets, uint8_t* bytes);
 hipError_t launch_emit_group_value(const LaunchCfg& cfg, const GroupRec* table, int64_t n_groups,
