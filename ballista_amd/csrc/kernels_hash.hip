@@ -241,42 +241,67 @@ join_build_narrow_kernel(NarrowJoinTable T, const uint32_t* keys, const uint64_t
     }
 }
 
+// PROBE_ROWS rows per lane and pass: the key loads, then the presence-bit loads, of all of them are in flight together
+// (the chain key -> bit -> slot is latency, not bandwidth: one row per pass left the kernel at 1.6 TB/s on Q5's 600 M probes)
+template <int PROBE_ROWS>   // 4: Q3 / Q5 SF100 5.39 / 5.65 ms; 2: 5.40 / 5.73; 8: 5.85 / 6.30 (registers)
 __global__ void __launch_bounds__(BLOCK)
 join_probe_match_narrow_kernel(NarrowJoinTable T, const uint32_t* rkeys, const uint64_t* rsel, const uint32_t* gather,
                                uint32_t n_right, int right_outer, uint32_t* partner, uint64_t* bitmap, uint32_t* tile_counts,
                                uint32_t* matched) {
-    const uint64_t n_round = ((uint64_t)n_right + 63u) & ~(uint64_t)63;
-    for (uint64_t row64 = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; row64 < n_round; row64 += (uint64_t)gridDim.x * BLOCK) {
-        const uint32_t row = (uint32_t)row64;
-        uint32_t m = 0xFFFFFFFFu;
-        const bool in = row64 < n_right;
-        const uint32_t src = (in && gather) ? gather[row] : row;      // probe row -> row of the (unfiltered) key column
-        if (in && bit_at(rsel, src)) {
-            const uint32_t key = rkeys[src];
-            // the exact set of build keys as one bit per value of [kmin, kmin + krange]: a probe that cannot match stops
-            // at a 32x smaller, mostly cache-resident structure and never touches the table
-            bool maybe = true;
-            if (T.present) {
-                const uint32_t d = key - T.kmin;
-                maybe = d <= T.krange && ((T.present[d >> 5] >> (d & 31)) & 1u);
+    static_assert(SEL_TILE % (64 * PROBE_ROWS) == 0, "the rows of one pass of a wave lie in one selection tile");
+    const int lane = threadIdx.x & 63;
+    const uint64_t n_round = ((uint64_t)n_right + 63u) & ~(uint64_t)63;          // rows covered by bitmap words
+    const uint64_t wave_rows = 64ull * PROBE_ROWS;
+    const uint64_t wave_id = (uint64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    const uint64_t n_waves = (uint64_t)gridDim.x * (BLOCK / 64);
+    for (uint64_t wbase = wave_id * wave_rows; wbase < n_round; wbase += n_waves * wave_rows) {
+        uint32_t key[PROBE_ROWS], m[PROBE_ROWS], pbit[PROBE_ROWS];
+        bool in[PROBE_ROWS], live[PROBE_ROWS];
+#pragma unroll
+        for (int k = 0; k < PROBE_ROWS; ++k) {
+            const uint64_t row64 = wbase + 64ull * k + lane;
+            in[k] = row64 < n_right;
+            const uint32_t src = (in[k] && gather) ? gather[(uint32_t)row64] : (uint32_t)row64;   // probe row -> row of the key column
+            live[k] = in[k] && bit_at(rsel, src);
+            key[k] = live[k] ? rkeys[src] : 0u;
+            m[k] = 0xFFFFFFFFu;
+        }
+        // the exact set of build keys as one bit per value of [kmin, kmin + krange]: a probe that cannot match stops
+        // at a 32x smaller, mostly cache-resident structure and never touches the table
+        if (T.present) {
+#pragma unroll
+            for (int k = 0; k < PROBE_ROWS; ++k) {
+                const uint32_t d = key[k] - T.kmin;
+                live[k] = live[k] && d <= T.krange;
+                pbit[k] = live[k] ? (T.present[d >> 5] >> (d & 31)) & 1u : 0u;
             }
-            if (maybe) {
-                uint64_t slot = narrow_hash(key) & T.mask;
+#pragma unroll
+            for (int k = 0; k < PROBE_ROWS; ++k) live[k] = live[k] && pbit[k];
+        }
+#pragma unroll
+        for (int k = 0; k < PROBE_ROWS; ++k) {
+            if (live[k]) {
+                uint64_t slot = narrow_hash(key[k]) & T.mask;
                 for (;;) {
                     const uint64_t v = T.slots[slot];
                     if (v == 0) break;
-                    if ((uint32_t)v == key) { m = (uint32_t)(v >> 32) - 1u; break; }
+                    if ((uint32_t)v == key[k]) { m[k] = (uint32_t)(v >> 32) - 1u; break; }
                     slot = (slot + 1) & T.mask;
                 }
+                if (matched && m[k] != 0xFFFFFFFFu) atomicOr(&matched[m[k] >> 5], 1u << (m[k] & 31));
             }
-            if (matched && m != 0xFFFFFFFFu) atomicOr(&matched[m >> 5], 1u << (m & 31));
         }
-        if (in) partner[row] = m;
-        const uint64_t word = __ballot(in && (right_outer || m != 0xFFFFFFFFu));
-        if ((threadIdx.x & 63) == 0) {
-            bitmap[row64 >> 6] = word;
-            if (word) atomicAdd(&tile_counts[row64 / SEL_TILE], (uint32_t)__popcll(word));
+        uint32_t emitted = 0;
+#pragma unroll
+        for (int k = 0; k < PROBE_ROWS; ++k) {
+            const uint64_t row64 = wbase + 64ull * k + lane;
+            const bool emit = in[k] && (right_outer || m[k] != 0xFFFFFFFFu);
+            if (emit) partner[(uint32_t)row64] = m[k];               // only emitted rows are ever read back (through the index list)
+            const uint64_t word = __ballot(emit);
+            if (lane == 0 && wbase + 64ull * k < n_round) bitmap[(wbase >> 6) + k] = word;
+            emitted += (uint32_t)__popcll(word);
         }
+        if (lane == 0 && emitted) atomicAdd(&tile_counts[wbase / SEL_TILE], emitted);
     }
 }
 
@@ -406,38 +431,62 @@ __global__ void __launch_bounds__(BLOCK)
 join_probe_match_narrow64_kernel(NarrowJoinTable T, const uint64_t* rkeys, const uint64_t* rsel, const uint32_t* gather,
                                  uint32_t n_right, int right_outer, uint32_t* partner, uint64_t* bitmap, uint32_t* tile_counts,
                                  uint32_t* matched) {
+    constexpr int PROBE_ROWS = 4;                                    // as join_probe_match_narrow_kernel
+    static_assert(SEL_TILE % (64 * PROBE_ROWS) == 0, "the rows of one pass of a wave lie in one selection tile");
     const ulonglong2* slots = reinterpret_cast<const ulonglong2*>(T.slots);
+    const int lane = threadIdx.x & 63;
     const uint64_t n_round = ((uint64_t)n_right + 63u) & ~(uint64_t)63;
-    for (uint64_t row64 = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; row64 < n_round; row64 += (uint64_t)gridDim.x * BLOCK) {
-        const uint32_t row = (uint32_t)row64;
-        uint32_t m = 0xFFFFFFFFu;
-        const bool in = row64 < n_right;
-        const uint32_t src = (in && gather) ? gather[row] : row;
-        if (in && bit_at(rsel, src)) {
-            const uint64_t key = rkeys[src];
-            bool maybe = true;
-            if (T.present) {
-                const uint64_t d = key - T.kmin64;
-                maybe = d <= T.krange && ((T.present[d >> 5] >> (d & 31)) & 1u);
+    const uint64_t wave_rows = 64ull * PROBE_ROWS;
+    const uint64_t wave_id = (uint64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    const uint64_t n_waves = (uint64_t)gridDim.x * (BLOCK / 64);
+    for (uint64_t wbase = wave_id * wave_rows; wbase < n_round; wbase += n_waves * wave_rows) {
+        uint64_t key[PROBE_ROWS];
+        uint32_t m[PROBE_ROWS], pbit[PROBE_ROWS];
+        bool in[PROBE_ROWS], live[PROBE_ROWS];
+#pragma unroll
+        for (int k = 0; k < PROBE_ROWS; ++k) {
+            const uint64_t row64 = wbase + 64ull * k + lane;
+            in[k] = row64 < n_right;
+            const uint32_t src = (in[k] && gather) ? gather[(uint32_t)row64] : (uint32_t)row64;
+            live[k] = in[k] && bit_at(rsel, src);
+            key[k] = live[k] ? rkeys[src] : 0ull;
+            m[k] = 0xFFFFFFFFu;
+        }
+        if (T.present) {
+#pragma unroll
+            for (int k = 0; k < PROBE_ROWS; ++k) {
+                const uint64_t d = key[k] - T.kmin64;
+                live[k] = live[k] && d <= T.krange;
+                pbit[k] = live[k] ? (T.present[d >> 5] >> (d & 31)) & 1u : 0u;
             }
-            if (maybe) {
-                uint64_t slot = mix64(key) & T.mask;
+#pragma unroll
+            for (int k = 0; k < PROBE_ROWS; ++k) live[k] = live[k] && pbit[k];
+        }
+#pragma unroll
+        for (int k = 0; k < PROBE_ROWS; ++k) {
+            if (live[k]) {
+                uint64_t slot = mix64(key[k]) & T.mask;
                 for (;;) {
-                    const ulonglong2 v = slots[slot];                    // {key, row1 | pad << 32}
+                    const ulonglong2 v = slots[slot];                // {key, row1 | pad << 32}
                     const uint32_t r = (uint32_t)v.y;
                     if (r == 0) break;
-                    if (v.x == key) { m = r - 1u; break; }
+                    if (v.x == key[k]) { m[k] = r - 1u; break; }
                     slot = (slot + 1) & T.mask;
                 }
+                if (matched && m[k] != 0xFFFFFFFFu) atomicOr(&matched[m[k] >> 5], 1u << (m[k] & 31));
             }
-            if (matched && m != 0xFFFFFFFFu) atomicOr(&matched[m >> 5], 1u << (m & 31));
         }
-        if (in) partner[row] = m;
-        const uint64_t word = __ballot(in && (right_outer || m != 0xFFFFFFFFu));
-        if ((threadIdx.x & 63) == 0) {
-            bitmap[row64 >> 6] = word;
-            if (word) atomicAdd(&tile_counts[row64 / SEL_TILE], (uint32_t)__popcll(word));
+        uint32_t emitted = 0;
+#pragma unroll
+        for (int k = 0; k < PROBE_ROWS; ++k) {
+            const uint64_t row64 = wbase + 64ull * k + lane;
+            const bool emit = in[k] && (right_outer || m[k] != 0xFFFFFFFFu);
+            if (emit) partner[(uint32_t)row64] = m[k];
+            const uint64_t word = __ballot(emit);
+            if (lane == 0 && wbase + 64ull * k < n_round) bitmap[(wbase >> 6) + k] = word;
+            emitted += (uint32_t)__popcll(word);
         }
+        if (lane == 0 && emitted) atomicAdd(&tile_counts[wbase / SEL_TILE], emitted);
     }
 }
 
@@ -538,7 +587,7 @@ hipError_t launch_join_probe_match_narrow(const LaunchCfg& cfg, const NarrowJoin
     hipError_t e = hipMemsetAsync(tile_counts, 0, n_tiles * 4, cfg.stream);
     if (e != hipSuccess) return e;
     if (key_width == 4)
-        hipLaunchKernelGGL(join_probe_match_narrow_kernel, dim3(grid_rows(cfg, n_right)), dim3(BLOCK), 0, cfg.stream, T,
+        hipLaunchKernelGGL(join_probe_match_narrow_kernel<4>, dim3(grid_rows(cfg, n_right)), dim3(BLOCK), 0, cfg.stream, T,
                            (const uint32_t*)rkeys, rsel, gather, n_right, right_outer ? 1 : 0, partner, bitmap, tile_counts, matched);
     else
         hipLaunchKernelGGL(join_probe_match_narrow64_kernel, dim3(grid_rows(cfg, n_right)), dim3(BLOCK), 0, cfg.stream, T,
