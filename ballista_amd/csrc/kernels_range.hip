@@ -9,6 +9,7 @@
 // interface of the expression-VM kernel it stands in for (kernels_scan.hip::scan_pred_bitmap_kernel), so
 // the index pass and the gathers after it are unchanged.  Algorithmic bytes: the predicate columns once
 // (Q6: 28 B/row) + 1 bit/row written.
+#include <type_traits>
 #include "lean_kernel.h"
 
 namespace bhip {
@@ -58,70 +59,87 @@ range_bitmap_kernel(const SopProgram* __restrict__ Sp, uint64_t* bitmap, uint32_
     }
     const uint32_t t8 = (uint32_t)tid * 8u, t16 = (uint32_t)tid * 16u;
 
-    for (int64_t t = blockIdx.x; t < n_tiles; t += grid) {
-        const int64_t row0 = t * RB_TILE;
-        LeanU4 rv[NRANGE][U];
+    // TPI consecutive tiles per pass: every load of the pass is issued before the first comparison (a predicate over one
+    // 4-byte column has only two 8-byte loads per thread and tile, too little in flight to cover HBM latency)
+    auto tiles = [&](auto tpi_c, const int64_t t0) {
+        constexpr int TPI = decltype(tpi_c)::value;
+        LeanU4 rv[TPI][NRANGE][U];
 #pragma unroll
-        for (int p = 0; p < NRANGE; ++p)
-            if (p < n_ranges) {
-                if (r32[p]) {
+        for (int q = 0; q < TPI; ++q) {
+            const int64_t row0 = (t0 + q) * RB_TILE;
 #pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const LeanU2 v = lean_ld2(rp[p] + row0 * 4 + u * (RB_SUB * 4) + t8);
-                        rv[p][u].x = v.x; rv[p][u].y = v.y; rv[p][u].z = 0; rv[p][u].w = 0;
-                    }
-                } else {
+            for (int p = 0; p < NRANGE; ++p)
+                if (p < n_ranges) {
+                    if (r32[p]) {
 #pragma unroll
-                    for (int u = 0; u < U; ++u) rv[p][u] = lean_ld4(rp[p] + row0 * 8 + u * (RB_SUB * 8) + t16);
-                }
-            }
-        bool live[RB_ROWS];
+                        for (int u = 0; u < U; ++u) {
+                            const LeanU2 v = lean_ld2(rp[p] + row0 * 4 + u * (RB_SUB * 4) + t8);
+                            rv[q][p][u].x = v.x; rv[q][p][u].y = v.y; rv[q][p][u].z = 0; rv[q][p][u].w = 0;
+                        }
+                    } else {
 #pragma unroll
-        for (int r = 0; r < RB_ROWS; ++r) live[r] = true;
-#pragma unroll
-        for (int p = 0; p < NRANGE; ++p)
-            if (p < n_ranges) {
-                if (r32[p]) {
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const double a = (double)(int32_t)rv[p][u].x, b = (double)(int32_t)rv[p][u].y;
-                        live[2 * u] = live[2 * u] && a >= rlo[p] && a <= rhi[p];
-                        live[2 * u + 1] = live[2 * u + 1] && b >= rlo[p] && b <= rhi[p];
-                    }
-                } else {
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const double a = u2d(((uint64_t)rv[p][u].y << 32) | rv[p][u].x), b = u2d(((uint64_t)rv[p][u].w << 32) | rv[p][u].z);
-                        live[2 * u] = live[2 * u] && a >= rlo[p] && a <= rhi[p];
-                        live[2 * u + 1] = live[2 * u + 1] && b >= rlo[p] && b <= rhi[p];
+                        for (int u = 0; u < U; ++u) rv[q][p][u] = lean_ld4(rp[p] + row0 * 8 + u * (RB_SUB * 8) + t16);
                     }
                 }
-                if (rvp[p]) {           // the word of rows [64k, 64k + 64) holding this lane's pair (32 lanes share it)
-                    const uint32_t bit = (2u * (uint32_t)tid) & 63u;
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const uint64_t w = rvp[p][(row0 >> 6) + u * (RB_SUB / 64) + (tid >> 5)];
-                        live[2 * u] = live[2 * u] && ((w >> bit) & 1ull);
-                        live[2 * u + 1] = live[2 * u + 1] && ((w >> (bit + 1u)) & 1ull);
-                    }
-                }
-            }
-        // lane l holds rows 2l, 2l+1 of this wave's 128-row span: interleave the two ballots into row order
-        uint32_t cnt = 0;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint64_t b0 = __ballot(live[2 * u]), b1 = __ballot(live[2 * u + 1]);
-            const uint64_t w_lo = spread32(b0) | (spread32(b1) << 1);
-            const uint64_t w_hi = spread32(b0 >> 32) | (spread32(b1 >> 32) << 1);
-            cnt += (uint32_t)(__popcll(b0) + __popcll(b1));
-            if (lane == 0) {
-                uint64_t* out = bitmap + (row0 >> 6) + u * (RB_SUB / 64) + wave * 2;
-                out[0] = w_lo;
-                out[1] = w_hi;
-            }
         }
-        if (lane == 0 && cnt) atomicAdd(&tile_counts[t], cnt);
-    }
+#pragma unroll
+        for (int q = 0; q < TPI; ++q) {
+            const int64_t t = t0 + q;
+            const int64_t row0 = t * RB_TILE;
+            bool live[RB_ROWS];
+#pragma unroll
+            for (int r = 0; r < RB_ROWS; ++r) live[r] = true;
+#pragma unroll
+            for (int p = 0; p < NRANGE; ++p)
+                if (p < n_ranges) {
+                    if (r32[p]) {
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const double a = (double)(int32_t)rv[q][p][u].x, b = (double)(int32_t)rv[q][p][u].y;
+                            live[2 * u] = live[2 * u] && a >= rlo[p] && a <= rhi[p];
+                            live[2 * u + 1] = live[2 * u + 1] && b >= rlo[p] && b <= rhi[p];
+                        }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const double a = u2d(((uint64_t)rv[q][p][u].y << 32) | rv[q][p][u].x),
+                                         b = u2d(((uint64_t)rv[q][p][u].w << 32) | rv[q][p][u].z);
+                            live[2 * u] = live[2 * u] && a >= rlo[p] && a <= rhi[p];
+                            live[2 * u + 1] = live[2 * u + 1] && b >= rlo[p] && b <= rhi[p];
+                        }
+                    }
+                    if (rvp[p]) {           // the word of rows [64k, 64k + 64) holding this lane's pair (32 lanes share it)
+                        const uint32_t bit = (2u * (uint32_t)tid) & 63u;
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const uint64_t w = rvp[p][(row0 >> 6) + u * (RB_SUB / 64) + (tid >> 5)];
+                            live[2 * u] = live[2 * u] && ((w >> bit) & 1ull);
+                            live[2 * u + 1] = live[2 * u + 1] && ((w >> (bit + 1u)) & 1ull);
+                        }
+                    }
+                }
+            // lane l holds rows 2l, 2l+1 of this wave's 128-row span: interleave the two ballots into row order
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint64_t b0 = __ballot(live[2 * u]), b1 = __ballot(live[2 * u + 1]);
+                const uint64_t w_lo = spread32(b0) | (spread32(b1) << 1);
+                const uint64_t w_hi = spread32(b0 >> 32) | (spread32(b1 >> 32) << 1);
+                cnt += (uint32_t)(__popcll(b0) + __popcll(b1));
+                if (lane == 0) {
+                    uint64_t* out = bitmap + (row0 >> 6) + u * (RB_SUB / 64) + wave * 2;
+                    out[0] = w_lo;
+                    out[1] = w_hi;
+                }
+            }
+            if (lane == 0 && cnt) atomicAdd(&tile_counts[t], cnt);
+        }
+    };
+    constexpr int TPI_MAIN = NRANGE == 1 ? 4 : 1;
+    const int64_t n_packs = n_tiles / TPI_MAIN;                       // packs of TPI_MAIN full tiles, then the full tiles left over
+    for (int64_t g = blockIdx.x; g < n_packs; g += grid) tiles(std::integral_constant<int, TPI_MAIN>{}, g * TPI_MAIN);
+    if (TPI_MAIN > 1)
+        for (int64_t t = n_packs * TPI_MAIN + blockIdx.x; t < n_tiles; t += grid) tiles(std::integral_constant<int, 1>{}, t);
 
     // ragged tail (< 1024 rows): one row per lane, the ballot is already in row order
     if ((int64_t)blockIdx.x == n_tiles % grid && n_tiles * RB_TILE < n_rows) {
@@ -148,6 +166,74 @@ range_bitmap_kernel(const SopProgram* __restrict__ Sp, uint64_t* bitmap, uint32_
     }
 }
 
+// ---- ONE range over ONE Int32 / Date32 column (l_shipdate > d, o_orderdate in [a, b) ...) -----------------------------------
+// The kernel above is instruction-bound there (2.7 TB/s on Q3's 600 M-row filter: int -> double conversions and the bit
+// interleave of the row-pair mapping per 4 bytes of input).  Here a lane owns rows base + 64 k + lane, so a ballot IS a
+// bitmap word, the bounds are integers, and R32_ROWS loads per lane are in flight before the first comparison.
+constexpr int R32_ROWS = 8;
+__global__ void __launch_bounds__(BLOCK)
+range_bitmap32_kernel(const int32_t* __restrict__ col, const uint64_t* __restrict__ validity, int32_t lo, int32_t hi, int64_t n_rows,
+                      uint64_t* bitmap, uint32_t* tile_counts) {
+    static_assert(SEL_TILE % (64 * R32_ROWS) == 0, "the rows of one pass of a wave lie in one selection tile");
+    const int lane = threadIdx.x & 63;
+    const int64_t chunk_rows = 64 * R32_ROWS;
+    const int64_t n_chunks = (n_rows + chunk_rows - 1) / chunk_rows;
+    const int64_t n_words = (n_rows + 63) / 64;
+    const int64_t n_waves = (int64_t)gridDim.x * (BLOCK / 64);
+    for (int64_t c = (int64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); c < n_chunks; c += n_waves) {
+        const int64_t base = c * chunk_rows;
+        int32_t x[R32_ROWS];
+        if (base + chunk_rows <= n_rows) {
+#pragma unroll
+            for (int k = 0; k < R32_ROWS; ++k) x[k] = col[base + 64 * k + lane];
+        } else {
+#pragma unroll
+            for (int k = 0; k < R32_ROWS; ++k) {
+                const int64_t row = base + 64 * k + lane;
+                x[k] = row < n_rows ? col[row] : 0;                  // rows past the end are masked in the ballot
+            }
+        }
+        uint64_t mine = 0;                                           // lane k keeps word k
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int k = 0; k < R32_ROWS; ++k) {
+            const int64_t row = base + 64 * k + lane;
+            uint64_t word = __ballot(row < n_rows && x[k] >= lo && x[k] <= hi);
+            const int64_t wi = (base >> 6) + k;
+            if (validity != nullptr && wi < n_words) word &= validity[wi];
+            cnt += (uint32_t)__popcll(word);
+            if (lane == k) mine = word;
+        }
+        if (lane < R32_ROWS && (base >> 6) + lane < n_words) bitmap[(base >> 6) + lane] = mine;
+        if (lane == 0 && cnt) atomicAdd(&tile_counts[base / SEL_TILE], cnt);
+    }
+}
+
+// the integer image of a double range [lo, hi] over Int32 values (empty: lo > hi)
+static void int_bounds(double lo, double hi, int32_t* lo_i, int32_t* hi_i) {
+    *lo_i = 1; *hi_i = 0;
+    if (lo != lo || hi != hi || lo > 2147483647.0 || hi < -2147483648.0) return;
+    const double l = __builtin_ceil(lo), h = __builtin_floor(hi);
+    *lo_i = l <= -2147483648.0 ? (int32_t)(-2147483647 - 1) : (int32_t)l;
+    *hi_i = h >= 2147483647.0 ? (int32_t)2147483647 : (int32_t)h;
+}
+
+static hipError_t launch_range32(const LaunchCfg& cfg, const SopProgram& S, uint64_t* bitmap, uint32_t* tile_counts) {
+    const int64_t n_tiles = (S.n_rows + SEL_TILE - 1) / SEL_TILE;
+    hipError_t e = hipMemsetAsync(tile_counts, 0, (size_t)n_tiles * 4, cfg.stream);
+    if (e != hipSuccess) return e;
+    int32_t lo, hi;
+    int_bounds(S.ranges[0].lo, S.ranges[0].hi, &lo, &hi);
+    const SopColumn& c = S.cols[S.ranges[0].col];
+    const int64_t n_chunks = (S.n_rows + 64 * R32_ROWS - 1) / (64 * R32_ROWS);
+    int64_t grid = (int64_t)cfg.device_cus * 8;
+    if (grid > (n_chunks + BLOCK / 64 - 1) / (BLOCK / 64)) grid = (n_chunks + BLOCK / 64 - 1) / (BLOCK / 64);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(range_bitmap32_kernel, dim3((unsigned)grid), dim3(BLOCK), 0, cfg.stream, (const int32_t*)c.data,
+                       (const uint64_t*)c.validity, lo, hi, S.n_rows, bitmap, tile_counts);
+    return hipGetLastError();
+}
+
 template <int NRANGE>
 static hipError_t launch_range_t(const LaunchCfg& cfg, const SopProgram& S, SopProgram* dprog, uint64_t* bitmap, uint32_t* tile_counts) {
     auto k = range_bitmap_kernel<NRANGE>;
@@ -165,6 +251,7 @@ static hipError_t launch_range_t(const LaunchCfg& cfg, const SopProgram& S, SopP
 
 hipError_t launch_range_bitmap(const LaunchCfg& cfg, const SopProgram& S, SopProgram* dprog, uint64_t* bitmap, uint32_t* tile_counts) {
     if (S.n_rows == 0) return hipSuccess;
+    if (S.n_ranges == 1 && S.ranges[0].is32) return launch_range32(cfg, S, bitmap, tile_counts);
     return S.n_ranges <= 1 ? launch_range_t<1>(cfg, S, dprog, bitmap, tile_counts) : launch_range_t<4>(cfg, S, dprog, bitmap, tile_counts);
 }
 

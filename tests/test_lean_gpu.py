@@ -228,3 +228,24 @@ def test_all_valid_bitmaps_are_dropped_at_import_and_take_the_fast_kernels():
                                  ba.FilterExec(E.coerce(col("d") <= E.date32("1998-09-02"), SCHEMA), helpers.memory_exec(c, [[b2]])))
     got2 = helpers.concat(helpers.collect_product(part2))
     helpers.assert_rows_equal(got2, plan_eval.collect(part2), ordered=False, float_rtol=RTOL, key_cols=["ks"])
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 511, 512, 513, 1024, 1025, 4097, 70_001])
+def test_single_int32_range_filter(n):
+    """one range over one Int32 / Date32 column takes range_bitmap32_kernel (kernels_range.hip): integer bounds, a
+    ballot per 64 rows, eight rows per lane; row set and order exact, with and without NULLs, at every ragged size"""
+    c = ba.Context(0)
+    rng = np.random.default_rng(n)
+    b = OrderedDict([("i", OCol("Int32", rng.integers(-100, 100, n), rng.random(n) > 0.2)),
+                     ("d", OCol("Date32", rng.integers(8000, 11000, n))),
+                     ("e", OCol("Int32", np.where(rng.random(n) < 0.1, 2 ** 31 - 1, np.where(rng.random(n) < 0.1, -2 ** 31, rng.integers(-5, 5, n))))),
+                     ("v", OCol("Float64", rng.random(n)))])
+    schema = {"i": E.INT32, "d": E.DATE32, "e": E.INT32, "v": E.FLOAT64}
+    preds = [col("d") > E.date32("1995-03-15"), col("d") <= E.date32("1992-01-01"),
+             (col("d") >= E.date32("1994-01-01")).and_(col("d") < E.date32("1995-01-01")),
+             col("i") >= lit(10, E.INT32), (col("i") > lit(5, E.INT32)).and_(col("i") < lit(3, E.INT32)),      # NULLs; empty range
+             col("e") >= lit(2 ** 31 - 1, E.INT32), col("e") <= lit(-2 ** 31, E.INT32), col("e") > lit(-2 ** 31, E.INT32),
+             col("i").eq(lit(7, E.INT32))]
+    for pred in preds:
+        flt = ba.FilterExec(E.coerce(pred, schema), helpers.memory_exec(c, [[b]]))
+        helpers.assert_rows_equal(helpers.concat(helpers.collect_product(flt)), plan_eval.collect(flt), ordered=True)
