@@ -278,15 +278,21 @@ join_probe_match_narrow_kernel(NarrowJoinTable T, const uint32_t* rkeys, const u
 #pragma unroll
             for (int k = 0; k < PROBE_ROWS; ++k) live[k] = live[k] && pbit[k];
         }
+        // the first slot of every live row is loaded before any is looked at; only collisions walk on
+        uint64_t slot[PROBE_ROWS], v[PROBE_ROWS];
+#pragma unroll
+        for (int k = 0; k < PROBE_ROWS; ++k) {
+            slot[k] = narrow_hash(key[k]) & T.mask;
+            v[k] = live[k] ? T.slots[slot[k]] : 0ull;
+        }
 #pragma unroll
         for (int k = 0; k < PROBE_ROWS; ++k) {
             if (live[k]) {
-                uint64_t slot = narrow_hash(key[k]) & T.mask;
                 for (;;) {
-                    const uint64_t v = T.slots[slot];
-                    if (v == 0) break;
-                    if ((uint32_t)v == key[k]) { m[k] = (uint32_t)(v >> 32) - 1u; break; }
-                    slot = (slot + 1) & T.mask;
+                    if (v[k] == 0) break;
+                    if ((uint32_t)v[k] == key[k]) { m[k] = (uint32_t)(v[k] >> 32) - 1u; break; }
+                    slot[k] = (slot[k] + 1) & T.mask;
+                    v[k] = T.slots[slot[k]];
                 }
                 if (matched && m[k] != 0xFFFFFFFFu) atomicOr(&matched[m[k] >> 5], 1u << (m[k] & 31));
             }
@@ -462,16 +468,22 @@ join_probe_match_narrow64_kernel(NarrowJoinTable T, const uint64_t* rkeys, const
 #pragma unroll
             for (int k = 0; k < PROBE_ROWS; ++k) live[k] = live[k] && pbit[k];
         }
+        uint64_t slot[PROBE_ROWS];
+        ulonglong2 v[PROBE_ROWS];                                    // {key, row1 | pad << 32}
+#pragma unroll
+        for (int k = 0; k < PROBE_ROWS; ++k) {
+            slot[k] = mix64(key[k]) & T.mask;
+            v[k] = live[k] ? slots[slot[k]] : ulonglong2{0ull, 0ull};
+        }
 #pragma unroll
         for (int k = 0; k < PROBE_ROWS; ++k) {
             if (live[k]) {
-                uint64_t slot = mix64(key[k]) & T.mask;
                 for (;;) {
-                    const ulonglong2 v = slots[slot];                // {key, row1 | pad << 32}
-                    const uint32_t r = (uint32_t)v.y;
+                    const uint32_t r = (uint32_t)v[k].y;
                     if (r == 0) break;
-                    if (v.x == key[k]) { m[k] = r - 1u; break; }
-                    slot = (slot + 1) & T.mask;
+                    if (v[k].x == key[k]) { m[k] = r - 1u; break; }
+                    slot[k] = (slot[k] + 1) & T.mask;
+                    v[k] = slots[slot[k]];
                 }
                 if (matched && m[k] != 0xFFFFFFFFu) atomicOr(&matched[m[k] >> 5], 1u << (m[k] & 31));
             }
