@@ -146,7 +146,10 @@ def all_gather_batches(dist, batch, device="cpu", slot_bytes=SLOT_BYTES):
     dist   : an initialised torch.distributed module ("nccl" = RCCL on the GPU box, "gloo" on CPU)
     device : where the exchange buffers live ("cuda:N" for RCCL)."""
     import torch
+    world = dist.get_world_size()
     buf = torch.from_numpy(pack_batch(batch, slot_bytes)).to(device)
-    out = [torch.empty_like(buf) for _ in range(dist.get_world_size())]
-    dist.all_gather(out, buf)
-    return [unpack_batch(t.cpu().numpy()) for t in out]
+    # one output tensor, one copy back to the host (a list of per-rank tensors costs a device-to-host copy per rank)
+    out = torch.empty(world * buf.numel(), dtype=buf.dtype, device=device)
+    dist.all_gather_into_tensor(out, buf)
+    host = out.cpu().numpy().reshape(world, buf.numel())
+    return [unpack_batch(host[r]) for r in range(world)]
