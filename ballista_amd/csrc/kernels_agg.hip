@@ -333,26 +333,25 @@ merge_assign_kernel(const GroupRec* partials, const uint32_t* partial_ng, int n_
     }
 }
 
-// Step 2: one wave per (group, accumulator): lanes stride over the partial records in record
-// order, then a fixed shuffle tree => deterministic.
+// Step 2: one workgroup per (group, accumulator): threads stride over the partial records in record order, a fixed
+// shuffle tree per wave, then the four wave results in wave order => deterministic.
 struct MergeAccSpecs { AccSpec acc[VM_MAX_ACC]; int n_acc; };
 
 __global__ void __launch_bounds__(BLOCK)
 merge_reduce_kernel(const GroupRec* partials, const uint32_t* entry_group, int n_entries,
                     MergeAccSpecs specs, GroupRec* table, const ScanStatus* status) {
+    __shared__ uint64_t s_v[BLOCK / 64], s_nv[BLOCK / 64];
     const int n_groups = (int)status->n_groups;
     const int per_group = specs.n_acc + 1;       // + rows
     const int n_pairs = n_groups * per_group;
-    const int lane = threadIdx.x & 63;
-    const int wave_global = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
-    const int n_waves = gridDim.x * (BLOCK / 64);
-    for (int pair = wave_global; pair < n_pairs; pair += n_waves) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
         const int g = pair / per_group, a = pair % per_group;
         const bool is_rows = (a == specs.n_acc);
         const int kind = is_rows ? (int)ACC_COUNT_ROWS : (int)specs.acc[a].kind;
         uint64_t v = is_rows ? 0 : acc_identity(kind);
         uint64_t nv = 0;
-        for (int e = lane; e < n_entries; e += 64) {
+        for (int e = threadIdx.x; e < n_entries; e += BLOCK) {
             if (entry_group[e] == (uint32_t)g) {
                 if (is_rows) v += partials[e].rows;
                 else {
@@ -363,10 +362,18 @@ merge_reduce_kernel(const GroupRec* partials, const uint32_t* entry_group, int n
         }
         v = wave_reduce(v, kind);
         nv = wave_reduce(nv, ACC_COUNT_ROWS);
-        if (lane == 0) {
-            if (is_rows) table[g].rows = v;
-            else { table[g].acc[a] = v; table[g].nvalid[a] = nv; }
+        if (lane == 0) { s_v[wave] = v; s_nv[wave] = nv; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t tv = s_v[0], tn = s_nv[0];
+            for (int w = 1; w < BLOCK / 64; ++w) {
+                tv = is_rows ? tv + s_v[w] : acc_combine(tv, s_v[w], kind);
+                tn += s_nv[w];
+            }
+            if (is_rows) table[g].rows = tv;
+            else { table[g].acc[a] = tv; table[g].nvalid[a] = tn; }
         }
+        __syncthreads();
     }
 }
 
@@ -442,7 +449,7 @@ hipError_t launch_merge_partials(const LaunchCfg& cfg, const GroupRec* partials,
     MergeAccSpecs specs;
     specs.n_acc = n_acc;
     for (int i = 0; i < VM_MAX_ACC; ++i) specs.acc[i] = i < n_acc ? acc_host[i] : AccSpec{ACC_COUNT_ROWS, 0, {0, 0}};
-    hipLaunchKernelGGL(merge_reduce_kernel, dim3(64), dim3(BLOCK), 0, cfg.stream, partials, entry_group,
+    hipLaunchKernelGGL(merge_reduce_kernel, dim3(256), dim3(BLOCK), 0, cfg.stream, partials, entry_group,
                        n_part * gmax, specs, table, status);
     return hipGetLastError();
 }
