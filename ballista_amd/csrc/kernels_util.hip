@@ -100,30 +100,36 @@ scan_apply_kernel(const uint32_t* in, int64_t n, const uint64_t* chunk_offsets, 
     }
 }
 
-// n <= SCAN_CHUNK: the whole scan in one workgroup and one launch (group tables, small gathers: a Q1 step runs eight of these)
+// n <= SCAN_ONE_LAUNCH_MAX: the whole scan by ONE workgroup in one launch, chunk after chunk with a running carry (group
+// tables, small gathers: three launches cost more than the serial walk)
+constexpr int64_t SCAN_ONE_LAUNCH_MAX = 8 * (int64_t)SCAN_CHUNK;    // ~3 us per serial chunk against ~10 us per extra launch
 template <class OutT>
 __global__ void __launch_bounds__(SCAN_BLOCK)
 scan_one_chunk_kernel(const uint32_t* in, int64_t n, OutT* out, int write_total, uint64_t* total_out) {
     __shared__ uint64_t s_wave[4];
-    uint32_t x[SCAN_ITEMS];
-    uint64_t sum = 0;
+    uint64_t carry = 0;
+    for (int64_t base = 0; base < n; base += SCAN_CHUNK) {
+        uint32_t x[SCAN_ITEMS];
+        uint64_t sum = 0;
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
-        const int64_t j = (int64_t)threadIdx.x * SCAN_ITEMS + i;
-        x[i] = j < n ? in[j] : 0;
-        sum += x[i];
-    }
-    uint64_t tot;
-    uint64_t run = block_exclusive_scan(sum, s_wave, &tot);
+        for (int i = 0; i < SCAN_ITEMS; ++i) {
+            const int64_t j = base + (int64_t)threadIdx.x * SCAN_ITEMS + i;
+            x[i] = j < n ? in[j] : 0;
+            sum += x[i];
+        }
+        uint64_t tot;
+        uint64_t run = carry + block_exclusive_scan(sum, s_wave, &tot);
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
-        const int64_t j = (int64_t)threadIdx.x * SCAN_ITEMS + i;
-        if (j < n) out[j] = (OutT)run;
-        run += x[i];
+        for (int i = 0; i < SCAN_ITEMS; ++i) {
+            const int64_t j = base + (int64_t)threadIdx.x * SCAN_ITEMS + i;
+            if (j < n) out[j] = (OutT)run;
+            run += x[i];
+        }
+        carry += tot;
     }
     if (threadIdx.x == 0) {
-        if (write_total) out[n] = (OutT)tot;
-        if (total_out) *total_out = tot;
+        if (write_total) out[n] = (OutT)carry;
+        if (total_out) *total_out = carry;
     }
 }
 
@@ -143,7 +149,7 @@ static hipError_t exclusive_scan_t(hipStream_t st, const uint32_t* in, int64_t n
         if (e == hipSuccess && write_total) e = hipMemsetAsync(out, 0, sizeof(OutT), st);
         return e;
     }
-    if (n_chunks == 1) {
+    if (n <= SCAN_ONE_LAUNCH_MAX) {
         hipLaunchKernelGGL((scan_one_chunk_kernel<OutT>), dim3(1), dim3(SCAN_BLOCK), 0, st, in, n, out, write_total ? 1 : 0, total_out);
         return hipGetLastError();
     }
