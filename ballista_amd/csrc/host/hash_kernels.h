@@ -35,7 +35,7 @@ hipError_t launch_wide_key_assign(const LaunchCfg& cfg, const WideKeyCols& K, co
 
 // ---- join -------------------------------------------------------------------------------------
 struct JoinTable {
-    uint32_t* owner;          // [capacity] id+1 of the build row whose key defines the slot
+    uint64_t* owner;          // [capacity] (id+1 of the build row whose key defines the slot) | (high half of the key hash) << 32
     uint32_t* head;           // [capacity] id+1 of the most recently inserted build row of the slot's key
     uint32_t* next;           // [n_left]   id+1 of the next build row with the same key
     uint64_t mask;

@@ -228,12 +228,12 @@ std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) co
         bs->slots.reset();
     }
     side_keys(ex, *bs->batch, lcols, bs->keys, bs->sel, bs->has_sel);
-    bs->owner = make_buffer(ex, cap * 4);
+    bs->owner = make_buffer(ex, cap * 8);
     bs->head = make_buffer(ex, cap * 4);
     bs->next = make_buffer(ex, (size_t)(n + 1) * 4);
-    HIP_CHECK(hipMemsetAsync(bs->owner->ptr(), 0, cap * 4, ex.stream));
+    HIP_CHECK(hipMemsetAsync(bs->owner->ptr(), 0, cap * 8, ex.stream));
     HIP_CHECK(hipMemsetAsync(bs->head->ptr(), 0, cap * 4, ex.stream));
-    bs->table.owner = bs->owner->as<uint32_t>();
+    bs->table.owner = bs->owner->as<uint64_t>();
     bs->table.head = bs->head->as<uint32_t>();
     bs->table.next = bs->next->as<uint32_t>();
     bs->table.mask = cap - 1;
