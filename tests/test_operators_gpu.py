@@ -368,6 +368,22 @@ def test_sort(ctx, si):
     run_both(plan, ordered=True)      # both sorts are stable, so even ties line up
 
 
+@pytest.mark.parametrize("n", [700, 5000])
+def test_sort_by_long_strings(ctx, n):
+    """Utf8 sort keys of any length (here up to 90 bytes, sharing long prefixes, with NULLs and empty strings): one
+    stable pass per 8-byte chunk from the last to the first, then the length; small (one-launch) and radix paths"""
+    from collections import OrderedDict
+    rng = np.random.default_rng(n)
+    stems = ["", "x", "Customer#000000", "carefully final deposits detect slyly agai", "carefully final deposits detect slyly agai" * 2]
+    vals = [stems[int(rng.integers(0, len(stems)))] + "".join(chr(int(c)) for c in rng.integers(97, 100, int(rng.integers(0, 7)))) for _ in range(n)]
+    b = OrderedDict([("s", OCol("Utf8", vals, rng.random(n) > 0.1)), ("k", OCol("Int32", rng.integers(0, 5, n))),
+                     ("v", OCol("Float64", rng.random(n)))])
+    m = helpers.memory_exec(ctx, [[b]])
+    for desc in (False, True):
+        run_both(ba.SortExec([E.PhysicalSortExpr(col("s"), descending=desc, nulls_first=desc)], m), ordered=True)
+    run_both(ba.SortExec([E.PhysicalSortExpr(col("k")), E.PhysicalSortExpr(col("s"), descending=True)], m), ordered=True)
+
+
 def test_sort_requires_single_partition(ctx):
     b = random_batch(10)
     with pytest.raises(ba.PlanError, match="single input partition"):
