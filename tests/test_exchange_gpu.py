@@ -50,6 +50,13 @@ plan = ba.HashAggregateExec(ba.plan.PARTIAL, [], [E.Sum(col("a"), "s"), E.Count(
 helpers.assert_rows_equal(helpers.concat(helpers.collect_product(plan)), plan_eval.collect(plan), ordered=False, float_rtol=1e-9)
 empty = ba.plan.hash_partition(helpers.to_device(ctx, helpers.slice_batch(t, 0, 0)), [col("k")], 1)
 assert all_to_all_device(dist, empty, ctx, "cuda:0").num_rows == 0      # an empty partition travels too
+# the bench's exchange (bench.py --gpus N): one RCCL all_gather of the packed partial-state batches, device buffers
+import pyarrow as pa
+from ballista_amd.exchange import all_gather_batches
+state = pa.RecordBatch.from_arrays([pa.array(["A", "N", "R"]), pa.array([1.5, 2.5, 3.5]), pa.array([7, 8, 9], pa.uint64())],
+                                   names=["l_returnflag", "sum_qty[sum]", "count_order[count]"])
+back = all_gather_batches(dist, state, device="cuda:0")
+assert len(back) == 1 and back[0].equals(state)
 dist.destroy_process_group()
 print("EXCHANGE OK")
 '''
