@@ -525,22 +525,16 @@ join_probe_match_narrow64_kernel(NarrowJoinTable T, const uint64_t* rkeys, const
 #pragma unroll
             for (int k = 0; k < PROBE_ROWS; ++k) live[k] = live[k] && pbit[k];
         }
-        uint64_t slot[PROBE_ROWS];
-        ulonglong2 v[PROBE_ROWS];                                    // {key, row1 | pad << 32}
-#pragma unroll
-        for (int k = 0; k < PROBE_ROWS; ++k) {
-            slot[k] = mix64(key[k]) & T.mask;
-            v[k] = live[k] ? slots[slot[k]] : ulonglong2{0ull, 0ull};
-        }
 #pragma unroll
         for (int k = 0; k < PROBE_ROWS; ++k) {
             if (live[k]) {
+                uint64_t slot = mix64(key[k]) & T.mask;
                 for (;;) {
-                    const uint32_t r = (uint32_t)v[k].y;
+                    const ulonglong2 v = slots[slot];                // {key, row1 | pad << 32}
+                    const uint32_t r = (uint32_t)v.y;
                     if (r == 0) break;
-                    if (v[k].x == key[k]) { m[k] = r - 1u; break; }
-                    slot[k] = (slot[k] + 1) & T.mask;
-                    v[k] = slots[slot[k]];
+                    if (v.x == key[k]) { m[k] = r - 1u; break; }
+                    slot = (slot + 1) & T.mask;
                 }
                 if (matched && m[k] != 0xFFFFFFFFu) atomicOr(&matched[m[k] >> 5], 1u << (m[k] & 31));
             }
