@@ -380,7 +380,15 @@ join_key_minmax_kernel(const int32_t* keys, const uint64_t* sel, uint32_t n, int
         lo = l2 < lo ? l2 : lo;
         hi = h2 > hi ? h2 : hi;
     }
-    if ((threadIdx.x & 63) == 0) { atomicMin(&mm[0], lo); atomicMax(&mm[1], hi); }
+    // one pair of atomics per workgroup (same-address atomics serialise: thousands of them cost more than the scan of the keys)
+    __shared__ int32_t s_lo[BLOCK / 64], s_hi[BLOCK / 64];
+    if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < BLOCK / 64; ++w) { lo = s_lo[w] < lo ? s_lo[w] : lo; hi = s_hi[w] > hi ? s_hi[w] : hi; }
+        atomicMin(&mm[0], lo);
+        atomicMax(&mm[1], hi);
+    }
 }
 
 // 64-bit keys: mm[0] = min, mm[1] = max of key ^ 2^63 (signed order as unsigned; seeded with ~0 / 0)
@@ -396,7 +404,14 @@ join_key_minmax64_kernel(const uint64_t* keys, const uint64_t* sel, uint32_t n, 
         lo = l2 < lo ? l2 : lo;
         hi = h2 > hi ? h2 : hi;
     }
-    if ((threadIdx.x & 63) == 0) { atomicMin(&mm[0], (unsigned long long)lo); atomicMax(&mm[1], (unsigned long long)hi); }
+    __shared__ uint64_t s_lo[BLOCK / 64], s_hi[BLOCK / 64];
+    if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < BLOCK / 64; ++w) { lo = s_lo[w] < lo ? s_lo[w] : lo; hi = s_hi[w] > hi ? s_hi[w] : hi; }
+        atomicMin(&mm[0], (unsigned long long)lo);
+        atomicMax(&mm[1], (unsigned long long)hi);
+    }
 }
 
 __global__ void __launch_bounds__(BLOCK)
