@@ -72,6 +72,7 @@ SYMBOLS = {
     "bhip_ctx_memory": (C.c_int32, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "bhip_ctx_kernel_time": (C.c_int32, [_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "bhip_ctx_kernel_name": (C.c_char_p, [_P]),
+    "bhip_ctx_kernel_stats": (C.c_int32, [_P, C.c_int32, C.c_char_p, C.c_size_t]),
     "bhip_batch_from_host": (C.c_int32, [_P, C.c_int32, C.POINTER(ColumnDesc), C.c_int64, _PP]),
     "bhip_batch_from_device": (C.c_int32, [_P, C.c_int32, C.POINTER(ColumnDesc), C.c_int64, _PP]),
     "bhip_batch_from_tbl": (C.c_int32, [_P, _P, C.c_int64, C.c_int32, C.POINTER(ColumnDesc), C.c_int32, C.POINTER(C.c_int32), _PP]),

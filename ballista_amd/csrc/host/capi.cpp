@@ -76,6 +76,21 @@ bhip_status bhip_ctx_kernel_time(bhip_ctx* ctx, int32_t reset, double* ms, uint6
     BHIP_API_END
 }
 
+bhip_status bhip_ctx_kernel_stats(bhip_ctx* ctx, int32_t reset, char* buf, size_t cap) {
+    BHIP_API_BEGIN
+    need(ctx, "ctx"); need(buf, "buf");
+    ctx->p->set_device();
+    std::string text;
+    for (auto& kv : ctx->p->kernel_stats(reset != 0)) {
+        char line[256];
+        snprintf(line, sizeof line, "%s\t%.6f\t%llu\n", kv.first.c_str(), kv.second.ms, (unsigned long long)kv.second.launches);
+        text += line;
+    }
+    if (text.size() + 1 > cap) fail(BHIP_EINVAL, "bhip_ctx_kernel_stats: buffer too small");
+    memcpy(buf, text.c_str(), text.size() + 1);
+    BHIP_API_END
+}
+
 const char* bhip_ctx_kernel_name(bhip_ctx* ctx) {
     static thread_local std::string name;
     name = ctx ? ctx->p->kernel_name() : std::string();

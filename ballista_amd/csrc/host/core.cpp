@@ -59,6 +59,8 @@ Context::~Context() {
     }
     for (auto& kv : live_) hipFree(kv.second.ptr);
     for (auto s : stream_pool_) hipStreamDestroy(s);
+    for (auto& p : pending_timed_) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+    for (auto e : event_pool_) hipEventDestroy(e);
 }
 
 static size_t round_size(size_t bytes) {
@@ -163,7 +165,50 @@ void Context::add_kernel_time(double ms, uint64_t launches, const char* kernel) 
     std::lock_guard<std::mutex> g(mu_);
     k_ms_ += ms;
     k_launches_ += launches;
-    if (kernel && launches) k_name_ = kernel;
+    if (kernel && launches) {
+        k_name_ = kernel;
+        auto& st = k_stats_[kernel];
+        st.ms += ms;
+        st.launches += launches;
+    }
+}
+
+hipEvent_t Context::timing_event() {
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        if (!event_pool_.empty()) {
+            hipEvent_t e = event_pool_.back();
+            event_pool_.pop_back();
+            return e;
+        }
+    }
+    hipEvent_t e = nullptr;
+    hipEventCreate(&e);
+    return e;
+}
+
+void Context::push_timed(hipEvent_t a, hipEvent_t b, const char* name) {
+    std::lock_guard<std::mutex> g(mu_);
+    pending_timed_.push_back({a, b, name});
+}
+
+std::map<std::string, Context::KernelStat> Context::kernel_stats(bool reset) {
+    std::lock_guard<std::mutex> g(mu_);
+    std::vector<PendingTimed> keep;
+    for (auto& p : pending_timed_) {
+        float t = 0;
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&t, p.a, p.b) == hipSuccess) {
+            auto& st = k_stats_[p.name];
+            st.ms += t;
+            st.launches += 1;
+        }
+        event_pool_.push_back(p.a);
+        event_pool_.push_back(p.b);
+    }
+    pending_timed_.clear();
+    auto out = k_stats_;
+    if (reset) k_stats_.clear();
+    return out;
 }
 
 std::string Context::kernel_name() {

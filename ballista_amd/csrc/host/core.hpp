@@ -74,6 +74,11 @@ public:
     std::string kernel_name();
     void kernel_time(bool reset, double* ms, uint64_t* launches);
     bool timing_enabled() const { return timing_; }
+    // per-kernel-name totals (BHIP_KERNEL_TIMING=1): event pairs queued by KernelTimer are resolved when read
+    struct KernelStat { double ms = 0; uint64_t launches = 0; };
+    void push_timed(hipEvent_t a, hipEvent_t b, const char* name);
+    hipEvent_t timing_event();
+    std::map<std::string, KernelStat> kernel_stats(bool reset);
 
 private:
     int device_;
@@ -87,6 +92,10 @@ private:
     double k_ms_ = 0;
     uint64_t k_launches_ = 0;
     std::string k_name_;
+    struct PendingTimed { hipEvent_t a, b; const char* name; };
+    std::vector<PendingTimed> pending_timed_;
+    std::vector<hipEvent_t> event_pool_;
+    std::map<std::string, KernelStat> k_stats_;
 };
 using ContextPtr = std::shared_ptr<Context>;
 
@@ -96,6 +105,29 @@ struct Exec {
     hipStream_t stream;
     LaunchCfg cfg() const { return LaunchCfg{ctx->cus(), stream}; }
 };
+
+// times the launches enqueued on ex.stream during its lifetime under `name` (no-op unless BHIP_KERNEL_TIMING=1);
+// nothing waits here: the event pair is read when the statistics are (bhip_ctx_kernel_stats)
+struct KernelTimer {
+    const Exec& ex;
+    const char* name;
+    hipEvent_t a = nullptr, b = nullptr;
+    KernelTimer(const Exec& e, const char* n) : ex(e), name(n) {
+        if (!ex.ctx->timing_enabled()) return;
+        a = ex.ctx->timing_event();
+        b = ex.ctx->timing_event();
+        hipEventRecord(a, ex.stream);
+    }
+    void stop() {
+        if (!a) return;
+        hipEventRecord(b, ex.stream);
+        ex.ctx->push_timed(a, b, name);
+        a = b = nullptr;
+    }
+    ~KernelTimer() { stop(); }
+};
+
+#define TIMED_LAUNCH(ex, name, call) do { ::bhip::KernelTimer _kt((ex), (name)); HIP_CHECK(call); } while (0)
 
 // ---- device buffers -----------------------------------------------------------------------------
 constexpr size_t BUFFER_SLACK = 16;

@@ -189,14 +189,14 @@ GroupRec* hash_aggregate(const Exec& ex, Temp& tmp, const ScanParams& P0, const 
     if (nullable) HIP_CHECK(hipMemsetAsync(T.nvalid, 0, cap * n_acc * 8, ex.stream));
     MergeAccKinds kinds;
     for (int i = 0; i < VM_MAX_ACC; ++i) kinds.kind[i] = i < P0.n_acc ? P0.acc[i].kind : (uint8_t)ACC_COUNT_ROWS;
-    if (P0.n_acc > 0) HIP_CHECK(launch_hash_agg_init(cfg, T, kinds));
+    if (P0.n_acc > 0) TIMED_LAUNCH(ex, "hash_agg_init", launch_hash_agg_init(cfg, T, kinds));
     HIP_CHECK(hipMemsetAsync(status, 0, sizeof(ScanStatus), ex.stream));
     uint32_t row_base = 0;
     for (auto& b : inputs) {
         ScanParams P = P0;
         ProgramBuilder::bind(P, pb.columns(), *b, nullable);
-        HIP_CHECK(launch_scan_keys(cfg, P, keys + 2ull * row_base, nullptr, nullptr, status));
-        HIP_CHECK(launch_scan_agg_hash(cfg, P, T, row_base, status));
+        TIMED_LAUNCH(ex, "scan_keys", launch_scan_keys(cfg, P, keys + 2ull * row_base, nullptr, nullptr, status));
+        TIMED_LAUNCH(ex, "scan_agg_hash", launch_scan_agg_hash(cfg, P, T, row_base, status));
         row_base += (uint32_t)b->n_rows;
     }
     // used slots -> dense records (slot order: deterministic for a given input)
@@ -204,12 +204,12 @@ GroupRec* hash_aggregate(const Exec& ex, Temp& tmp, const ScanParams& P0, const 
     uint64_t* dense = tmp.get<uint64_t>(cap + 1);
     uint64_t* total = tmp.get<uint64_t>(1);
     void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes((int64_t)cap));
-    HIP_CHECK(launch_hash_agg_flags(cfg, T, flags));
+    TIMED_LAUNCH(ex, "hash_agg_flags", launch_hash_agg_flags(cfg, T, flags));
     HIP_CHECK(exclusive_scan_u32_u64(ex.stream, flags, (int64_t)cap, dense, false, total, scan_tmp));
     const uint64_t ng = read_device(ex, total);
     check_scan_status(ex, status);                   // after the one wait above: the stream is idle, this read is immediate
     GroupRec* table = tmp.get<GroupRec>(ng ? ng : 1);
-    if (ng) HIP_CHECK(launch_hash_agg_compact(cfg, T, dense, nullable, table));
+    if (ng) TIMED_LAUNCH(ex, "hash_agg_compact", launch_hash_agg_compact(cfg, T, dense, nullable, table));
     *n_groups = (int64_t)ng;
     return table;
 }
@@ -408,7 +408,7 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
         uint32_t* entry_group = tmp.get<uint32_t>((size_t)n_part * gmax);
         AccSpec specs[VM_MAX_ACC];
         for (int i = 0; i < n_acc; ++i) specs[i] = P0.acc[i];
-        HIP_CHECK(launch_merge_partials(cfg, partials, partial_ng, n_part, gmax, specs, n_acc, table, cap, entry_group, status));
+        TIMED_LAUNCH(ex, "merge_partials", launch_merge_partials(cfg, partials, partial_ng, n_part, gmax, specs, n_acc, table, cap, entry_group, status));
         ScanStatus st = read_device(ex, status);
         timer.collect();
         if (lean_now && (st.flags & SCAN_ERR_KEY_TOO_LONG)) {
@@ -469,20 +469,20 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
             c.offsets = make_buffer(ex, (size_t)(n_groups + 1) * 4);
             c.data = make_buffer(ex, (size_t)n_groups * (size_t)kinfo[gi].width + 8);
             if (n_groups > 0 && n_groups <= EMIT_UTF8_SMALL_MAX) {
-                HIP_CHECK(launch_emit_group_utf8_small(cfg, table, n_groups, ks, vptr, c.offsets->as<int32_t>(), c.data->as<uint8_t>(),
+                TIMED_LAUNCH(ex, "emit_group_utf8_small", launch_emit_group_utf8_small(cfg, table, n_groups, ks, vptr, c.offsets->as<int32_t>(), c.data->as<uint8_t>(),
                                                        totals + gi));
             } else {
                 uint32_t* lengths = tmp.get<uint32_t>((size_t)n_groups + 1);
                 void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes(n_groups));
-                if (n_groups) HIP_CHECK(launch_emit_group_key(cfg, table, n_groups, ks, nullptr, vptr, lengths));
+                if (n_groups) TIMED_LAUNCH(ex, "emit_group_key", launch_emit_group_key(cfg, table, n_groups, ks, nullptr, vptr, lengths));
                 HIP_CHECK(exclusive_scan_u32_i32(ex.stream, lengths, n_groups, c.offsets->as<int32_t>(), true, totals + gi, scan_tmp));
-                if (n_groups) HIP_CHECK(launch_emit_group_utf8(cfg, table, n_groups, ks, c.offsets->as<int32_t>(), c.data->as<uint8_t>()));
+                if (n_groups) TIMED_LAUNCH(ex, "emit_group_utf8", launch_emit_group_utf8(cfg, table, n_groups, ks, c.offsets->as<int32_t>(), c.data->as<uint8_t>()));
             }
             utf8_cols.push_back(gi);
         } else {
             const size_t bytes = c.dtype == DT_BOOLEAN ? bitmap_bytes(n_groups) : (size_t)n_groups * dtype_width(c.dtype);
             c.data = make_buffer(ex, bytes + 8);
-            if (n_groups) HIP_CHECK(launch_emit_group_key(cfg, table, n_groups, ks, c.data->ptr(), vptr, nullptr));
+            if (n_groups) TIMED_LAUNCH(ex, "emit_group_key", launch_emit_group_key(cfg, table, n_groups, ks, c.data->ptr(), vptr, nullptr));
         }
         out->cols.push_back(std::move(c));
     }
@@ -502,7 +502,7 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
         vb.data[vb.n] = c.data->ptr();
         vb.validity[vb.n] = c.validity ? c.validity->as<uint64_t>() : nullptr;
         if (++vb.n == EMIT_BATCH_MAX || k + 1 == emits.size()) {
-            HIP_CHECK(launch_emit_group_values(cfg, table, n_groups, vb));
+            TIMED_LAUNCH(ex, "emit_group_values", launch_emit_group_values(cfg, table, n_groups, vb));
             vb.n = 0;
         }
         out->cols.push_back(std::move(c));

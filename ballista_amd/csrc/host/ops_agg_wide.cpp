@@ -65,7 +65,7 @@ std::vector<BatchPtr> HashAggregateExec::run_wide(int partition, const Exec& ex)
         uint64_t* hashes = tmp.get<uint64_t>((size_t)n);
         ScanStatus* st = tmp.get<ScanStatus>(1);
         HIP_CHECK(hipMemsetAsync(st, 0, sizeof(ScanStatus), ex.stream));
-        HIP_CHECK(launch_scan_keys(cfg, P, nullptr, hashes, nullptr, st));
+        TIMED_LAUNCH(ex, "scan_keys", launch_scan_keys(cfg, P, nullptr, hashes, nullptr, st));
         check_scan_status(ex, st);
         uint64_t cap = 1024;
         while (cap < 2ull * (uint64_t)n) cap <<= 1;
@@ -75,7 +75,7 @@ std::vector<BatchPtr> HashAggregateExec::run_wide(int partition, const Exec& ex)
         memset(&K, 0, sizeof(K));
         K.n = (int32_t)keys.size();
         for (size_t i = 0; i < keys.size(); ++i) K.col[i] = keys[i].ref();
-        HIP_CHECK(launch_wide_key_assign(cfg, K, hashes, table, cap - 1, (uint32_t)n, rep->as<uint32_t>()));
+        TIMED_LAUNCH(ex, "wide_key_assign", launch_wide_key_assign(cfg, K, hashes, table, cap - 1, (uint32_t)n, rep->as<uint32_t>()));
         HIP_CHECK(hipStreamSynchronize(ex.stream));                  // the scratch is released here
     }
 

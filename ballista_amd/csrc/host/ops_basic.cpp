@@ -64,7 +64,7 @@ Column take_column(const Exec& ex, const Column& c, const uint32_t* idx, int64_t
     if (c.dtype == DT_UTF8) {
         Temp tmp(ex);
         uint32_t* lengths = tmp.get<uint32_t>((size_t)n + 1);
-        HIP_CHECK(launch_take_utf8_lengths(cfg, c.offsets->as<int32_t>(), idx, n, lengths));
+        TIMED_LAUNCH(ex, "take_utf8_lengths", launch_take_utf8_lengths(cfg, c.offsets->as<int32_t>(), idx, n, lengths));
         out.offsets = make_buffer(ex, (size_t)(n + 1) * 4);
         uint64_t* total = tmp.get<uint64_t>(1);
         void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes(n));
@@ -73,15 +73,15 @@ Column take_column(const Exec& ex, const Column& c, const uint32_t* idx, int64_t
         if (bytes > 0x7FFFFFFFull) fail(BHIP_EEXEC, "Utf8 column exceeds 2 GiB of value bytes");
         out.data_bytes = (int64_t)bytes;
         out.data = make_buffer(ex, (size_t)bytes + 8);
-        HIP_CHECK(launch_take_utf8_copy(cfg, c.offsets->as<int32_t>(), c.data->as<uint8_t>(), idx, n,
+        TIMED_LAUNCH(ex, "take_utf8_copy", launch_take_utf8_copy(cfg, c.offsets->as<int32_t>(), c.data->as<uint8_t>(), idx, n,
                                         out.offsets->as<int32_t>(), out.data->as<uint8_t>()));
     } else if (c.dtype == DT_BOOLEAN) {
         out.data = make_buffer(ex, bitmap_bytes(n) + 8);
-        HIP_CHECK(launch_take_bitmap(cfg, c.data->as<uint64_t>(), idx, n, out.data->as<uint64_t>()));
+        TIMED_LAUNCH(ex, "take_bitmap", launch_take_bitmap(cfg, c.data->as<uint64_t>(), idx, n, out.data->as<uint64_t>()));
     } else {
         const int w = dtype_width(c.dtype);
         out.data = make_buffer(ex, (size_t)n * w + 8);
-        HIP_CHECK(launch_take_fixed(cfg, c.data->ptr(), w, idx, n, out.data->ptr()));
+        TIMED_LAUNCH(ex, "take_fixed", launch_take_fixed(cfg, c.data->ptr(), w, idx, n, out.data->ptr()));
     }
     return out;
 }
@@ -92,7 +92,7 @@ static Column take_column_v(const Exec& ex, const Column& c, const uint32_t* idx
     Column out = take_column(ex, c, idx, n, permutation && c.dtype == DT_UTF8 ? c.data_bytes : -1);
     if (c.validity || may_null) {
         out.validity = make_buffer(ex, bitmap_bytes(n) + 8);
-        HIP_CHECK(launch_take_bitmap(ex.cfg(), c.validity ? c.validity->as<uint64_t>() : nullptr, idx, n,
+        TIMED_LAUNCH(ex, "take_bitmap", launch_take_bitmap(ex.cfg(), c.validity ? c.validity->as<uint64_t>() : nullptr, idx, n,
                                      out.validity->as<uint64_t>()));
     }
     return out;
@@ -106,7 +106,7 @@ std::vector<Column> take_columns(const Exec& ex, const std::vector<const Column*
     TakeMany tm;
     tm.n = 0;
     auto flush = [&]() {
-        if (tm.n) HIP_CHECK(launch_take_many(ex.cfg(), tm, idx, n));
+        if (tm.n) TIMED_LAUNCH(ex, "take_many", launch_take_many(ex.cfg(), tm, idx, n));
         tm.n = 0;
     };
     auto add = [&](const void* src, void* dst, int width) {
@@ -217,20 +217,20 @@ BatchPtr concat_batches(const Exec& ex, const SchemaPtr& schema, const std::vect
             const int64_t n = p->n_rows;
             if (n == 0) continue;
             if (oc.dtype == DT_UTF8) {
-                HIP_CHECK(launch_rebase_offsets(cfg, c.offsets->as<int32_t>(), n + 1, (int32_t)byte, oc.offsets->as<int32_t>() + row));
+                TIMED_LAUNCH(ex, "rebase_offsets", launch_rebase_offsets(cfg, c.offsets->as<int32_t>(), n + 1, (int32_t)byte, oc.offsets->as<int32_t>() + row));
                 if (c.data_bytes)
                     HIP_CHECK(hipMemcpyAsync(oc.data->as<uint8_t>() + byte, c.data->ptr(), (size_t)c.data_bytes,
                                              hipMemcpyDeviceToDevice, ex.stream));
                 byte += c.data_bytes;
             } else if (oc.dtype == DT_BOOLEAN) {
-                HIP_CHECK(launch_copy_bits(cfg, c.data->as<uint64_t>(), 0, oc.data->as<uint64_t>(), row, n));
+                TIMED_LAUNCH(ex, "copy_bits", launch_copy_bits(cfg, c.data->as<uint64_t>(), 0, oc.data->as<uint64_t>(), row, n));
             } else {
                 const int w = dtype_width(oc.dtype);
                 HIP_CHECK(hipMemcpyAsync(oc.data->as<uint8_t>() + row * w, c.data->ptr(), (size_t)n * w,
                                          hipMemcpyDeviceToDevice, ex.stream));
             }
             if (any_validity)
-                HIP_CHECK(launch_copy_bits(cfg, c.validity ? c.validity->as<uint64_t>() : nullptr, 0,
+                TIMED_LAUNCH(ex, "copy_bits", launch_copy_bits(cfg, c.validity ? c.validity->as<uint64_t>() : nullptr, 0,
                                            oc.validity->as<uint64_t>(), row, n));
             row += n;
         }
@@ -271,9 +271,9 @@ int64_t filter_indices(const Exec& ex, const Batch& in, const ExprPtr& predicate
     if (!range_disabled && build_sop(*in.schema, predicate, {}, {}, rp) && rp.prog.n_ranges >= 1 && sop_columns_bindable(rp, in, true) &&
         lean_bindable(rp, in)) {
         bind_sop(rp, in);
-        HIP_CHECK(launch_range_bitmap(ex.cfg(), rp.prog, tmp.get<SopProgram>(1), bitmap, tile_counts));
+        TIMED_LAUNCH(ex, "range_bitmap", launch_range_bitmap(ex.cfg(), rp.prog, tmp.get<SopProgram>(1), bitmap, tile_counts));
     } else {
-        HIP_CHECK(launch_scan_pred_bitmap(ex.cfg(), P, bitmap, tile_counts, st));
+        TIMED_LAUNCH(ex, "scan_pred_bitmap", launch_scan_pred_bitmap(ex.cfg(), P, bitmap, tile_counts, st));
     }
     uint64_t* tile_off = tmp.get<uint64_t>((size_t)n_tiles + 1);
     uint64_t* total = tmp.get<uint64_t>(1);
@@ -282,7 +282,7 @@ int64_t filter_indices(const Exec& ex, const Batch& in, const ExprPtr& predicate
     check_scan_status(ex, st);
     const uint64_t count = read_device(ex, total);
     indices_out = make_buffer(ex, (size_t)count * 4 + 8);
-    if (count) HIP_CHECK(launch_select_indices(ex.cfg(), bitmap, tile_off, n, indices_out->as<uint32_t>()));
+    if (count) TIMED_LAUNCH(ex, "select_indices", launch_select_indices(ex.cfg(), bitmap, tile_off, n, indices_out->as<uint32_t>()));
     return (int64_t)count;
 }
 
@@ -421,7 +421,7 @@ static BatchPtr project_batch(const Exec& ex, const Batch& in, const std::vector
     }
     Temp tmp(ex);
     ScanStatus* st = new_status(tmp);
-    HIP_CHECK(launch_scan_project(ex.cfg(), P, po, st));
+    TIMED_LAUNCH(ex, "scan_project", launch_scan_project(ex.cfg(), P, po, st));
     check_scan_status(ex, st);
     return out;
 }

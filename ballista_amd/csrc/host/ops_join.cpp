@@ -89,7 +89,7 @@ static void side_keys(const Exec& ex, const Batch& b, const std::vector<std::str
         if (w && !c.validity) {
             keys = make_buffer(ex, (size_t)b.n_rows * 16 + 16);
             has_sel = false;
-            HIP_CHECK(launch_widen_key(ex.cfg(), c.data->ptr(), w, b.n_rows, keys->as<uint64_t>()));
+            TIMED_LAUNCH(ex, "widen_key", launch_widen_key(ex.cfg(), c.data->ptr(), w, b.n_rows, keys->as<uint64_t>()));
             return;
         }
     }
@@ -116,7 +116,7 @@ static void side_keys(const Exec& ex, const Batch& b, const std::vector<std::str
     Temp tmp(ex);
     ScanStatus* st = tmp.get<ScanStatus>(1);
     HIP_CHECK(hipMemsetAsync(st, 0, sizeof(ScanStatus), ex.stream));
-    HIP_CHECK(launch_scan_keys(ex.cfg(), P, keys->as<uint64_t>(), nullptr, has_sel ? sel->as<uint64_t>() : nullptr, st));
+    TIMED_LAUNCH(ex, "scan_keys", launch_scan_keys(ex.cfg(), P, keys->as<uint64_t>(), nullptr, has_sel ? sel->as<uint64_t>() : nullptr, st));
     check_scan_status(ex, st);
 }
 
@@ -174,7 +174,7 @@ std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) co
         HIP_CHECK(hipMemsetAsync(bs->dup->ptr(), 0, 8, ex.stream));
         bs->ntable = NarrowJoinTable{bs->slots->as<uint64_t>(), cap - 1, bs->dup->as<uint32_t>(), nullptr, 0, 0, 0};
         bs->narrow_width = nkw;
-        HIP_CHECK(launch_join_build_narrow(ex.cfg(), bs->ntable, kc.data->ptr(), nkw,
+        TIMED_LAUNCH(ex, "join_build_narrow", launch_join_build_narrow(ex.cfg(), bs->ntable, kc.data->ptr(), nkw,
                                            kc.validity ? kc.validity->as<uint64_t>() : nullptr, (uint32_t)n));
         if (read_device(ex, bs->dup->as<uint32_t>()) == 0) {
             bs->narrow = bs->unique = true;
@@ -190,7 +190,7 @@ std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) co
                 if (nkw == 4) {
                     const int32_t seed[2] = {2147483647, -2147483647 - 1};
                     HIP_CHECK(hipMemcpyAsync(mm, seed, 8, hipMemcpyHostToDevice, ex.stream));
-                    HIP_CHECK(launch_join_key_minmax(ex.cfg(), kc.data->as<int32_t>(), ksel, (uint32_t)n, reinterpret_cast<int32_t*>(mm)));
+                    TIMED_LAUNCH(ex, "join_key_minmax", launch_join_key_minmax(ex.cfg(), kc.data->as<int32_t>(), ksel, (uint32_t)n, reinterpret_cast<int32_t*>(mm)));
                     int32_t got[2];
                     HIP_CHECK(hipMemcpyAsync(got, mm, 8, hipMemcpyDeviceToHost, ex.stream));
                     HIP_CHECK(hipStreamSynchronize(ex.stream));
@@ -199,7 +199,7 @@ std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) co
                 } else {
                     const uint64_t seed[2] = {~0ull, 0};
                     HIP_CHECK(hipMemcpyAsync(mm, seed, 16, hipMemcpyHostToDevice, ex.stream));
-                    HIP_CHECK(launch_join_key_minmax64(ex.cfg(), kc.data->as<uint64_t>(), ksel, (uint32_t)n, mm));
+                    TIMED_LAUNCH(ex, "join_key_minmax64", launch_join_key_minmax64(ex.cfg(), kc.data->as<uint64_t>(), ksel, (uint32_t)n, mm));
                     HIP_CHECK(hipMemcpyAsync(host_mm, mm, 16, hipMemcpyDeviceToHost, ex.stream));
                     HIP_CHECK(hipStreamSynchronize(ex.stream));
                 }
@@ -210,10 +210,10 @@ std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) co
                     bs->present = make_buffer(ex, words * 4);
                     HIP_CHECK(hipMemsetAsync(bs->present->ptr(), 0, words * 4, ex.stream));
                     if (nkw == 4)
-                        HIP_CHECK(launch_join_key_present(ex.cfg(), kc.data->as<uint32_t>(), ksel, (uint32_t)n, (uint32_t)kmin,
+                        TIMED_LAUNCH(ex, "join_key_present", launch_join_key_present(ex.cfg(), kc.data->as<uint32_t>(), ksel, (uint32_t)n, (uint32_t)kmin,
                                                           bs->present->as<uint32_t>()));
                     else
-                        HIP_CHECK(launch_join_key_present64(ex.cfg(), kc.data->as<uint64_t>(), ksel, (uint32_t)n, kmin,
+                        TIMED_LAUNCH(ex, "join_key_present64", launch_join_key_present64(ex.cfg(), kc.data->as<uint64_t>(), ksel, (uint32_t)n, kmin,
                                                             bs->present->as<uint32_t>()));
                     HIP_CHECK(hipStreamSynchronize(ex.stream));
                     bs->ntable.present = bs->present->as<uint32_t>();
@@ -241,7 +241,7 @@ std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) co
     bs->dup = make_buffer(ex, 8);
     HIP_CHECK(hipMemsetAsync(bs->dup->ptr(), 0, 8, ex.stream));
     bs->table.dup_flag = bs->dup->as<uint32_t>();
-    HIP_CHECK(launch_join_build(ex.cfg(), bs->table, bs->has_sel ? bs->sel->as<uint64_t>() : nullptr, (uint32_t)n));
+    TIMED_LAUNCH(ex, "join_build", launch_join_build(ex.cfg(), bs->table, bs->has_sel ? bs->sel->as<uint64_t>() : nullptr, (uint32_t)n));
     // other tasks (other HIP streams) will read the table: it must be complete before it is published
     bs->unique = read_device(ex, bs->dup->as<uint32_t>()) == 0;
     bs->table.dup_flag = nullptr;
@@ -310,38 +310,38 @@ StreamPtr HashJoinExec::execute(int partition, const Exec& ex) const {
                 void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes(n_tiles));
                 if (bs->narrow) {
                     const Column& kc = keysrc ? *keysrc : probe.cols[probe.schema->index_of(rcols[0])];
-                    HIP_CHECK(launch_join_probe_match_narrow(cfg, bs->ntable, kc.data->ptr(), bs->narrow_width,
+                    TIMED_LAUNCH(ex, "join_probe_match_narrow", launch_join_probe_match_narrow(cfg, bs->ntable, kc.data->ptr(), bs->narrow_width,
                                                              kc.validity ? kc.validity->as<uint64_t>() : nullptr,
                                                              keysrc ? remap : nullptr, (uint32_t)n_right,
                                                              right_outer, partner, bitmap, tile_counts,
                                                              left_outer ? matched->as<uint32_t>() : nullptr));
                 } else
-                    HIP_CHECK(launch_join_probe_match(cfg, bs->table, rkeys->as<uint64_t>(), rselp, (uint32_t)n_right, right_outer, partner,
+                    TIMED_LAUNCH(ex, "join_probe_match", launch_join_probe_match(cfg, bs->table, rkeys->as<uint64_t>(), rselp, (uint32_t)n_right, right_outer, partner,
                                                       bitmap, tile_counts, left_outer ? matched->as<uint32_t>() : nullptr));
                 HIP_CHECK(exclusive_scan_u32_u64(ex.stream, tile_counts, n_tiles, tile_off, false, total, scan_tmp));
                 n_out = read_device(ex, total);
                 if (n_out == 0) return;
                 lidx = tmp.get<uint32_t>((size_t)n_out);
                 ridx = tmp.get<uint32_t>((size_t)n_out);
-                HIP_CHECK(launch_select_indices(cfg, bitmap, tile_off, n_right, ridx));
-                HIP_CHECK(launch_take_fixed(cfg, partner, 4, ridx, (int64_t)n_out, lidx));
+                TIMED_LAUNCH(ex, "select_indices", launch_select_indices(cfg, bitmap, tile_off, n_right, ridx));
+                TIMED_LAUNCH(ex, "take_fixed", launch_take_fixed(cfg, partner, 4, ridx, (int64_t)n_out, lidx));
             } else {
                 uint32_t* counts = tmp.get<uint32_t>((size_t)n_right + 1);
                 uint64_t* offsets = tmp.get<uint64_t>((size_t)n_right + 1);
                 void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes(n_right));
-                HIP_CHECK(launch_join_probe_count(cfg, bs->table, rkeys->as<uint64_t>(), rselp, (uint32_t)n_right, right_outer, counts));
+                TIMED_LAUNCH(ex, "join_probe_count", launch_join_probe_count(cfg, bs->table, rkeys->as<uint64_t>(), rselp, (uint32_t)n_right, right_outer, counts));
                 HIP_CHECK(exclusive_scan_u32_u64(ex.stream, counts, n_right, offsets, false, total, scan_tmp));
                 n_out = read_device(ex, total);
                 if (n_out > 0xFFFFFFF0ull) fail(BHIP_EEXEC, "join output of one probe batch exceeds 2^32 rows");
                 if (n_out == 0) return;
                 lidx = tmp.get<uint32_t>((size_t)n_out);
                 ridx = tmp.get<uint32_t>((size_t)n_out);
-                HIP_CHECK(launch_join_probe_emit(cfg, bs->table, rkeys->as<uint64_t>(), rselp, (uint32_t)n_right, right_outer, offsets,
+                TIMED_LAUNCH(ex, "join_probe_emit", launch_join_probe_emit(cfg, bs->table, rkeys->as<uint64_t>(), rselp, (uint32_t)n_right, right_outer, offsets,
                                                  lidx, ridx, left_outer ? matched->as<uint32_t>() : nullptr));
             }
             if (remap) {
                 uint32_t* orig = tmp.get<uint32_t>((size_t)n_out);
-                HIP_CHECK(launch_take_fixed(cfg, remap, 4, ridx, (int64_t)n_out, orig));
+                TIMED_LAUNCH(ex, "take_fixed", launch_take_fixed(cfg, remap, 4, ridx, (int64_t)n_out, orig));
                 ridx = orig;
             }
             emit(outsrc, lidx, ridx, (int64_t)n_out);
@@ -404,12 +404,12 @@ StreamPtr HashJoinExec::execute(int partition, const Exec& ex) const {
             uint64_t* offsets = tmp.get<uint64_t>((size_t)n_left + 1);
             uint64_t* total = tmp.get<uint64_t>(1);
             void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes(n_left));
-            HIP_CHECK(launch_join_unmatched_flags(cfg, matched->as<uint32_t>(), (uint32_t)n_left, flags));
+            TIMED_LAUNCH(ex, "join_unmatched_flags", launch_join_unmatched_flags(cfg, matched->as<uint32_t>(), (uint32_t)n_left, flags));
             HIP_CHECK(exclusive_scan_u32_u64(ex.stream, flags, n_left, offsets, false, total, scan_tmp));
             const uint64_t n_un = read_device(ex, total);
             if (n_un) {
                 uint32_t* lidx = tmp.get<uint32_t>((size_t)n_un);
-                HIP_CHECK(launch_compact_flags(cfg, flags, offsets, (uint32_t)n_left, lidx));
+                TIMED_LAUNCH(ex, "compact_flags", launch_compact_flags(cfg, flags, offsets, (uint32_t)n_left, lidx));
                 emit(nullptr, lidx, nullptr, (int64_t)n_un);
                 HIP_CHECK(hipStreamSynchronize(ex.stream));
             }

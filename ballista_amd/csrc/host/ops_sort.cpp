@@ -76,7 +76,7 @@ StreamPtr SortExec::execute(int partition, const Exec& ex) const {
         const LaunchCfg cfg = ex.cfg();
         BufferPtr perm = make_buffer(ex, (size_t)n * 4 + 8);
         BufferPtr keys = make_buffer(ex, (size_t)n * 8 + 8);
-        HIP_CHECK(launch_iota_u32(cfg, perm->as<uint32_t>(), n, 0));
+        TIMED_LAUNCH(ex, "iota_u32", launch_iota_u32(cfg, perm->as<uint32_t>(), n, 0));
         for (size_t k = self->exprs_.size(); k-- > 0;) {
             const SortDesc& sd = self->exprs_[k];
             const Column col = evaluate_column(ex, *in, sd.expr);
@@ -86,22 +86,22 @@ StreamPtr SortExec::execute(int partition, const Exec& ex) const {
                 if (col.data_bytes > 32) {
                     Temp tmp(ex);
                     uint32_t* maxlen_dev = tmp.get<uint32_t>(1);
-                    HIP_CHECK(launch_utf8_max_len(cfg, col.offsets->as<int32_t>(), n, maxlen_dev));
+                    TIMED_LAUNCH(ex, "utf8_max_len", launch_utf8_max_len(cfg, col.offsets->as<int32_t>(), n, maxlen_dev));
                     maxlen = read_device(ex, maxlen_dev);
                 }
                 // least significant first: the length, then the 8-byte chunks from the last to the first
-                HIP_CHECK(launch_sort_key_utf8(cfg, cr, perm->as<uint32_t>(), n, -1, sd.descending, keys->as<uint64_t>()));
+                TIMED_LAUNCH(ex, "sort_key_utf8", launch_sort_key_utf8(cfg, cr, perm->as<uint32_t>(), n, -1, sd.descending, keys->as<uint64_t>()));
                 radix_sort_pairs(ex, keys, perm, n);
                 for (int chunk = (int)((maxlen + 7) / 8) - 1; chunk >= 0; --chunk) {
-                    HIP_CHECK(launch_sort_key_utf8(cfg, cr, perm->as<uint32_t>(), n, chunk, sd.descending, keys->as<uint64_t>()));
+                    TIMED_LAUNCH(ex, "sort_key_utf8", launch_sort_key_utf8(cfg, cr, perm->as<uint32_t>(), n, chunk, sd.descending, keys->as<uint64_t>()));
                     radix_sort_pairs(ex, keys, perm, n);
                 }
             } else {
-                HIP_CHECK(launch_sort_key_fixed(cfg, cr, perm->as<uint32_t>(), n, sd.descending, keys->as<uint64_t>()));
+                TIMED_LAUNCH(ex, "sort_key_fixed", launch_sort_key_fixed(cfg, cr, perm->as<uint32_t>(), n, sd.descending, keys->as<uint64_t>()));
                 radix_sort_pairs(ex, keys, perm, n);
             }
             if (col.validity) {
-                HIP_CHECK(launch_sort_key_null(cfg, col.validity->as<uint64_t>(), perm->as<uint32_t>(), n, sd.nulls_first,
+                TIMED_LAUNCH(ex, "sort_key_null", launch_sort_key_null(cfg, col.validity->as<uint64_t>(), perm->as<uint32_t>(), n, sd.nulls_first,
                                                keys->as<uint64_t>()));
                 radix_sort_pairs(ex, keys, perm, n);
             }
@@ -174,14 +174,14 @@ std::vector<BatchPtr> hash_partition_batch(const Exec& ex, const BatchPtr& in, c
         uint64_t* hashes = tmp.get<uint64_t>((size_t)n);
         ScanStatus* st = tmp.get<ScanStatus>(1);
         HIP_CHECK(hipMemsetAsync(st, 0, sizeof(ScanStatus), ex.stream));
-        HIP_CHECK(launch_scan_keys(cfg, P, nullptr, hashes, nullptr, st));
+        TIMED_LAUNCH(ex, "scan_keys", launch_scan_keys(cfg, P, nullptr, hashes, nullptr, st));
         BufferPtr keys = make_buffer(ex, (size_t)n * 8 + 8);
-        HIP_CHECK(launch_hash_to_pid(cfg, hashes, n, (uint32_t)n_parts, keys->as<uint64_t>()));
-        HIP_CHECK(launch_iota_u32(cfg, perm->as<uint32_t>(), n, 0));
+        TIMED_LAUNCH(ex, "hash_to_pid", launch_hash_to_pid(cfg, hashes, n, (uint32_t)n_parts, keys->as<uint64_t>()));
+        TIMED_LAUNCH(ex, "iota_u32", launch_iota_u32(cfg, perm->as<uint32_t>(), n, 0));
         check_scan_status(ex, st);
         radix_sort_pairs(ex, keys, perm, n);
         uint32_t* first_dev = tmp.get<uint32_t>((size_t)n_parts + 1);
-        HIP_CHECK(launch_partition_bounds(cfg, keys->as<uint64_t>(), n, (uint32_t)n_parts, first_dev));
+        TIMED_LAUNCH(ex, "partition_bounds", launch_partition_bounds(cfg, keys->as<uint64_t>(), n, (uint32_t)n_parts, first_dev));
         HIP_CHECK(hipMemcpyAsync(first.data(), first_dev, ((size_t)n_parts + 1) * 4, hipMemcpyDeviceToHost, ex.stream));
         HIP_CHECK(hipStreamSynchronize(ex.stream));
     }

@@ -72,6 +72,16 @@ class Context:
     def kernel_name(self):
         return L.lib().bhip_ctx_kernel_name(self._h).decode()
 
+    def kernel_stats(self, reset=False):
+        """{kernel name: (total ms, launches)} of every kernel timed since the last reset (BHIP_KERNEL_TIMING=1)"""
+        buf = C.create_string_buffer(1 << 16)
+        L.check(L.lib().bhip_ctx_kernel_stats(self._h, 1 if reset else 0, buf, len(buf)))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, ms, n = line.split("\t")
+            out[name] = (float(ms), int(n))
+        return out
+
     def __del__(self):
         try:
             if getattr(self, "_h", None):

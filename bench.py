@@ -1,26 +1,33 @@
 #!/usr/bin/env python3
-"""bench.py — TPC-H Q1 at SF100 on MI355X (BASELINE.json configs[1]).
+"""bench.py — TPC-H Q1 at SF100 on MI355X (BASELINE.json configs[1]); --query q6 | q3 | q5 are configs[2..4].
 
-A step = one full pass of Q1 (scan -> filter -> partial aggregate -> merge -> final aggregate ->
-projection -> sort) through the C ABI over a synthetic TPC-H-shaped lineitem table that is already
-resident in HBM (600,037,902 rows per GPU, generated on the device from a seed).
+A step = one full pass of the query through the C ABI over synthetic TPC-H-shaped tables that are already resident
+in HBM (generated on the device from a seed).  Every step runs a plan whose operators are NEW objects
+(`tpch.fresh`: a with_new_children clone of the whole tree): join build sides, hash tables and path choices are
+rebuilt inside the timed region, as a task that has just decoded its plan does
+(rust/executor/src/flight_service.rs:87-121).
 
-  python bench.py --gpus N --steps K --warmup W
-      N > 1 is launched by `python -m torch.distributed.run --nproc-per-node N ...` (one rank per
-      GPU).  Each rank owns one SF100-sized shard (rows [rank*R, (rank+1)*R) of the seeded table)
-      and runs stage 1 on it; the per-rank partial states (<= 16 groups x 13 columns) are exchanged
-      with ONE small all_gather (RCCL) and every rank runs the Final aggregate — the MergeExec of
-      the reference's stage 2 (rust/scheduler/src/planner.rs:136-148).  Weak scaling.
+  python bench.py --gpus N --steps K --warmup W [--query q1]
+      N > 1: one process per GPU.  When WORLD_SIZE is not set this process only spawns
+      `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child (before anything touches the
+      GPU) and relays its output and exit code.
+      STRONG scaling is the reported `value`: the fixed SF100 tables are split N ways by row blocks
+      (the metric reads "Q1 SF100 at 1/2/4/8 GPUs"); the weak-scaling figure (every rank its own SF100 shard) is
+      the extra key `weak_scaling`.  Q1 / Q6: stage 1 per shard, ONE small all_gather of the partial-state
+      batches, Final aggregate on every rank (rust/scheduler/src/planner.rs:136-171).  Q3 / Q5: hash repartition of
+      both join sides on the order key + all-to-all (ballista_amd/distributed.py).
 
-Prints ONE JSON line (rank 0).  `value` = input rows of all ranks / max-over-ranks wall time.
-`roofline`: algorithmic bytes (46 B/row) of one launch of the fused scan kernel /
-its average duration, timed with HIP events on the stream it ran on (BHIP_KERNEL_TIMING=1).
-`cpu_baseline`: the oracle's threaded port of the same stage in DataFusion's structure
-(oracle/oracle_ops.c) on a bounded sample, on the host cores of the same box.
+Prints ONE JSON line (rank 0).  `value` = driving-table rows of the whole job / max-over-ranks wall time.
+`roofline`: algorithmic bytes of one launch of the dominant kernel / its average duration, timed
+with HIP events on the stream it ran on (BHIP_KERNEL_TIMING=1).  `cpu_baseline`: the oracle's threaded port of the
+same query in DataFusion's structure (oracle/oracle_ops.c) on a bounded sample, on the host cores of the same box;
+`cpu_baseline_acero`: Arrow C++ (pyarrow) on the same sample, a second, independent CPU engine.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,178 +36,241 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("BHIP_KERNEL_TIMING", "1")
 
 SF = 100.0
-ROWS_SF100 = 600_037_902
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rows", type=int, default=ROWS_SF100, help="rows per GPU (default: SF100 lineitem)")
-    ap.add_argument("--query", default="q1", choices=["q1", "q6"])
+    ap.add_argument("--query", default="q1", choices=["q1", "q6", "q3", "q5"])
+    ap.add_argument("--sf", type=float, default=SF, help="scale factor of the tables (default 100)")
+    ap.add_argument("--rows", type=int, default=0, help="lineitem rows of the whole job (default: the scale factor's)")
+    ap.add_argument("--key64", action="store_true", help="Int64 order keys (what TPC-H needs at SF1000)")
     ap.add_argument("--cpu-rows", type=int, default=96_000_000, help="rows of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the extra weak-scaling measurement")
+    ap.add_argument("--join-exchange", default="shuffle", choices=["shuffle", "broadcast"],
+                    help="N > 1, q3 / q5: hash-partition both sides of the order-key join (config #5) or broadcast the build side")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse the N-rank flow on a box with fewer GPUs)")
-    return ap.parse_args()
+                    help="transport for N > 1 (nccl = RCCL; gloo only to rehearse the N-rank flow on a box with fewer GPUs)")
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(query, sample_rows):
-    """oracle port (DataFusion structure: 32768-row batches, materialised intermediates, one partition
-    per thread) on rows [0, sample_rows) of the same seeded table"""
-    import numpy as np
-    from oracle import gen
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: spawn the N ranks as a CHILD process tree before this process
+    touches the GPU (never exec from a process that has), relay rank 0's line and the exit code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if line is not None:
+        print(line, flush=True)
+    else:
+        sys.stdout.write(proc.stdout)
+    return proc.returncode if (proc.returncode != 0 or line is not None) else 1
+
+
+# ---- CPU baselines (N = 1 only) -----------------------------------------------------------------------------
+
+def _cpu_threads():
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     # a one-GPU box's CPU share is 16 cores (an 8-GPU host has 256): use that many threads
-    cores = max(1, min(cores, int(os.environ.get("BHIP_CPU_THREADS", "16"))))
-    a = gen.lineitem_arrays(SF, 0, sample_rows)
-    parts = max(cores, 1) * 4
-    best = None
-    t_total = 0.0
-    reps = 0
-    while reps < 3 or (t_total < 10.0 and reps < 1000):      # about 10 s of CPU work
+    return max(1, min(cores, int(os.environ.get("BHIP_CPU_THREADS", "16"))))
+
+
+def _best_of(fn, budget_s=10.0, min_reps=3):
+    best, total, reps = None, 0.0, 0
+    while reps < min_reps or (total < budget_s and reps < 1000):
         t0 = time.perf_counter()
-        if query == "q1":
-            gen.q1_partial_port(a, parts, cores)
-        else:
-            gen.q6_partial_port(a, parts, cores)
+        fn()
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
-        t_total += dt
+        total += dt
         reps += 1
+    return best, total, reps
+
+
+def cpu_baseline(query, sf, sample_rows):
+    """oracle port (DataFusion structure: 32768-row batches, materialised intermediates, one partition per thread) on
+    rows [0, sample_rows) of the same seeded lineitem (Q3 / Q5: with the matching prefix of orders and the whole small
+    tables)"""
+    from oracle import gen
+    cores = _cpu_threads()
+    parts = cores * 4
+    if query in ("q1", "q6"):
+        a = gen.lineitem_arrays(sf, 0, sample_rows)
+        fn = (lambda: gen.q1_partial_port(a, parts, cores)) if query == "q1" else (lambda: gen.q6_partial_port(a, parts, cores))
+        what = f"oracle/oracle_ops.c::oracle_{query}_partial"
+    else:
+        from ballista_amd import tpch
+        port = gen.JoinQueryPort(query, sf, sample_rows, tpch.dimension_arrays(sf))
+        fn = lambda: port.run(parts, cores)
+        what = f"oracle/oracle_ops.c::oracle_{query}_join_port (both hash-join builds inside the timed call)"
+    best, total, reps = _best_of(fn)
     return dict(value=sample_rows / best, unit="rows/s", cores=cores, kind="port",
-                sample=f"rows [0,{sample_rows}) of the seeded SF100 lineitem, {parts} partitions, best of {reps} passes "
-                       f"({t_total:.1f} s of CPU work), oracle/oracle_ops.c::oracle_{query}_partial")
+                sample=f"lineitem rows [0,{sample_rows}) of the seeded SF{sf:g} table, {parts} partitions, best of {reps} passes "
+                       f"({total:.1f} s of CPU work), {what}")
+
+
+def cpu_baseline_acero(query, sf, sample_rows):
+    """Arrow C++ (pyarrow compute / Acero) on the same sample: an independent CPU engine, NOT the reference"""
+    try:
+        import numpy as np
+        import pyarrow as pa
+        import pyarrow.compute as pc
+        from oracle import gen
+    except ImportError:
+        return None
+    if query not in ("q1", "q6"):
+        return None
+    sample_rows = min(sample_rows, 24_000_000)
+    a = gen.lineitem_arrays(sf, 0, sample_rows)
+    cols = {k: pa.array(a[k]) for k in ("l_quantity", "l_extendedprice", "l_discount", "l_tax", "l_shipdate")}
+    for k in ("l_returnflag", "l_linestatus"):
+        cols[k] = pa.Array.from_buffers(pa.string(), sample_rows, [None, pa.py_buffer(a[k + ".off"]), pa.py_buffer(a[k + ".data"])])
+    t = pa.table(cols)
+    pa.set_cpu_count(_cpu_threads())
+
+    def q1():
+        f = t.filter(pc.less_equal(t["l_shipdate"], 10471))
+        dp = pc.multiply(f["l_extendedprice"], pc.subtract(1.0, f["l_discount"]))
+        ch = pc.multiply(dp, pc.add(1.0, f["l_tax"]))
+        f = f.append_column("disc_price", dp).append_column("charge", ch)
+        return f.group_by(["l_returnflag", "l_linestatus"]).aggregate(
+            [("l_quantity", "sum"), ("l_extendedprice", "sum"), ("disc_price", "sum"), ("charge", "sum"), ("l_quantity", "mean"),
+             ("l_extendedprice", "mean"), ("l_discount", "mean"), ("l_quantity", "count")])
+
+    def q6():
+        m = pc.and_(pc.and_(pc.greater_equal(t["l_shipdate"], 8766), pc.less(t["l_shipdate"], 9131)),
+                    pc.and_(pc.and_(pc.greater_equal(t["l_discount"], 0.06 - 0.01), pc.less_equal(t["l_discount"], 0.06 + 0.01)),
+                            pc.less(t["l_quantity"], 24.0)))
+        f = t.filter(m)
+        return pc.sum(pc.multiply(f["l_extendedprice"], f["l_discount"]))
+
+    best, total, reps = _best_of(q1 if query == "q1" else q6, budget_s=5.0)
+    return dict(value=sample_rows / best, unit="rows/s", cores=_cpu_threads(), kind="acero",
+                sample=f"pyarrow {pa.__version__} compute + group_by on rows [0,{sample_rows}), best of {reps} passes ({total:.1f} s)")
 
 
 def pmc_traffic(kernel, rows, query):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic.json, written
-    by tools/profile_bench.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 runs of this command).
-    FETCH_SIZE is doubled (gfx950 counts wide streaming reads at half, MI355X_MICROARCH.md §HBM).
-    None when no pass exists for this kernel and launch size — counters cannot be read from inside."""
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic*.json, written by
+    tools/profile_bench.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 runs of this command).  FETCH_SIZE is
+    doubled (gfx950 counts wide streaming reads at half, MI355X_MICROARCH.md §HBM).  None when no pass exists for
+    this kernel and launch size — counters cannot be read from inside."""
     for name in ("pmc_traffic.json", f"pmc_traffic_{query}.json"):
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", name)))
         except (OSError, ValueError):
             continue
-        if kernel in rec.get("kernel", "") and rec.get("rows_per_launch") == rows and rec.get("query", "q1") == query:
+        if kernel and kernel in rec.get("kernel", "") and rec.get("rows_per_launch") == rows and rec.get("query", "q1") == query:
             return (2.0 * rec["fetch_size_kb_per_launch"] + rec["write_size_kb_per_launch"]) * 1024.0
     return None
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        n_dev = torch.cuda.device_count()
-        if args.backend == "gloo":
-            local_rank = local_rank % max(n_dev, 1)        # rehearsal: ranks may share a GPU
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(args.backend)
-    coll_device = "cpu" if args.backend == "gloo" else f"cuda:{local_rank}"
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     import ballista_amd as ba
-    from ballista_amd import tpch
+    from ballista_amd import tpch, distributed as D
 
-    ctx = ba.Context(local_rank)
-    rows = args.rows
-    # each rank holds its own SF100-sized shard of the seeded table
-    table = ba.plan.tpch_lineitem(ctx, SF, tpch.SEED, rank * rows, rows)
-    scan = ba.MemoryExec([[table]], ctx)
-    if args.query == "q1":
-        stage1 = tpch.q1_stage1(scan)
-        bytes_per_row = tpch.Q1_BYTES_PER_ROW
-    else:
-        stage1 = tpch.q6_stage1(scan)
-        bytes_per_row = tpch.Q6_BYTES_PER_ROW
+    group = D.ProcessGroup.from_env(args.backend) if world > 1 else D.ProcessGroup.single()
+    ctx = ba.Context(group.device_index(local_rank))
+    group.attach(ctx)
 
-    if world == 1:
-        plan = tpch.q1_final(stage1) if args.query == "q1" else tpch.q6_plan(scan)
-
-        def step():
-            return plan.collect()
-    else:
-        from ballista_amd.exchange import all_gather_batches
-
-        def step():
-            part = stage1.collect()[0].to_pyarrow()
-            # ONE 16-KiB all_gather (RCCL) of the partial-state batches; tests/test_distributed_cpu.py
-            parts = all_gather_batches(dist, part, device=coll_device)
-            # one import for all ranks' state rows (MergeExec semantics: the partitions' rows, concatenated)
-            import pyarrow as pa
-            state = pa.Table.from_batches(parts).combine_chunks().to_batches()[0]
-            merged = ba.MemoryExec([[ba.RecordBatch.from_pyarrow(ctx, state)]], ctx)
-            if args.query == "q1":
-                final = tpch.q1_final(merged)
-            else:
-                final = ba.HashAggregateExec(ba.plan.FINAL, [], [ba.expr.AggregateExpr("SUM", ba.expr.col("revenue[sum]"), "revenue")],
-                                             ba.MergeExec(merged))
-            return final.collect()
+    n = tpch.table_rows(args.sf)
+    if args.rows:
+        n["lineitem"] = args.rows
+    key_bytes = 8 if args.key64 else 4
+    W = D.Workload(args.query, ctx, group, sf=args.sf, rows=n, key64=args.key64, join_exchange=args.join_exchange)
 
     def barrier():
         ctx.synchronize()
-        if dist is not None:
-            dist.barrier()
-            ctx.synchronize()
+        group.barrier()
+        ctx.synchronize()
 
-    result = None
-    for _ in range(args.warmup):
-        result = step()
-    ctx.kernel_time(reset=True)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        result = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    k_ms, k_launches = ctx.kernel_time(reset=True)
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(step, steps, warmup):
+        result = None
+        for _ in range(warmup):
+            result = step()
+        ctx.synchronize()
+        ctx.kernel_stats(reset=True)
+        ctx.kernel_time(reset=True)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            result = step()
+        barrier()
+        elapsed = group.max_over_ranks(time.perf_counter() - t0)
+        return elapsed, result, ctx.kernel_stats(reset=True)
+
+    # ---- strong scaling on the fixed tables (N = 1: the whole tables) -------------------------------------------
+    W.load(mode="strong")
+    elapsed, result, kstats = timed(W.step, args.steps, args.warmup)
+    exch = W.exchange_stats(reset=True)
+
+    weak = None
+    if world > 1 and not args.no_weak:
+        W.load(mode="weak")
+        w_steps = max(3, args.steps // 4)
+        w_elapsed, _, _ = timed(W.step, w_steps, 1)
+        weak = dict(value=n["lineitem"] * world * w_steps / w_elapsed, unit="rows/s", ms_per_step=w_elapsed / w_steps * 1e3,
+                    steps=w_steps, rows_per_gpu=n["lineitem"], note="every rank holds its own full-size shard of the seeded tables")
 
     if rank == 0:
-        total_rows = rows * world * args.steps
-        value = total_rows / elapsed
-        kernel_ms = k_ms / max(k_launches, 1)
-        algo_bytes = rows * bytes_per_row
-        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        rows_job = n["lineitem"]
+        rows_launch = W.rows_local("lineitem")                      # rows one launch of the dominant kernel covers
+        dom = max(kstats.items(), key=lambda kv: kv[1][0]) if kstats else ("", (0.0, 0))
+        dom_name, (dom_ms, dom_n) = dom
+        kernel_ms = dom_ms / max(dom_n, 1)
+        algo_launch = W.algorithmic_bytes_of_kernel(dom_name, key_bytes)
+        achieved = algo_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        algo_job = W.algorithmic_bytes(key_bytes)
         out = {
-            "metric": f"tpch_{args.query}_sf100_rows_per_sec", "value": value, "unit": "rows/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"TPC-H {args.query.upper()} SF100 (scan+filter+group-by aggregate), "
-                                   f"{rows} lineitem rows per GPU resident in HBM, Arrow layout ({bytes_per_row} B/row)",
-                       "rows_per_gpu": rows, "partitioning": f"{world} x SF100 shard, one partial-state all_gather"},
-            "hbm_gbs_whole_step": rows * world * bytes_per_row * args.steps / elapsed / 1e9,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(ctx.kernel_name(), rows, args.query),
-                         "kernel": ctx.kernel_name(), "kernel_ms": kernel_ms, "launches": int(k_launches),
-                         "algorithmic_bytes_per_launch": algo_bytes},
+            "metric": f"tpch_{args.query}_sf{args.sf:g}_rows_per_sec", "value": rows_job * args.steps / elapsed, "unit": "rows/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": W.describe(), "lineitem_rows": rows_job, "rows_per_gpu": rows_launch,
+                       "partitioning": W.partitioning(), "plan_per_step": "fresh operator tree (join builds and path choices inside the timed region)"},
+            "hbm_gbs_whole_step": algo_job * args.steps / elapsed / 1e9,
+            "hbm_frac_whole_step": algo_job * args.steps / elapsed / 1e9 / (HBM_PEAK_GBS * world),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic(dom_name, rows_launch, args.query), "kernel": dom_name, "kernel_ms": kernel_ms,
+                         "launches": int(dom_n), "algorithmic_bytes_per_launch": algo_launch},
+            "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(kstats.items(), key=lambda kv: -kv[1][0])[:12]},
+            "result_check": W.result_check(result),
         }
-        groups = result[0].to_pydict() if result else {}
-        out["result_check"] = {"groups": len(next(iter(groups.values()))) if groups else 0,
-                               "rows_counted": int(sum(groups.get("count_order", [0])))}
-        if world == 1 and not args.no_cpu_baseline and args.cpu_rows > 0:      # the CPU leg runs at N=1 only
-            # free the GPU table first? no: host memory only; the sample lives in host RAM
-            out["cpu_baseline"] = cpu_baseline(args.query, min(args.cpu_rows, rows))
+        if weak is not None:
+            out["weak_scaling"] = weak
+        if exch:
+            out["exchange"] = exch
+        if world == 1 and not args.no_cpu_baseline and args.cpu_rows > 0:      # the CPU legs run at N=1 only
+            sample = min(args.cpu_rows, rows_job)
+            out["cpu_baseline"] = cpu_baseline(args.query, args.sf, sample)
+            out["cpu_baseline_acero"] = cpu_baseline_acero(args.query, args.sf, sample)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    group.barrier()
+    group.close()
 
 
 if __name__ == "__main__":

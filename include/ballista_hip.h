@@ -307,6 +307,9 @@ bhip_status bhip_tpch_orders(bhip_ctx* ctx, double sf, uint64_t seed, uint64_t r
 /* time (ms, HIP events on the stream the kernels ran on) and launch count of the dominant scan
  * kernel accumulated on this context since the last reset */
 bhip_status bhip_ctx_kernel_time(bhip_ctx* ctx, int32_t reset, double* ms, uint64_t* launches);
+/* every kernel timed since the last reset (BHIP_KERNEL_TIMING=1), one line per kernel: "name\tms\tlaunches\n"
+ * (NUL terminated; BHIP_EINVAL when `cap` is too small).  Waits for the timed launches to finish. */
+bhip_status bhip_ctx_kernel_stats(bhip_ctx* ctx, int32_t reset, char* buf, size_t cap);
 /* name of the kernel those launches ran ("" before the first timed launch); valid until the next call */
 const char* bhip_ctx_kernel_name(bhip_ctx* ctx);
 

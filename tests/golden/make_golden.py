@@ -13,7 +13,13 @@ reference's own DATA fixtures and three independent CPU computations that must a
      Acero `group_by().aggregate()` and the figures recorded in SURVEY.md §8(c).
   2. q1_synth.json / q6_synth.json — Q1 / Q6 over seeded synthetic lineitem (oracle/tpch_gen.c,
      sf = 0.01, 60 000 rows, 3 partitions): exact-rational expected values + Acero cross-check.
-  3. gen_pin.json — first rows and column checksums of the synthetic generator, so the CPU and
+  3. q3_synth.json / q5_synth.json / q12_synth.json — the join queries over the seeded synthetic tables (sf = 0.01), evaluated
+     by pyarrow / Acero (`Table.join`, `group_by`, `sort_by`) — an engine that shares no code with oracle/ — with the
+     per-group revenue re-summed exactly (fractions.Fraction over the separately rounded per-row products).
+     join_cases.json / sort_cases.json — Inner / Left / Right joins with duplicate and NULL keys and multi-key sorts
+     (descending, NULL placement) over small seeded tables: inputs AND pyarrow's outputs, so the oracle and the HIP path are
+     each checked against a third party rather than against each other.
+  4. gen_pin.json — first rows and column checksums of the synthetic generator, so the CPU and
      HIP generators are pinned to one spec.
 """
 import json
@@ -103,6 +109,122 @@ def exact_q6(batch):
     return dict(revenue=float(s), selected=int(sel.sum()))
 
 
+def _tbl(batch):
+    cols = {}
+    for k, c in batch.items():
+        vals = c.to_pylist()
+        if c.dtype == "Utf8":
+            cols[k] = pa.array(vals, pa.string())
+        elif c.dtype == "Date32":
+            cols[k] = pa.array(vals, pa.int32())
+        else:
+            cols[k] = pa.array(vals, {"Int32": pa.int32(), "Int64": pa.int64(), "Float64": pa.float64(), "UInt64": pa.uint64(),
+                                      "Boolean": pa.bool_(), "UInt8": pa.uint8()}[c.dtype])
+    return pa.table(cols)
+
+
+def _exact_group_sums(keys, values):
+    """{key tuple: correctly rounded sum of `values`} with exact rational accumulation"""
+    acc = {}
+    for k, v in zip(keys, values):
+        acc[k] = acc.get(k, Fraction(0)) + Fraction(float(v))
+    return {k: float(v) for k, v in acc.items()}
+
+
+def acero_q3(customer, orders, lineitem):
+    c = customer.filter(pc.equal(customer["c_mktsegment"], "BUILDING")).select(["c_custkey"])
+    o = orders.filter(pc.less(orders["o_orderdate"], 9204))
+    li = lineitem.filter(pc.greater(lineitem["l_shipdate"], 9204)).select(["l_orderkey", "l_extendedprice", "l_discount"])
+    j1 = c.join(o, keys="c_custkey", right_keys="o_custkey", join_type="inner").select(["o_orderkey", "o_orderdate", "o_shippriority"])
+    j2 = j1.join(li, keys="o_orderkey", right_keys="l_orderkey", join_type="inner")
+    rev = pc.multiply(j2["l_extendedprice"], pc.subtract(1.0, j2["l_discount"]))
+    j2 = j2.append_column("rev", rev)
+    g = j2.group_by(["o_orderkey", "o_orderdate", "o_shippriority"]).aggregate([("rev", "sum")])
+    exact = _exact_group_sums(zip(j2["o_orderkey"].to_pylist(), j2["o_orderdate"].to_pylist(), j2["o_shippriority"].to_pylist()),
+                              j2["rev"].to_pylist())
+    rows = []
+    for k, d, p, r in zip(g["o_orderkey"].to_pylist(), g["o_orderdate"].to_pylist(), g["o_shippriority"].to_pylist(), g["rev_sum"].to_pylist()):
+        e = exact[(k, d, p)]
+        assert close(e, r, 1e-12), (k, e, r)
+        rows.append(dict(l_orderkey=k, revenue=e, o_orderdate=d, o_shippriority=p))
+    rows.sort(key=lambda r: (-r["revenue"], r["o_orderdate"], r["l_orderkey"]))
+    return rows
+
+
+def acero_q5(customer, orders, lineitem, supplier, nation, region):
+    r = region.filter(pc.equal(region["r_name"], "ASIA")).select(["r_regionkey"])
+    n = r.join(nation, keys="r_regionkey", right_keys="n_regionkey", join_type="inner").select(["n_nationkey", "n_name"])
+    c = n.join(customer, keys="n_nationkey", right_keys="c_nationkey", join_type="inner").select(["c_custkey", "n_nationkey", "n_name"])
+    o = orders.filter(pc.and_(pc.greater_equal(orders["o_orderdate"], 8766), pc.less(orders["o_orderdate"], 9131))).select(["o_orderkey", "o_custkey"])
+    co = c.join(o, keys="c_custkey", right_keys="o_custkey", join_type="inner").select(["o_orderkey", "n_nationkey", "n_name"])
+    col_ = co.join(lineitem.select(["l_orderkey", "l_suppkey", "l_extendedprice", "l_discount"]), keys="o_orderkey", right_keys="l_orderkey",
+                   join_type="inner")
+    j = supplier.join(col_, keys=["s_suppkey", "s_nationkey"], right_keys=["l_suppkey", "n_nationkey"], join_type="inner")
+    rev = pc.multiply(j["l_extendedprice"], pc.subtract(1.0, j["l_discount"]))
+    exact = _exact_group_sums(j["n_name"].to_pylist(), rev.to_pylist())
+    g = j.append_column("rev", rev).group_by(["n_name"]).aggregate([("rev", "sum")])
+    for k, v in zip(g["n_name"].to_pylist(), g["rev_sum"].to_pylist()):
+        assert close(exact[k], v, 1e-12)
+    return [dict(n_name=k, revenue=v) for k, v in sorted(exact.items(), key=lambda kv: -kv[1])]
+
+
+def join_goldens():
+    from collections import OrderedDict
+    from oracle.engine import OCol
+    li, od, cu, su = gen.lineitem(SF), gen.orders(SF), gen.customer(SF), gen.supplier(SF)
+    q3 = acero_q3(_tbl(cu), _tbl(od), _tbl(li))
+    assert len(q3) > 50
+    json.dump(dict(sf=SF, seed=gen.SEED, engine=f"pyarrow {pa.__version__} + exact rational sums", rows=q3),
+              open(os.path.join(OUT, "q3_synth.json"), "w"))
+    q5 = acero_q5(_tbl(cu), _tbl(od), _tbl(li), _tbl(su), _tbl(gen.nation()), _tbl(gen.region()))
+    assert 1 <= len(q5) <= 5
+    json.dump(dict(sf=SF, seed=gen.SEED, engine=f"pyarrow {pa.__version__} + exact rational sums", rows=q5),
+              open(os.path.join(OUT, "q5_synth.json"), "w"), indent=1)
+
+    # joins with duplicate and NULL keys on both sides (SQL semantics: NULL never matches), inputs included
+    rng = np.random.default_rng(2026)
+    cases = []
+    for name, nl, nr, kmax, null_p in (("dups_and_nulls", 40, 70, 12, 0.15), ("unique_build", 30, 90, 30, 0.0), ("no_match", 10, 10, 5, 0.0),
+                                       ("all_null_left", 8, 20, 6, 1.0)):
+        lk = rng.integers(0, kmax, nl)
+        if name == "unique_build":
+            lk = rng.permutation(kmax)[:nl]
+        rk = rng.integers(0, kmax, nr) + (100 if name == "no_match" else 0)
+        lkey = [None if rng.random() < null_p else int(v) for v in lk]
+        rkey = [None if rng.random() < null_p * 0.5 else int(v) for v in rk]
+        left = dict(k=lkey, lv=[float(i) + 0.5 for i in range(nl)], ls=[None if i % 7 == 3 else f"L{i % 5}" for i in range(nl)])
+        right = dict(rk=rkey, rv=[int(i * 3) for i in range(nr)], rs=[f"R{i}" for i in range(nr)])
+        lt = pa.table({"k": pa.array(left["k"], pa.int32()), "lv": pa.array(left["lv"], pa.float64()), "ls": pa.array(left["ls"], pa.string())})
+        rt = pa.table({"rk": pa.array(right["rk"], pa.int32()), "rv": pa.array(right["rv"], pa.int64()), "rs": pa.array(right["rs"], pa.string())})
+        want = {}
+        for jt, pj in (("Inner", "inner"), ("Left", "left outer"), ("Right", "right outer")):
+            # coalesce_keys=False keeps both key columns, as HashJoinExec does for differently named keys
+            out = lt.join(rt, keys="k", right_keys="rk", join_type=pj, coalesce_keys=False).select(["k", "lv", "ls", "rk", "rv", "rs"])
+            rows = [tuple(r[c] for c in ("k", "lv", "ls", "rk", "rv", "rs")) for r in out.to_pylist()]
+            rows.sort(key=lambda r: tuple((0, 0) if v is None else (1, v) for v in r))
+            want[jt] = rows
+        cases.append(dict(name=name, left=left, right=right, expected=want))
+    json.dump(dict(engine=f"pyarrow {pa.__version__} Table.join", columns=["k", "lv", "ls", "rk", "rv", "rs"], cases=cases),
+              open(os.path.join(OUT, "join_cases.json"), "w"))
+
+    # sorts: (Int32 with NULLs, Float64 with ties, Utf8) x (asc / desc) x (nulls first / last, one placement per sort: pyarrow's limit)
+    n = 300
+    a = [None if rng.random() < 0.1 else int(v) for v in rng.integers(-5, 5, n)]
+    f = [None if rng.random() < 0.1 else float(v) / 4 for v in rng.integers(-8, 8, n)]
+    sv = [None if rng.random() < 0.1 else "".join(chr(97 + int(c)) for c in rng.integers(0, 3, rng.integers(0, 4))) for _ in range(n)]
+    rid = list(range(n))
+    t = pa.table({"a": pa.array(a, pa.int32()), "f": pa.array(f, pa.float64()), "s": pa.array(sv, pa.string()), "rid": pa.array(rid, pa.int32())})
+    sorts = []
+    for keys in ([("a", False)], [("a", True), ("f", False)], [("s", False), ("a", True)], [("f", True), ("s", True), ("a", False)], [("s", True)]):
+        for nulls_first in (True, False):
+            # rid as the last key makes the expected order total (tie order is unspecified in the operator)
+            order = [(k, "descending" if d else "ascending") for k, d in keys] + [("rid", "ascending")]
+            idx = pc.sort_indices(t, sort_keys=order, null_placement="at_start" if nulls_first else "at_end")
+            sorts.append(dict(keys=[dict(column=k, descending=d, nulls_first=nulls_first) for k, d in keys], order=idx.to_pylist()))
+    json.dump(dict(engine=f"pyarrow {pa.__version__} sort_indices", table=dict(a=a, f=f, s=sv, rid=rid), sorts=sorts),
+              open(os.path.join(OUT, "sort_cases.json"), "w"))
+
+
 def main():
     # ---- 1. the reference's own lineitem fixture --------------------------------------------------
     part = helpers.lineitem_fixture("lineitem_partition0")
@@ -136,7 +258,10 @@ def main():
     assert close(pc.sum(pc.multiply(tf["l_extendedprice"], tf["l_discount"])).as_py(), q6["revenue"])
     json.dump(dict(sf=SF, seed=gen.SEED, n_rows=n, **q6), open(os.path.join(OUT, "q6_synth.json"), "w"), indent=1)
 
-    # ---- 3. generator pin --------------------------------------------------------------------------------
+    # ---- 3. join queries, joins, sorts: pyarrow / Acero as the independent engine ---------------------------------
+    join_goldens()
+
+    # ---- 4. generator pin --------------------------------------------------------------------------------
     a = gen.lineitem_arrays(SF, dates=True)
     o = gen.orders_arrays(SF)
     c = gen.customer_arrays(SF)
