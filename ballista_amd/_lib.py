@@ -56,6 +56,23 @@ class Aggregate(C.Structure):
     _fields_ = [("fn", C.c_int32), ("arg", Expr), ("name", C.c_char_p)]
 
 
+class PartitionLocation(C.Structure):
+    _fields_ = [("job_id", C.c_char_p), ("stage_id", C.c_uint32), ("partition_id", C.c_uint32), ("executor_id", C.c_char_p),
+                ("host", C.c_char_p), ("port", C.c_uint32), ("num_rows", C.c_int64), ("num_batches", C.c_int64), ("num_bytes", C.c_int64)]
+
+
+class LeafDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("path", C.c_char_p), ("n_filenames", C.c_int32), ("filenames", C.POINTER(C.c_char_p)),
+                ("has_projection", C.c_int32), ("n_projection", C.c_int32), ("projection", C.POINTER(C.c_uint32)),
+                ("n_fields", C.c_int32), ("fields", C.POINTER(ColumnDesc)), ("has_header", C.c_int32), ("delimiter", C.c_char_p),
+                ("file_extension", C.c_char_p), ("batch_size", C.c_uint32), ("num_partitions", C.c_uint32),
+                ("n_locations", C.c_int32), ("locations", C.POINTER(PartitionLocation)), ("n_stage_ids", C.c_int32),
+                ("stage_ids", C.POINTER(C.c_uint32)), ("partition_count", C.c_uint32)]
+
+
+LEAF_RESOLVER = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(LeafDesc), C.POINTER(C.c_void_p))
+
+
 class SortExprC(C.Structure):
     _fields_ = [("expr", Expr), ("descending", C.c_int32), ("nulls_first", C.c_int32)]
 
@@ -101,6 +118,8 @@ SYMBOLS = {
     "bhip_plan_merge": (C.c_int32, [_P, _PP]),
     "bhip_plan_global_limit": (C.c_int32, [_P, C.c_int64, _PP]),
     "bhip_plan_local_limit": (C.c_int32, [_P, C.c_int64, _PP]),
+    "bhip_plan_from_proto": (C.c_int32, [_P, C.c_char_p, C.c_size_t, _P, _P, _PP]),
+    "bhip_expr_from_proto_display": (C.c_int32, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),
     "bhip_plan_retain": (None, [_P]),
     "bhip_plan_release": (None, [_P]),
     "bhip_plan_name": (C.c_char_p, [_P]),

@@ -324,6 +324,23 @@ bhip_status bhip_plan_local_limit(bhip_plan* input, int64_t limit, bhip_plan** o
     BHIP_API_END
 }
 
+bhip_status bhip_plan_from_proto(bhip_ctx* ctx, const void* bytes, size_t len, bhip_leaf_resolver resolve, void* user,
+                                 bhip_plan** out) {
+    BHIP_API_BEGIN
+    need(out, "out");
+    if (len) need(bytes, "bytes");
+    *out = wrap_plan(plan_from_proto(ctx ? ctx->p : ContextPtr(), bytes, len, resolve, user));
+    BHIP_API_END
+}
+
+bhip_status bhip_expr_from_proto_display(const void* bytes, size_t len, char* buf, size_t cap) {
+    BHIP_API_BEGIN
+    need(buf, "buf");
+    if (len) need(bytes, "bytes");
+    snprintf(buf, cap, "%s", expr_from_proto(bytes, len)->to_string().c_str());
+    BHIP_API_END
+}
+
 void bhip_plan_retain(bhip_plan* p) { if (p) p->rc.fetch_add(1); }
 void bhip_plan_release(bhip_plan* p) {
     if (p && p->rc.fetch_sub(1) == 1) delete p;
@@ -391,6 +408,7 @@ bhip_status bhip_plan_execute(bhip_plan* p, int32_t partition, bhip_stream** out
     BHIP_API_BEGIN
     need(p, "plan"); need(out, "out");
     ContextPtr ctx = p->p->context();
+    if (!ctx) fail(BHIP_EEXEC, "Ballista Error: this plan has unresolved leaves and no device context; it can be inspected, not executed");
     ctx->set_device();
     auto h = std::unique_ptr<bhip_stream>(new bhip_stream());
     h->ex = Exec{ctx, ctx->acquire_stream()};

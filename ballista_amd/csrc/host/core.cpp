@@ -19,6 +19,16 @@ const char* dtype_name(int dt) {
         case DT_DATE32: return "Date32";
         case DT_BOOLEAN: return "Boolean";
         case DT_UTF8: return "Utf8";
+        case DT_INT8: return "Int8";
+        case DT_INT16: return "Int16";
+        case DT_UINT16: return "UInt16";
+        case DT_UINT32: return "UInt32";
+        case DT_FLOAT32: return "Float32";
+        case DT_DATE64: return "Date64";
+        case DT_TIMESTAMP_S: return "Timestamp(Second)";
+        case DT_TIMESTAMP_MS: return "Timestamp(Millisecond)";
+        case DT_TIMESTAMP_US: return "Timestamp(Microsecond)";
+        case DT_TIMESTAMP_NS: return "Timestamp(Nanosecond)";
         default: return "?";
     }
 }
@@ -26,11 +36,21 @@ const char* dtype_name(int dt) {
 int dtype_width(int dt) {
     switch (dt) {
         case DT_INT32:
-        case DT_DATE32: return 4;
+        case DT_DATE32:
+        case DT_UINT32:
+        case DT_FLOAT32: return 4;
         case DT_INT64:
         case DT_UINT64:
-        case DT_FLOAT64: return 8;
-        case DT_UINT8: return 1;
+        case DT_FLOAT64:
+        case DT_DATE64:
+        case DT_TIMESTAMP_S:
+        case DT_TIMESTAMP_MS:
+        case DT_TIMESTAMP_US:
+        case DT_TIMESTAMP_NS: return 8;
+        case DT_UINT8:
+        case DT_INT8: return 1;
+        case DT_INT16:
+        case DT_UINT16: return 2;
         default: return 0;
     }
 }

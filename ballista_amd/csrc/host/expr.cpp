@@ -45,6 +45,11 @@ static int math_fn(const std::string& n) {
     return -1;
 }
 
+void check_scalar_function(const std::string& name, int n_args) {
+    if (math_fn(name) < 0) fail(BHIP_ENOTIMPL, "scalar function '" + name + "' is not supported");
+    if (n_args != 1) fail(BHIP_EINVAL, "scalar function takes one argument");
+}
+
 ExprPtr make_column(const std::string& name) {
     auto e = std::make_shared<Expr>();
     e->kind = BHIP_EXPR_COLUMN;
@@ -125,10 +130,8 @@ ExprPtr parse_expr(const bhip_expr& pe) {
                 e->args = items;
             } break;
             case BHIP_EXPR_SCALAR_FN: {
-                if (!n.name || math_fn(n.name) < 0)
-                    fail(BHIP_ENOTIMPL, std::string("scalar function '") + (n.name ? n.name : "") + "' is not supported");
+                check_scalar_function(n.name ? n.name : "", n.n_args);
                 e->name = n.name;
-                if (n.n_args != 1) fail(BHIP_EINVAL, "scalar function takes one argument");
                 e->args = {pop()};
             } break;
             default: fail(BHIP_ENOTIMPL, "unsupported expression kind " + std::to_string(n.kind));
@@ -224,6 +227,93 @@ int expr_type(const ExprPtr& e, const Schema& schema) {
         }
         case BHIP_EXPR_SCALAR_FN: return DT_FLOAT64;
         default: fail(BHIP_ENOTIMPL, "unsupported expression kind");
+    }
+}
+
+// ---- coercion -------------------------------------------------------------------------------------
+static int numeric_rank(int t) {
+    switch (t) {
+        case DT_UINT8: return 1;
+        case DT_INT32:
+        case DT_DATE32: return 2;
+        case DT_INT64: return 3;
+        case DT_UINT64: return 4;
+        case DT_FLOAT64: return 5;
+        default: return 0;
+    }
+}
+
+static int common_type(int a, int b) {
+    if (a == b) return a;
+    const int ra = numeric_rank(a), rb = numeric_rank(b);
+    if (ra && rb) {
+        if (a == DT_DATE32 || b == DT_DATE32) return DT_DATE32;
+        return ra >= rb ? a : b;
+    }
+    fail(BHIP_EINVAL, std::string("cannot coerce ") + dtype_name(a) + " and " + dtype_name(b));
+}
+
+static ExprPtr cast_to(const ExprPtr& x, int t, const Schema& schema) {
+    if (expr_type(x, schema) == t) return x;
+    if (x->kind == BHIP_EXPR_LITERAL && !x->is_null && numeric_rank(t) && numeric_rank(x->dtype)) {
+        auto l = std::make_shared<Expr>(*x);        // a numeric literal is re-typed, not cast
+        if (t == DT_FLOAT64 && x->dtype != DT_FLOAT64) l->f64 = x->dtype == DT_UINT64 ? (double)(uint64_t)x->i64 : (double)x->i64;
+        if (t != DT_FLOAT64 && x->dtype == DT_FLOAT64) l->i64 = (int64_t)x->f64;
+        l->dtype = t;
+        return l;
+    }
+    auto c = std::make_shared<Expr>();
+    c->kind = BHIP_EXPR_CAST;
+    c->dtype = t;
+    c->args = {x};
+    return c;
+}
+
+ExprPtr coerce_expr(const ExprPtr& e, const Schema& schema) {
+    switch (e->kind) {
+        case BHIP_EXPR_COLUMN:
+        case BHIP_EXPR_LITERAL: return e;
+        case BHIP_EXPR_BINARY: {
+            ExprPtr l = coerce_expr(e->args[0], schema), r = coerce_expr(e->args[1], schema);
+            if (is_arith(e->name) || is_compare(e->name)) {
+                const int t = common_type(expr_type(l, schema), expr_type(r, schema));
+                l = cast_to(l, t, schema);
+                r = cast_to(r, t, schema);
+            }
+            return make_binary(l, e->name, r);
+        }
+        case BHIP_EXPR_IN_LIST: {
+            auto c = std::make_shared<Expr>(*e);
+            c->args[0] = coerce_expr(e->args[0], schema);
+            const int t = expr_type(c->args[0], schema);
+            for (size_t i = 1; i < c->args.size(); ++i) c->args[i] = cast_to(coerce_expr(e->args[i], schema), t, schema);
+            return c;
+        }
+        case BHIP_EXPR_CASE: {
+            auto c = std::make_shared<Expr>(*e);
+            for (auto& a : c->args) a = coerce_expr(a, schema);
+            size_t fw, np;
+            case_layout(*c, fw, np);
+            int t = expr_type(c->args[fw + 1], schema);
+            for (size_t i = 1; i < np; ++i) t = common_type(t, expr_type(c->args[fw + 2 * i + 1], schema));
+            if (c->has_else) t = common_type(t, expr_type(c->args.back(), schema));
+            for (size_t i = 0; i < np; ++i) {
+                if (c->has_base) c->args[fw + 2 * i] = cast_to(c->args[fw + 2 * i], expr_type(c->args[0], schema), schema);
+                c->args[fw + 2 * i + 1] = cast_to(c->args[fw + 2 * i + 1], t, schema);
+            }
+            if (c->has_else) c->args.back() = cast_to(c->args.back(), t, schema);
+            return c;
+        }
+        case BHIP_EXPR_SCALAR_FN: {
+            auto c = std::make_shared<Expr>(*e);
+            for (auto& a : c->args) a = cast_to(coerce_expr(a, schema), DT_FLOAT64, schema);
+            return c;
+        }
+        default: {
+            auto c = std::make_shared<Expr>(*e);
+            for (auto& a : c->args) a = coerce_expr(a, schema);
+            return c;
+        }
     }
 }
 

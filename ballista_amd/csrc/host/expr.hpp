@@ -39,6 +39,13 @@ ExprPtr make_binary(const ExprPtr& l, const std::string& op, const ExprPtr& r);
 ExprPtr substitute(const ExprPtr& e, const std::map<std::string, ExprPtr>& subst);
 void collect_columns(const ExprPtr& e, std::vector<std::string>& out);
 
+// the casts DataFusion's physical planner inserts (create_physical_expr behind compile_expr,
+// rust/core/src/serde/physical_plan/from_proto.rs:348-364): both sides of a comparison / arithmetic node, the items of an
+// IN list and the branches of a CASE are brought to one type, numeric literals are re-typed instead of cast
+ExprPtr coerce_expr(const ExprPtr& e, const Schema& schema);
+// BHIP_ENOTIMPL unless the device evaluates `name` with `n_args` arguments
+void check_scalar_function(const std::string& name, int n_args);
+
 int expr_type(const ExprPtr& e, const Schema& schema);
 bool expr_nullable(const ExprPtr& e, const Schema& schema);
 

@@ -262,6 +262,10 @@ private:
     std::shared_ptr<SplitCache> cache_;
 };
 
+// the wire plan (proto.cpp): protobuf PhysicalPlanNode -> operator tree; ctx may be null (inspection only)
+PlanPtr plan_from_proto(const ContextPtr& ctx, const void* bytes, size_t len, bhip_leaf_resolver resolver, void* user);
+ExprPtr expr_from_proto(const void* bytes, size_t len);
+
 // shared helpers (ops_*.cpp)
 // evaluate `predicate` over `in` and return the surviving rows as ascending indices
 int64_t filter_indices(const Exec& ex, const Batch& in, const ExprPtr& predicate, BufferPtr& indices_out);

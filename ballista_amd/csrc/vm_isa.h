@@ -18,7 +18,11 @@ namespace bhip {
 // ---- Arrow types at the boundary (SURVEY §8(b) "Data types at the edge") -------------
 enum DType : int32_t {
     DT_INT32 = 1, DT_INT64 = 2, DT_UINT8 = 3, DT_UINT64 = 4, DT_FLOAT64 = 5,
-    DT_DATE32 = 6, DT_BOOLEAN = 7, DT_UTF8 = 8
+    DT_DATE32 = 6, DT_BOOLEAN = 7, DT_UTF8 = 8,
+    // the other primitive types the serde can ship (rust/core/proto/ballista.proto:755-790)
+    DT_INT8 = 9, DT_INT16 = 10, DT_UINT16 = 11, DT_UINT32 = 12, DT_FLOAT32 = 13, DT_DATE64 = 14,
+    DT_TIMESTAMP_S = 15, DT_TIMESTAMP_MS = 16, DT_TIMESTAMP_US = 17, DT_TIMESTAMP_NS = 18,
+    DT_LAST = 18
 };
 
 // value class of a VM slot

@@ -18,7 +18,9 @@ import numpy as np
 from . import _lib as L
 from . import expr as E
 
-DTYPE_ID = {E.INT32: 1, E.INT64: 2, E.UINT8: 3, E.UINT64: 4, E.FLOAT64: 5, E.DATE32: 6, E.BOOLEAN: 7, E.UTF8: 8}
+DTYPE_ID = {E.INT32: 1, E.INT64: 2, E.UINT8: 3, E.UINT64: 4, E.FLOAT64: 5, E.DATE32: 6, E.BOOLEAN: 7, E.UTF8: 8,
+            "Int8": 9, "Int16": 10, "UInt16": 11, "UInt32": 12, "Float32": 13, "Date64": 14, "Timestamp(Second)": 15,
+            "Timestamp(Millisecond)": 16, "Timestamp(Microsecond)": 17, "Timestamp(Nanosecond)": 18}
 DTYPE_NAME = {v: k for k, v in DTYPE_ID.items()}
 NP_DTYPE = {E.INT32: np.int32, E.INT64: np.int64, E.UINT8: np.uint8, E.UINT64: np.uint64,
             E.FLOAT64: np.float64, E.DATE32: np.int32}
@@ -501,7 +503,7 @@ class ExecutionPlan:
     def __init__(self, handle, ctx, children=()):
         self._h = handle
         self.ctx = ctx
-        self._children = list(children)
+        self._children = None if children is None else list(children)
 
     def __del__(self):
         try:
@@ -523,7 +525,57 @@ class ExecutionPlan:
         return Partitioning(s.value, n.value)
 
     def children(self) -> List["ExecutionPlan"]:
+        if self._children is None:             # a plan the library built (from_proto): ask it
+            n = C.c_int32()
+            L.check(L.lib().bhip_plan_children(self._h, 0, None, C.byref(n)))
+            arr = (C.c_void_p * max(1, n.value))()
+            L.check(L.lib().bhip_plan_children(self._h, n.value, arr, C.byref(n)))
+            self._children = [ExecutionPlan(C.c_void_p(arr[i]), self.ctx, None) for i in range(n.value)]
         return list(self._children)
+
+    @staticmethod
+    def from_proto(ctx: Optional["Context"], data: bytes, resolver=None) -> "ExecutionPlan":
+        """bhip_plan_from_proto: the protobuf bytes of a PhysicalPlanNode (rust/core/proto/ballista.proto:294-312) ->
+        operator tree (rust/core/src/serde/physical_plan/from_proto.rs:58-346).  resolver(leaf: dict) -> ExecutionPlan | None
+        is offered every scan / shuffle leaf.  ctx None: the plan can be inspected, not executed."""
+        keep, err = [], []
+
+        def _cb(_user, leaf_p, out_p):
+            try:
+                d = leaf_p.contents
+                fields = [(d.fields[i].name.decode(), DTYPE_NAME[d.fields[i].dtype], bool(d.fields[i].nullable)) for i in range(d.n_fields)]
+                leaf = dict(kind={1: "CsvScan", 2: "ParquetScan", 3: "ShuffleReader", 4: "UnresolvedShuffle"}[d.kind],
+                            path=(d.path or b"").decode(), filenames=[d.filenames[i].decode() for i in range(d.n_filenames)],
+                            projection=[d.projection[i] for i in range(d.n_projection)] if d.has_projection else None, fields=fields,
+                            has_header=bool(d.has_header), delimiter=(d.delimiter or b"").decode(),
+                            file_extension=(d.file_extension or b"").decode(), batch_size=d.batch_size, num_partitions=d.num_partitions,
+                            locations=[dict(job_id=d.locations[i].job_id.decode(), stage_id=d.locations[i].stage_id,
+                                            partition_id=d.locations[i].partition_id, executor_id=d.locations[i].executor_id.decode(),
+                                            host=d.locations[i].host.decode(), port=d.locations[i].port,
+                                            num_rows=d.locations[i].num_rows, num_batches=d.locations[i].num_batches,
+                                            num_bytes=d.locations[i].num_bytes) for i in range(d.n_locations)],
+                            stage_ids=[d.stage_ids[i] for i in range(d.n_stage_ids)], partition_count=d.partition_count)
+                got = resolver(leaf)
+                if got is None:
+                    out_p[0] = None
+                else:
+                    keep.append(got)
+                    L.lib().bhip_plan_retain(got._h)          # ownership of the handle passes to the library
+                    out_p[0] = got._h.value if isinstance(got._h, C.c_void_p) else got._h
+                return L.OK
+            except BaseException as e:                          # noqa: BLE001 - must not unwind through C
+                err.append(e)
+                return L.EINVAL
+
+        cb = L.LEAF_RESOLVER(_cb) if resolver is not None else None
+        h = C.c_void_p()
+        st = L.lib().bhip_plan_from_proto(ctx._h if ctx is not None else None, data, len(data), cb, None, C.byref(h))
+        if err:
+            raise err[0]
+        L.check(st)
+        plan = ExecutionPlan(h, ctx, None)
+        plan._leaves = keep
+        return plan
 
     def with_new_children(self, children: Sequence["ExecutionPlan"]) -> "ExecutionPlan":
         arr = (C.c_void_p * max(1, len(children)))(*[c._h for c in children])
@@ -531,7 +583,7 @@ class ExecutionPlan:
         L.check(L.lib().bhip_plan_with_new_children(self._h, len(children), arr, C.byref(h)))
         new = object.__new__(type(self))
         new.__dict__.update(self.__dict__)
-        ExecutionPlan.__init__(new, h, self.ctx, children)
+        ExecutionPlan.__init__(new, h, self.ctx, list(children))
         if len(children) == 1 and hasattr(self, "input"):
             new.input = children[0]
         if len(children) == 2 and hasattr(self, "left"):

@@ -96,7 +96,10 @@ const char* bhip_version(void);
 /* ---- types (Arrow types of the TPC-H schemas, rust/benchmarks/tpch/src/main.rs:267-360) */
 typedef enum {
     BHIP_INT32 = 1, BHIP_INT64 = 2, BHIP_UINT8 = 3, BHIP_UINT64 = 4, BHIP_FLOAT64 = 5,
-    BHIP_DATE32 = 6, BHIP_BOOLEAN = 7, BHIP_UTF8 = 8
+    BHIP_DATE32 = 6, BHIP_BOOLEAN = 7, BHIP_UTF8 = 8,
+    /* the other primitive types of the serde (rust/core/proto/ballista.proto:755-790) */
+    BHIP_INT8 = 9, BHIP_INT16 = 10, BHIP_UINT16 = 11, BHIP_UINT32 = 12, BHIP_FLOAT32 = 13, BHIP_DATE64 = 14,
+    BHIP_TIMESTAMP_S = 15, BHIP_TIMESTAMP_MS = 16, BHIP_TIMESTAMP_US = 17, BHIP_TIMESTAMP_NS = 18
 } bhip_dtype;
 
 typedef struct bhip_ctx bhip_ctx;        /* one GPU: allocator, stream pool */
@@ -250,6 +253,55 @@ bhip_status bhip_plan_coalesce_batches(bhip_plan* input, int64_t target_batch_si
 bhip_status bhip_plan_merge(bhip_plan* input, bhip_plan** out);                                       /* :129-132 */
 bhip_status bhip_plan_global_limit(bhip_plan* input, int64_t limit, bhip_plan** out);                 /* :165-168 */
 bhip_status bhip_plan_local_limit(bhip_plan* input, int64_t limit, bhip_plan** out);                  /* :169-172 */
+
+/* ---- the wire plan ------------------------------------------------------------------------------
+ * bhip_plan_from_proto: `impl TryInto<Arc<dyn ExecutionPlan>> for &protobuf::PhysicalPlanNode`
+ * (rust/core/src/serde/physical_plan/from_proto.rs:58-346): `bytes` is the protobuf encoding of a PhysicalPlanNode
+ * (rust/core/proto/ballista.proto:294-312) exactly as a task carries it (TaskDefinition.plan :531-534,
+ * ExecutePartition.plan :451-458).  Expressions are planned against their input schema with DataFusion's coercion
+ * rules (compile_expr, :348-364).  Every leaf (CsvScan / ParquetScan / ShuffleReader / UnresolvedShuffle) is offered
+ * to `resolve` (may be NULL): it returns BHIP_OK with *out = a plan that produces the leaf's rows (a bhip_plan_memory, a
+ * bhip_plan_arrow_stream over a CPU reader ...; ownership of that handle passes to the library), or BHIP_OK with *out = NULL to leave the leaf to the library:
+ * a CsvScan over '|'-separated header-less local files becomes the device `.tbl` scan (bhip_batch_from_tbl), any
+ * other leaf an operator that describes itself and fails on execute with BHIP_EEXEC
+ * (UnresolvedShuffleExec::execute, rust/core/src/execution_plans/unresolved_shuffle.rs:83-90).
+ * `ctx` may be NULL when every leaf is left unresolved: the plan can then be inspected (bhip_plan_display, _schema,
+ * _children) but not executed — what the CPU-only tests use. */
+typedef enum {
+    BHIP_LEAF_CSV_SCAN = 1, BHIP_LEAF_PARQUET_SCAN = 2, BHIP_LEAF_SHUFFLE_READER = 3, BHIP_LEAF_UNRESOLVED_SHUFFLE = 4
+} bhip_leaf_kind;
+typedef struct {                 /* PartitionLocation, ballista.proto:461-465 */
+    const char* job_id;
+    uint32_t stage_id, partition_id;
+    const char* executor_id;
+    const char* host;
+    uint32_t port;
+    int64_t num_rows, num_batches, num_bytes;       /* PartitionStats; -1 = not sent */
+} bhip_partition_location;
+typedef struct {
+    int32_t kind;                                   /* bhip_leaf_kind */
+    const char* path;                               /* CsvScan */
+    int32_t n_filenames;
+    const char* const* filenames;                   /* CsvScan partition files / ParquetScan files */
+    int32_t has_projection, n_projection;
+    const uint32_t* projection;                     /* indices into `fields` (CsvScan) / the file schema (ParquetScan) */
+    int32_t n_fields;
+    const bhip_column_desc* fields;                 /* CsvScan: the FILE's fields; shuffle leaves: the output schema */
+    int32_t has_header;
+    const char* delimiter;
+    const char* file_extension;
+    uint32_t batch_size, num_partitions;
+    int32_t n_locations;
+    const bhip_partition_location* locations;       /* ShuffleReader */
+    int32_t n_stage_ids;
+    const uint32_t* stage_ids;                      /* UnresolvedShuffle */
+    uint32_t partition_count;
+} bhip_leaf_desc;
+typedef bhip_status (*bhip_leaf_resolver)(void* user, const bhip_leaf_desc* leaf, bhip_plan** out);
+bhip_status bhip_plan_from_proto(bhip_ctx* ctx, const void* bytes, size_t len, bhip_leaf_resolver resolve, void* user,
+                                 bhip_plan** out);
+/* one LogicalExprNode (ballista.proto:14-45) rendered the way plan displays render expressions; for tools and tests */
+bhip_status bhip_expr_from_proto_display(const void* bytes, size_t len, char* buf, size_t cap);
 
 void bhip_plan_retain(bhip_plan* plan);
 void bhip_plan_release(bhip_plan* plan);
