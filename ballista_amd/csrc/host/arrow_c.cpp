@@ -8,6 +8,8 @@
 #include <cstring>
 
 #include "../util_kernels.h"
+#include <memory>
+#include <mutex>
 #include "plan.hpp"
 
 using namespace bhip;
@@ -312,72 +314,85 @@ bhip_status bhip_batch_import_arrow(bhip_ctx* ctx, struct ArrowArray* array, str
 
 namespace {
 
-// Leaf over a host-side Arrow C stream (the C image of a DataFusion child operator's RecordBatchStream): the stream
-// is drained on the first execute, each batch imported to the device; later executes replay the device batches.
+// Leaf over host-side Arrow C streams (the C image of a DataFusion child operator's RecordBatchStream, one per output
+// partition): a partition's stream is drained on its first execute, each batch imported to the device; later executes replay
+// the device batches.
 class ArrowStreamExec : public bhip::ExecutionPlan {
 public:
-    ArrowStreamExec(bhip::ContextPtr ctx, ArrowArrayStream* stream, bhip::SchemaPtr schema) : schema_(std::move(schema)) {
+    ArrowStreamExec(bhip::ContextPtr ctx, int n, ArrowArrayStream* const* streams, bhip::SchemaPtr schema) : schema_(std::move(schema)) {
         ctx_ = std::move(ctx);
         own_.p = ctx_;                  // a context handle of its own for the batch import
-        stream_ = *stream;              // the stream is moved into the plan (C stream interface ownership)
-        stream->release = nullptr;
+        for (int i = 0; i < n; ++i) {
+            auto p = std::make_unique<Part>();
+            p->stream = *streams[i];    // the streams are moved into the plan (C stream interface ownership)
+            streams[i]->release = nullptr;
+            parts_.push_back(std::move(p));
+        }
     }
     ~ArrowStreamExec() override {
-        if (stream_.release) stream_.release(&stream_);
+        for (auto& p : parts_)
+            if (p->stream.release) p->stream.release(&p->stream);
     }
     const char* name() const override { return "ArrowStreamExec"; }
     bhip::SchemaPtr schema() const override { return schema_; }
-    bhip::Partitioning output_partitioning() const override { return bhip::Partitioning{BHIP_PART_UNKNOWN, 1, {}}; }
+    bhip::Partitioning output_partitioning() const override { return bhip::Partitioning{BHIP_PART_UNKNOWN, (int)parts_.size(), {}}; }
     std::vector<bhip::PlanPtr> children() const override { return {}; }
     bhip::PlanPtr with_new_children(const std::vector<bhip::PlanPtr>& c) const override {
         if (!c.empty()) fail(BHIP_EINVAL, "ArrowStreamExec has no children");
         return shared_from_this();
     }
-    std::string describe() const override { return "ArrowStreamExec"; }
+    std::string describe() const override { return "ArrowStreamExec: partitions=" + std::to_string(parts_.size()); }
     bhip::StreamPtr execute(int partition, const bhip::Exec&) const override {
-        if (partition != 0) fail(BHIP_EINVAL, "ArrowStreamExec invalid partition " + std::to_string(partition));
-        std::lock_guard<std::mutex> g(mu_);
-        if (!drained_) {
+        if (partition < 0 || partition >= (int)parts_.size()) fail(BHIP_EINVAL, "ArrowStreamExec invalid partition " + std::to_string(partition));
+        Part& P = *parts_[partition];
+        std::lock_guard<std::mutex> g(P.mu);
+        if (!P.drained) {
             for (;;) {
                 ArrowArray arr;
                 memset(&arr, 0, sizeof(arr));
-                if (stream_.get_next(&stream_, &arr) != 0) {
-                    const char* m = stream_.get_last_error ? stream_.get_last_error(&stream_) : nullptr;
+                if (P.stream.get_next(&P.stream, &arr) != 0) {
+                    const char* m = P.stream.get_last_error ? P.stream.get_last_error(&P.stream) : nullptr;
                     fail(BHIP_EEXEC, std::string("Arrow stream: ") + (m ? m : "get_next failed"));
                 }
                 if (!arr.release) break;                       // end of stream
                 ArrowSchema sch;
                 memset(&sch, 0, sizeof(sch));
-                if (stream_.get_schema(&stream_, &sch) != 0) { arr.release(&arr); fail(BHIP_EEXEC, "Arrow stream: get_schema failed"); }
+                if (P.stream.get_schema(&P.stream, &sch) != 0) { arr.release(&arr); fail(BHIP_EEXEC, "Arrow stream: get_schema failed"); }
                 bhip_batch* b = nullptr;
                 const bhip_status st = bhip_batch_import_arrow(&own_, &arr, &sch, &b);
                 if (sch.release) sch.release(&sch);
                 if (st != BHIP_OK) { if (arr.release) arr.release(&arr); fail(st, bhip_last_error()); }
-                batches_.push_back(b->p);
+                P.batches.push_back(b->p);
                 bhip_batch_release(b);
             }
-            drained_ = true;
-            stream_.release(&stream_);                         // the producer is done with: let it go now
-            stream_.release = nullptr;
+            P.drained = true;
+            P.stream.release(&P.stream);                       // the producer is done with: let it go now
+            P.stream.release = nullptr;
         }
-        return bhip::StreamPtr(new bhip::VecStream(schema_, batches_));
+        return bhip::StreamPtr(new bhip::VecStream(schema_, P.batches));
     }
 private:
+    struct Part {
+        ArrowArrayStream stream;
+        std::mutex mu;
+        bool drained = false;
+        std::vector<bhip::BatchPtr> batches;
+    };
     mutable bhip_ctx own_;
     bhip::SchemaPtr schema_;
-    mutable ArrowArrayStream stream_;
-    mutable std::mutex mu_;
-    mutable bool drained_ = false;
-    mutable std::vector<bhip::BatchPtr> batches_;
+    std::vector<std::unique_ptr<Part>> parts_;
 };
 
 }  // namespace
 
 extern "C" {
 
-bhip_status bhip_plan_arrow_stream(bhip_ctx* ctx, struct ArrowArrayStream* stream, bhip_plan** out) {
+bhip_status bhip_plan_arrow_streams(bhip_ctx* ctx, int32_t n_partitions, struct ArrowArrayStream* const* streams, bhip_plan** out) {
     try {
-        if (!ctx || !stream || !out || !stream->get_schema) fail(BHIP_EINVAL, "null argument");
+        if (!ctx || !streams || !out || n_partitions < 1) fail(BHIP_EINVAL, "null argument");
+        for (int i = 0; i < n_partitions; ++i)
+            if (!streams[i] || !streams[i]->get_schema || !streams[i]->release) fail(BHIP_EINVAL, "released or null Arrow stream");
+        ArrowArrayStream* stream = streams[0];
         ArrowSchema sch;
         memset(&sch, 0, sizeof(sch));
         if (stream->get_schema(stream, &sch) != 0) fail(BHIP_EEXEC, "Arrow stream: get_schema failed");
@@ -393,11 +408,15 @@ bhip_status bhip_plan_arrow_stream(bhip_ctx* ctx, struct ArrowArrayStream* strea
         if (sch.release) sch.release(&sch);
         if (!err.empty()) fail(strncmp(err.c_str(), "unsupported", 11) == 0 ? BHIP_ENOTIMPL : BHIP_EINVAL, err);
         auto* h = new bhip_plan();
-        h->p = std::make_shared<ArrowStreamExec>(ctx->p, stream, schema);
+        h->p = std::make_shared<ArrowStreamExec>(ctx->p, (int)n_partitions, streams, schema);
         *out = h;
         return BHIP_OK;
     } catch (const bhip::Error& e) { set_last_error(e.what()); return e.code; }
     catch (const std::exception& e) { set_last_error(e.what()); return BHIP_EINVAL; }
+}
+
+bhip_status bhip_plan_arrow_stream(bhip_ctx* ctx, struct ArrowArrayStream* stream, bhip_plan** out) {
+    return bhip_plan_arrow_streams(ctx, 1, &stream, out);
 }
 
 bhip_status bhip_batch_export_arrow(bhip_batch* batch, struct ArrowArray* out_array, struct ArrowSchema* out_schema) {

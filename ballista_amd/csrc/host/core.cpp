@@ -67,7 +67,7 @@ Context::Context(int device) : device_(device) {
     HIP_CHECK(hipGetDeviceProperties(&prop, device));
     cus_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const char* t = getenv("BHIP_KERNEL_TIMING");
-    timing_ = t && atoi(t) != 0;
+    timing_ = t ? atoi(t) : 0;
 }
 
 Context::~Context() {

@@ -73,7 +73,8 @@ public:
     void add_kernel_time(double ms, uint64_t launches, const char* kernel = nullptr);
     std::string kernel_name();
     void kernel_time(bool reset, double* ms, uint64_t* launches);
-    bool timing_enabled() const { return timing_; }
+    bool timing_enabled() const { return timing_ > 0; }
+    int timing_level() const { return timing_; }
     // per-kernel-name totals (BHIP_KERNEL_TIMING=1): event pairs queued by KernelTimer are resolved when read
     struct KernelStat { double ms = 0; uint64_t launches = 0; };
     void push_timed(hipEvent_t a, hipEvent_t b, const char* name);
@@ -83,7 +84,7 @@ public:
 private:
     int device_;
     int cus_ = 256;
-    bool timing_ = false;
+    int timing_ = 0;
     std::mutex mu_;
     std::multimap<size_t, Block> free_blocks_;
     std::map<void*, Block> live_;
@@ -112,8 +113,11 @@ struct KernelTimer {
     const Exec& ex;
     const char* name;
     hipEvent_t a = nullptr, b = nullptr;
-    KernelTimer(const Exec& e, const char* n) : ex(e), name(n) {
-        if (!ex.ctx->timing_enabled()) return;
+    // rows: what the launch covers.  BHIP_KERNEL_TIMING=1 times launches over >= 2^18 rows only (an event pair per tiny
+    // launch would stretch the small-launch tail it is there to measure); =2 times every launch
+    KernelTimer(const Exec& e, const char* n, int64_t rows = -1) : ex(e), name(n) {
+        const int level = ex.ctx->timing_level();
+        if (level <= 0 || (level == 1 && rows < (1 << 18))) return;
         a = ex.ctx->timing_event();
         b = ex.ctx->timing_event();
         hipEventRecord(a, ex.stream);
@@ -128,6 +132,7 @@ struct KernelTimer {
 };
 
 #define TIMED_LAUNCH(ex, name, call) do { ::bhip::KernelTimer _kt((ex), (name)); HIP_CHECK(call); } while (0)
+#define TIMED_LAUNCH_N(ex, name, rows, call) do { ::bhip::KernelTimer _kt((ex), (name), (int64_t)(rows)); HIP_CHECK(call); } while (0)
 
 // ---- device buffers -----------------------------------------------------------------------------
 constexpr size_t BUFFER_SLACK = 16;

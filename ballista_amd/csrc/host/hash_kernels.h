@@ -80,6 +80,22 @@ hipError_t launch_join_build_narrow(const LaunchCfg& cfg, const NarrowJoinTable&
 hipError_t launch_join_probe_match_narrow(const LaunchCfg& cfg, const NarrowJoinTable& T, const void* rkeys, int key_width,
                                           const uint64_t* rsel, const uint32_t* gather, uint32_t n_right, bool right_outer,
                                           uint32_t* partner, uint64_t* bitmap, uint32_t* tile_counts, uint32_t* matched);
+// the probe side as one pass over the UNFILTERED batch (kernels_join.hip): AND of integer ranges over NULL-free
+// Int32 / Date32 columns (n = 0: no filter) -> key-set bitmap -> table.  One wave owns a whole 1024-row tile: tile_counts[] are
+// plain stores (no memset needed), staging[tile * 1024 + j] = build row of the tile's j-th emitted row (staging may be null:
+// a semi-join needs no partners).  Then: exclusive scan of tile_counts, launch_select_indices for the row indices,
+// launch_join_compact_staged for the partners.
+constexpr int JOIN_FILTER_MAX = 3;
+struct ProbeFilter {
+    int32_t n;
+    int32_t lo[JOIN_FILTER_MAX], hi[JOIN_FILTER_MAX];
+    const int32_t* col[JOIN_FILTER_MAX];
+};
+hipError_t launch_join_filter_probe(const LaunchCfg& cfg, const NarrowJoinTable& T, const ProbeFilter& F, const void* rkeys, int key_width,
+                                    const uint64_t* rsel, uint32_t n_right, bool right_outer, uint64_t* bitmap, uint32_t* tile_counts,
+                                    uint32_t* staging, uint32_t* matched);
+hipError_t launch_join_compact_staged(const LaunchCfg& cfg, const uint32_t* staging, const uint64_t* tile_off, uint64_t total,
+                                      int64_t n_tiles, uint32_t* out);
 hipError_t launch_join_unmatched_flags(const LaunchCfg& cfg, const uint32_t* matched, uint32_t n_left, uint32_t* flags);
 hipError_t launch_compact_flags(const LaunchCfg& cfg, const uint32_t* flags, const uint64_t* offsets, uint32_t n, uint32_t* out);
 

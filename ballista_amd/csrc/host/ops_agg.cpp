@@ -195,8 +195,8 @@ GroupRec* hash_aggregate(const Exec& ex, Temp& tmp, const ScanParams& P0, const 
     for (auto& b : inputs) {
         ScanParams P = P0;
         ProgramBuilder::bind(P, pb.columns(), *b, nullable);
-        TIMED_LAUNCH(ex, "scan_keys", launch_scan_keys(cfg, P, keys + 2ull * row_base, nullptr, nullptr, status));
-        TIMED_LAUNCH(ex, "scan_agg_hash", launch_scan_agg_hash(cfg, P, T, row_base, status));
+        TIMED_LAUNCH_N(ex, "scan_keys", b->n_rows, launch_scan_keys(cfg, P, keys + 2ull * row_base, nullptr, nullptr, status));
+        TIMED_LAUNCH_N(ex, "scan_agg_hash", b->n_rows, launch_scan_agg_hash(cfg, P, T, row_base, status));
         row_base += (uint32_t)b->n_rows;
     }
     // used slots -> dense records (slot order: deterministic for a given input)
@@ -204,12 +204,12 @@ GroupRec* hash_aggregate(const Exec& ex, Temp& tmp, const ScanParams& P0, const 
     uint64_t* dense = tmp.get<uint64_t>(cap + 1);
     uint64_t* total = tmp.get<uint64_t>(1);
     void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes((int64_t)cap));
-    TIMED_LAUNCH(ex, "hash_agg_flags", launch_hash_agg_flags(cfg, T, flags));
+    TIMED_LAUNCH_N(ex, "hash_agg_flags", cap, launch_hash_agg_flags(cfg, T, flags));
     HIP_CHECK(exclusive_scan_u32_u64(ex.stream, flags, (int64_t)cap, dense, false, total, scan_tmp));
     const uint64_t ng = read_device(ex, total);
     check_scan_status(ex, status);                   // after the one wait above: the stream is idle, this read is immediate
     GroupRec* table = tmp.get<GroupRec>(ng ? ng : 1);
-    if (ng) TIMED_LAUNCH(ex, "hash_agg_compact", launch_hash_agg_compact(cfg, T, dense, nullable, table));
+    if (ng) TIMED_LAUNCH_N(ex, "hash_agg_compact", cap, launch_hash_agg_compact(cfg, T, dense, nullable, table));
     *n_groups = (int64_t)ng;
     return table;
 }
@@ -335,7 +335,15 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
     // ---- input ------------------------------------------------------------------------------------
     std::vector<BatchPtr> inputs;
     {
-        auto s = f.source->execute(partition, ex);
+        StreamPtr s;
+        if (auto hj = dynamic_cast<const HashJoinExec*>(f.source.get())) {
+            // aggregate over a join: the join gathers only the columns the aggregate's program reads
+            std::vector<bool> needed(src_schema.fields.size(), false);
+            for (int ci : pb.columns()) needed[ci] = true;
+            s = hj->execute_needed(partition, ex, needed);
+        } else {
+            s = f.source->execute(partition, ex);
+        }
         while (BatchPtr b = s->next())
             if (b->n_rows > 0) inputs.push_back(b);
     }
@@ -366,7 +374,20 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
     if (hint == 8 || hint == -1) gmax = hint;
     if (n_acc > AGG_NACC) gmax = -1;
 
+    // A plan that has not run yet does not know how many groups there are.  With a large input the ladder below (4 groups per
+    // workgroup -> 8 -> hash table) is first walked on the leading 32 Ki rows only: an aggregate with many groups (Q3: one per
+    // order) finds out for the price of two tiny launches instead of two passes over the whole input.
+    std::vector<BatchPtr> sample;
+    int64_t total_in = 0;
+    for (auto& b : inputs) total_in += b->n_rows;
+    if (hint == 0 && gmax > 0 && !group_.empty() && total_in >= (1 << 20)) {
+        auto head = std::make_shared<Batch>(*inputs[0]);
+        head->n_rows = std::min<int64_t>(head->n_rows, 32768);
+        sample.push_back(head);
+    }
     while (!inputs.empty()) {
+        const bool sampling = !sample.empty();
+        const std::vector<BatchPtr>& cur = sampling ? sample : inputs;
         if (gmax == -1) {
             // ---- hash path: one device-wide table, atomics ----------------------------------------
             sop_layout = false;              // the hash path packs keys with the VM's layout
@@ -375,7 +396,7 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
         }
         // ---- register path ----------------------------------------------------------------------
         const int max_grid = scan_agg_lowcard_max_grid(cfg);
-        const size_t max_parts = inputs.size() * (size_t)max_grid;
+        const size_t max_parts = cur.size() * (size_t)max_grid;
         GroupRec* partials = tmp.get<GroupRec>(max_parts * gmax);
         uint32_t* partial_ng = tmp.get<uint32_t>(max_parts);
         HIP_CHECK(hipMemsetAsync(status, 0, sizeof(ScanStatus), ex.stream));
@@ -383,7 +404,7 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
         const bool lean_now = use_lean && (gmax == 1 || gmax == 4);
         const bool sop_now = !lean_now && use_sop;
         sop_layout = lean_now || sop_now;
-        for (auto& b : inputs) {
+        for (auto& b : cur) {
             ScanParams P = P0;
             ProgramBuilder::bind(P, pb.columns(), *b, nullable);
             int grid = 0;
@@ -423,8 +444,10 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
         if (st.flags & SCAN_OVERFLOW_GROUPS) {
             gmax = gmax == 4 ? 8 : -1;       // more groups than the register path holds: widen, then hash
             path_hint_.store(gmax);
+            if (gmax == -1) sample.clear();
             continue;
         }
+        if (sampling) { sample.clear(); continue; }       // the head fits this width: now the whole input
         n_groups = st.n_groups;
         break;
     }

@@ -64,7 +64,7 @@ Column take_column(const Exec& ex, const Column& c, const uint32_t* idx, int64_t
     if (c.dtype == DT_UTF8) {
         Temp tmp(ex);
         uint32_t* lengths = tmp.get<uint32_t>((size_t)n + 1);
-        TIMED_LAUNCH(ex, "take_utf8_lengths", launch_take_utf8_lengths(cfg, c.offsets->as<int32_t>(), idx, n, lengths));
+        TIMED_LAUNCH_N(ex, "take_utf8_lengths", n, launch_take_utf8_lengths(cfg, c.offsets->as<int32_t>(), idx, n, lengths));
         out.offsets = make_buffer(ex, (size_t)(n + 1) * 4);
         uint64_t* total = tmp.get<uint64_t>(1);
         void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes(n));
@@ -73,7 +73,7 @@ Column take_column(const Exec& ex, const Column& c, const uint32_t* idx, int64_t
         if (bytes > 0x7FFFFFFFull) fail(BHIP_EEXEC, "Utf8 column exceeds 2 GiB of value bytes");
         out.data_bytes = (int64_t)bytes;
         out.data = make_buffer(ex, (size_t)bytes + 8);
-        TIMED_LAUNCH(ex, "take_utf8_copy", launch_take_utf8_copy(cfg, c.offsets->as<int32_t>(), c.data->as<uint8_t>(), idx, n,
+        TIMED_LAUNCH_N(ex, "take_utf8_copy", n, launch_take_utf8_copy(cfg, c.offsets->as<int32_t>(), c.data->as<uint8_t>(), idx, n,
                                         out.offsets->as<int32_t>(), out.data->as<uint8_t>()));
     } else if (c.dtype == DT_BOOLEAN) {
         out.data = make_buffer(ex, bitmap_bytes(n) + 8);
@@ -81,7 +81,7 @@ Column take_column(const Exec& ex, const Column& c, const uint32_t* idx, int64_t
     } else {
         const int w = dtype_width(c.dtype);
         out.data = make_buffer(ex, (size_t)n * w + 8);
-        TIMED_LAUNCH(ex, "take_fixed", launch_take_fixed(cfg, c.data->ptr(), w, idx, n, out.data->ptr()));
+        TIMED_LAUNCH_N(ex, "take_fixed", n, launch_take_fixed(cfg, c.data->ptr(), w, idx, n, out.data->ptr()));
     }
     return out;
 }
@@ -106,7 +106,7 @@ std::vector<Column> take_columns(const Exec& ex, const std::vector<const Column*
     TakeMany tm;
     tm.n = 0;
     auto flush = [&]() {
-        if (tm.n) TIMED_LAUNCH(ex, "take_many", launch_take_many(ex.cfg(), tm, idx, n));
+        if (tm.n) TIMED_LAUNCH_N(ex, "take_many", n, launch_take_many(ex.cfg(), tm, idx, n));
         tm.n = 0;
     };
     auto add = [&](const void* src, void* dst, int width) {
@@ -271,9 +271,9 @@ int64_t filter_indices(const Exec& ex, const Batch& in, const ExprPtr& predicate
     if (!range_disabled && build_sop(*in.schema, predicate, {}, {}, rp) && rp.prog.n_ranges >= 1 && sop_columns_bindable(rp, in, true) &&
         lean_bindable(rp, in)) {
         bind_sop(rp, in);
-        TIMED_LAUNCH(ex, "range_bitmap", launch_range_bitmap(ex.cfg(), rp.prog, tmp.get<SopProgram>(1), bitmap, tile_counts));
+        TIMED_LAUNCH_N(ex, "range_bitmap", n, launch_range_bitmap(ex.cfg(), rp.prog, tmp.get<SopProgram>(1), bitmap, tile_counts));
     } else {
-        TIMED_LAUNCH(ex, "scan_pred_bitmap", launch_scan_pred_bitmap(ex.cfg(), P, bitmap, tile_counts, st));
+        TIMED_LAUNCH_N(ex, "scan_pred_bitmap", n, launch_scan_pred_bitmap(ex.cfg(), P, bitmap, tile_counts, st));
     }
     uint64_t* tile_off = tmp.get<uint64_t>((size_t)n_tiles + 1);
     uint64_t* total = tmp.get<uint64_t>(1);
@@ -282,7 +282,7 @@ int64_t filter_indices(const Exec& ex, const Batch& in, const ExprPtr& predicate
     check_scan_status(ex, st);
     const uint64_t count = read_device(ex, total);
     indices_out = make_buffer(ex, (size_t)count * 4 + 8);
-    if (count) TIMED_LAUNCH(ex, "select_indices", launch_select_indices(ex.cfg(), bitmap, tile_off, n, indices_out->as<uint32_t>()));
+    if (count) TIMED_LAUNCH_N(ex, "select_indices", n, launch_select_indices(ex.cfg(), bitmap, tile_off, n, indices_out->as<uint32_t>()));
     return (int64_t)count;
 }
 
@@ -474,7 +474,21 @@ StreamPtr ProjectionExec::execute(int partition, const Exec& ex) const {
             }));
         }
     }
-    auto child = std::shared_ptr<RecordBatchStream>(input_->execute(partition, ex).release());
+    std::shared_ptr<RecordBatchStream> child;
+    if (auto hj = dynamic_cast<const HashJoinExec*>(input_.get())) {
+        // Projection over a join: the join gathers only the columns read here (DataFusion's join copies all of both sides)
+        const Schema& js = *hj->schema();
+        std::vector<std::string> used;
+        for (auto& en : exprs) collect_columns(en.first, used);
+        std::vector<bool> needed(js.fields.size(), false);
+        for (auto& u : used) {
+            const int i = js.index_of(u);
+            if (i >= 0) needed[i] = true;
+        }
+        child = std::shared_ptr<RecordBatchStream>(hj->execute_needed(partition, ex, needed).release());
+    } else {
+        child = std::shared_ptr<RecordBatchStream>(input_->execute(partition, ex).release());
+    }
     return StreamPtr(new LazyStream(sch, [child, exprs, ex, sch]() {
         std::vector<BatchPtr> out;
         while (BatchPtr b = child->next()) out.push_back(project_batch(ex, *b, exprs, sch));

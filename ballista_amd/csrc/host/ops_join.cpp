@@ -11,6 +11,7 @@
 #include "../util_kernels.h"
 #include "hash_kernels.h"
 #include "plan.hpp"
+#include "sop.hpp"
 
 namespace bhip {
 
@@ -89,7 +90,7 @@ static void side_keys(const Exec& ex, const Batch& b, const std::vector<std::str
         if (w && !c.validity) {
             keys = make_buffer(ex, (size_t)b.n_rows * 16 + 16);
             has_sel = false;
-            TIMED_LAUNCH(ex, "widen_key", launch_widen_key(ex.cfg(), c.data->ptr(), w, b.n_rows, keys->as<uint64_t>()));
+            TIMED_LAUNCH_N(ex, "widen_key", b.n_rows, launch_widen_key(ex.cfg(), c.data->ptr(), w, b.n_rows, keys->as<uint64_t>()));
             return;
         }
     }
@@ -116,7 +117,7 @@ static void side_keys(const Exec& ex, const Batch& b, const std::vector<std::str
     Temp tmp(ex);
     ScanStatus* st = tmp.get<ScanStatus>(1);
     HIP_CHECK(hipMemsetAsync(st, 0, sizeof(ScanStatus), ex.stream));
-    TIMED_LAUNCH(ex, "scan_keys", launch_scan_keys(ex.cfg(), P, keys->as<uint64_t>(), nullptr, has_sel ? sel->as<uint64_t>() : nullptr, st));
+    TIMED_LAUNCH_N(ex, "scan_keys", b.n_rows, launch_scan_keys(ex.cfg(), P, keys->as<uint64_t>(), nullptr, has_sel ? sel->as<uint64_t>() : nullptr, st));
     check_scan_status(ex, st);
 }
 
@@ -174,7 +175,7 @@ std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) co
         HIP_CHECK(hipMemsetAsync(bs->dup->ptr(), 0, 8, ex.stream));
         bs->ntable = NarrowJoinTable{bs->slots->as<uint64_t>(), cap - 1, bs->dup->as<uint32_t>(), nullptr, 0, 0, 0};
         bs->narrow_width = nkw;
-        TIMED_LAUNCH(ex, "join_build_narrow", launch_join_build_narrow(ex.cfg(), bs->ntable, kc.data->ptr(), nkw,
+        TIMED_LAUNCH_N(ex, "join_build_narrow", n, launch_join_build_narrow(ex.cfg(), bs->ntable, kc.data->ptr(), nkw,
                                            kc.validity ? kc.validity->as<uint64_t>() : nullptr, (uint32_t)n));
         if (read_device(ex, bs->dup->as<uint32_t>()) == 0) {
             bs->narrow = bs->unique = true;
@@ -190,7 +191,7 @@ std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) co
                 if (nkw == 4) {
                     const int32_t seed[2] = {2147483647, -2147483647 - 1};
                     HIP_CHECK(hipMemcpyAsync(mm, seed, 8, hipMemcpyHostToDevice, ex.stream));
-                    TIMED_LAUNCH(ex, "join_key_minmax", launch_join_key_minmax(ex.cfg(), kc.data->as<int32_t>(), ksel, (uint32_t)n, reinterpret_cast<int32_t*>(mm)));
+                    TIMED_LAUNCH_N(ex, "join_key_minmax", n, launch_join_key_minmax(ex.cfg(), kc.data->as<int32_t>(), ksel, (uint32_t)n, reinterpret_cast<int32_t*>(mm)));
                     int32_t got[2];
                     HIP_CHECK(hipMemcpyAsync(got, mm, 8, hipMemcpyDeviceToHost, ex.stream));
                     HIP_CHECK(hipStreamSynchronize(ex.stream));
@@ -199,7 +200,7 @@ std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) co
                 } else {
                     const uint64_t seed[2] = {~0ull, 0};
                     HIP_CHECK(hipMemcpyAsync(mm, seed, 16, hipMemcpyHostToDevice, ex.stream));
-                    TIMED_LAUNCH(ex, "join_key_minmax64", launch_join_key_minmax64(ex.cfg(), kc.data->as<uint64_t>(), ksel, (uint32_t)n, mm));
+                    TIMED_LAUNCH_N(ex, "join_key_minmax64", n, launch_join_key_minmax64(ex.cfg(), kc.data->as<uint64_t>(), ksel, (uint32_t)n, mm));
                     HIP_CHECK(hipMemcpyAsync(host_mm, mm, 16, hipMemcpyDeviceToHost, ex.stream));
                     HIP_CHECK(hipStreamSynchronize(ex.stream));
                 }
@@ -210,10 +211,10 @@ std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) co
                     bs->present = make_buffer(ex, words * 4);
                     HIP_CHECK(hipMemsetAsync(bs->present->ptr(), 0, words * 4, ex.stream));
                     if (nkw == 4)
-                        TIMED_LAUNCH(ex, "join_key_present", launch_join_key_present(ex.cfg(), kc.data->as<uint32_t>(), ksel, (uint32_t)n, (uint32_t)kmin,
+                        TIMED_LAUNCH_N(ex, "join_key_present", n, launch_join_key_present(ex.cfg(), kc.data->as<uint32_t>(), ksel, (uint32_t)n, (uint32_t)kmin,
                                                           bs->present->as<uint32_t>()));
                     else
-                        TIMED_LAUNCH(ex, "join_key_present64", launch_join_key_present64(ex.cfg(), kc.data->as<uint64_t>(), ksel, (uint32_t)n, kmin,
+                        TIMED_LAUNCH_N(ex, "join_key_present64", n, launch_join_key_present64(ex.cfg(), kc.data->as<uint64_t>(), ksel, (uint32_t)n, kmin,
                                                             bs->present->as<uint32_t>()));
                     HIP_CHECK(hipStreamSynchronize(ex.stream));
                     bs->ntable.present = bs->present->as<uint32_t>();
@@ -241,7 +242,7 @@ std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) co
     bs->dup = make_buffer(ex, 8);
     HIP_CHECK(hipMemsetAsync(bs->dup->ptr(), 0, 8, ex.stream));
     bs->table.dup_flag = bs->dup->as<uint32_t>();
-    TIMED_LAUNCH(ex, "join_build", launch_join_build(ex.cfg(), bs->table, bs->has_sel ? bs->sel->as<uint64_t>() : nullptr, (uint32_t)n));
+    TIMED_LAUNCH_N(ex, "join_build", n, launch_join_build(ex.cfg(), bs->table, bs->has_sel ? bs->sel->as<uint64_t>() : nullptr, (uint32_t)n));
     // other tasks (other HIP streams) will read the table: it must be complete before it is published
     bs->unique = read_device(ex, bs->dup->as<uint32_t>()) == 0;
     bs->table.dup_flag = nullptr;
@@ -249,17 +250,96 @@ std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) co
     return bs;
 }
 
+// the integer image of a double range [lo, hi] over Int32 values (empty: lo > hi) — the SOP plan table keeps ranges as doubles
+static void int_bounds(double lo, double hi, int32_t* lo_i, int32_t* hi_i) {
+    *lo_i = 1; *hi_i = 0;
+    if (lo != lo || hi != hi || lo > 2147483647.0 || hi < -2147483648.0) return;
+    const double l = __builtin_ceil(lo), h = __builtin_floor(hi);
+    *lo_i = l <= -2147483648.0 ? (int32_t)(-2147483647 - 1) : (int32_t)l;
+    *hi_i = h >= 2147483647.0 ? (int32_t)2147483647 : (int32_t)h;
+}
+
+namespace {
+
+// where the probe rows come from: right_ = [ProjectionExec(plain columns)] over [CoalesceBatchesExec]* over [FilterExec] over src.
+// The probe then runs on src's UNFILTERED batches and only the rows that join are ever gathered (late materialisation).
+struct ProbeChain {
+    bool ok = false;
+    PlanPtr src;
+    ExprPtr pred;                  // may be null
+    std::vector<int> src_of;       // column i of right_'s schema -> column of src's schema
+};
+
+ProbeChain probe_chain(const PlanPtr& right) {
+    ProbeChain c;
+    const ExecutionPlan* p = right.get();
+    PlanPtr cur = right;
+    const ProjectionExec* proj = dynamic_cast<const ProjectionExec*>(p);
+    if (proj) {
+        for (auto& en : proj->exprs())
+            if (en.first->kind != BHIP_EXPR_COLUMN) return c;          // computed columns: the operator runs as it stands
+        cur = proj->input();
+    }
+    while (auto co = dynamic_cast<const CoalesceBatchesExec*>(cur.get())) cur = co->input();
+    if (auto flt = dynamic_cast<const FilterExec*>(cur.get())) {
+        c.pred = flt->predicate();
+        cur = flt->input();
+    }
+    c.src = cur;
+    const Schema& ss = *c.src->schema();
+    if (proj) {
+        for (auto& en : proj->exprs()) {
+            const int j = ss.index_of(en.first->name);
+            if (j < 0) return c;
+            c.src_of.push_back(j);
+        }
+    } else {
+        for (size_t i = 0; i < right->schema()->fields.size(); ++i) c.src_of.push_back((int)i);
+    }
+    c.ok = true;
+    return c;
+}
+
+// `pred` as an AND of integer ranges over NULL-free Int32 / Date32 columns of `b` (the fused probe's filter form)
+bool int_ranges_of(const ExprPtr& pred, const Batch& b, ProbeFilter& F) {
+    memset(&F, 0, sizeof(F));
+    if (!pred) return true;
+    SopPlan rp;
+    if (!build_sop(*b.schema, pred, {}, {}, rp) || rp.prog.n_ranges < 1 || rp.prog.n_ranges > JOIN_FILTER_MAX) return false;
+    for (int i = 0; i < rp.prog.n_ranges; ++i) {
+        const SopRange& r = rp.prog.ranges[i];
+        if (!r.is32) return false;
+        const Column& c = b.cols[rp.col_map[r.col]];
+        if (c.validity || (c.dtype != DT_INT32 && c.dtype != DT_DATE32)) return false;
+        F.col[i] = c.data->as<int32_t>();
+        int_bounds(r.lo, r.hi, &F.lo[i], &F.hi[i]);
+    }
+    F.n = rp.prog.n_ranges;
+    return true;
+}
+
+}  // namespace
+
 StreamPtr HashJoinExec::execute(int partition, const Exec& ex) const {
+    return execute_needed(partition, ex, std::vector<bool>(schema_->fields.size(), true));
+}
+
+StreamPtr HashJoinExec::execute_needed(int partition, const Exec& ex, const std::vector<bool>& needed_in) const {
     check_partition(*this, partition);
     auto self = std::static_pointer_cast<const HashJoinExec>(shared_from_this());
-    return StreamPtr(new LazyStream(schema_, [self, partition, ex]() {
+    std::vector<bool> needed = needed_in;
+    needed.resize(schema_->fields.size(), true);
+    return StreamPtr(new LazyStream(schema_, [self, partition, ex, needed]() {
         std::vector<BatchPtr> out;
         auto bs = self->build_side(ex);
         const Batch& L = *bs->batch;
         const int64_t n_left = L.n_rows;
+        const size_t n_lcols = L.cols.size();
         const bool right_outer = self->join_type_ == BHIP_JOIN_RIGHT;
         const bool left_outer = self->join_type_ == BHIP_JOIN_LEFT;
         const LaunchCfg cfg = ex.cfg();
+        bool need_left = false;
+        for (size_t i = 0; i < n_lcols; ++i) need_left = need_left || needed[i];
         BufferPtr matched;
         if (left_outer) {
             matched = make_buffer(ex, (size_t)(n_left / 32 + 2) * 4);
@@ -268,29 +348,46 @@ StreamPtr HashJoinExec::execute(int partition, const Exec& ex) const {
         std::vector<std::string> rcols;
         for (auto& p : self->on_) rcols.push_back(p.second);
 
-        auto emit = [&](const Batch* R, const uint32_t* lidx, const uint32_t* ridx, int64_t n_out) {
+        // output batch from index pairs; R: the batch the right columns are gathered from, rmap[i] = its column for right
+        // output column i (nullptr: self->right_cols_).  Columns no parent reads stay placeholders.
+        auto emit = [&](const Batch* R, const std::vector<int>* rmap, const uint32_t* lidx, const uint32_t* ridx, int64_t n_out) {
             auto b = std::make_shared<Batch>();
             b->schema = self->schema_;
             b->ctx = ex.ctx;
             b->n_rows = n_out;
+            b->cols.resize(self->schema_->fields.size());
+            for (size_t i = 0; i < b->cols.size(); ++i) { b->cols[i].dtype = self->schema_->fields[i].dtype; b->cols[i].length = n_out; }
             std::vector<const Column*> lc, rc;
-            for (auto& c : L.cols) lc.push_back(&c);
-            for (auto& c : take_columns(ex, lc, lidx, n_out, right_outer)) b->cols.push_back(std::move(c));
-            if (R) {
-                for (int ci : self->right_cols_) rc.push_back(&R->cols[ci]);
-                for (auto& c : take_columns(ex, rc, ridx, n_out, left_outer)) b->cols.push_back(std::move(c));
-            } else {
-                for (int ci : self->right_cols_) b->cols.push_back(null_column(ex, self->right_->schema()->fields[ci].dtype, n_out));
+            std::vector<size_t> lpos, rpos;
+            for (size_t i = 0; i < n_lcols; ++i)
+                if (needed[i]) { lc.push_back(&L.cols[i]); lpos.push_back(i); }
+            if (!lc.empty()) {
+                if (lidx) {
+                    auto got = take_columns(ex, lc, lidx, n_out, right_outer);
+                    for (size_t k = 0; k < got.size(); ++k) b->cols[lpos[k]] = std::move(got[k]);
+                } else {
+                    for (size_t k = 0; k < lc.size(); ++k) b->cols[lpos[k]] = null_column(ex, lc[k]->dtype, n_out);
+                }
+            }
+            for (size_t k = 0; k < self->right_cols_.size(); ++k) {
+                const size_t oi = n_lcols + k;
+                if (!needed[oi]) continue;
+                if (!R) { b->cols[oi] = null_column(ex, self->schema_->fields[oi].dtype, n_out); continue; }
+                rc.push_back(&R->cols[rmap ? (*rmap)[k] : self->right_cols_[k]]);
+                rpos.push_back(oi);
+            }
+            if (!rc.empty()) {
+                auto got = take_columns(ex, rc, ridx, n_out, left_outer);
+                for (size_t k = 0; k < got.size(); ++k) b->cols[rpos[k]] = std::move(got[k]);
             }
             out.push_back(b);
         };
 
-        // probe: `probe` holds the key columns of the probe rows; output columns are gathered from `outsrc`, whose
-        // row of probe row i is remap[i] (nullptr: the same row)
-        // keysrc (narrow tables only): the UNFILTERED key column, read through `remap` by the probe itself
-        auto process = [&](const Batch& probe, const Batch* outsrc, const uint32_t* remap, const Column* keysrc = nullptr,
-                           int64_t n_probe = -1) {
-            const int64_t n_right = keysrc ? n_probe : probe.n_rows;
+        // ---- probe of a materialised batch (general table, or a probe side that is not a filter chain) ---------------------
+        // `probe` holds the key columns of the probe rows; output columns are gathered from `outsrc`, whose row of probe row i
+        // is remap[i] (nullptr: the same row)
+        auto process = [&](const Batch& probe, const Batch* outsrc, const std::vector<int>* rmap, const uint32_t* remap) {
+            const int64_t n_right = probe.n_rows;
             if (n_right == 0) return;
             BufferPtr rkeys, rsel;
             bool has_rsel = false;
@@ -309,93 +406,117 @@ StreamPtr HashJoinExec::execute(int partition, const Exec& ex) const {
                 uint64_t* tile_off = tmp.get<uint64_t>((size_t)n_tiles + 1);
                 void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes(n_tiles));
                 if (bs->narrow) {
-                    const Column& kc = keysrc ? *keysrc : probe.cols[probe.schema->index_of(rcols[0])];
-                    TIMED_LAUNCH(ex, "join_probe_match_narrow", launch_join_probe_match_narrow(cfg, bs->ntable, kc.data->ptr(), bs->narrow_width,
-                                                             kc.validity ? kc.validity->as<uint64_t>() : nullptr,
-                                                             keysrc ? remap : nullptr, (uint32_t)n_right,
-                                                             right_outer, partner, bitmap, tile_counts,
-                                                             left_outer ? matched->as<uint32_t>() : nullptr));
+                    const Column& kc = probe.cols[probe.schema->index_of(rcols[0])];
+                    TIMED_LAUNCH_N(ex, "join_probe_match_narrow", n_right,
+                                   launch_join_probe_match_narrow(cfg, bs->ntable, kc.data->ptr(), bs->narrow_width,
+                                                                  kc.validity ? kc.validity->as<uint64_t>() : nullptr, nullptr, (uint32_t)n_right,
+                                                                  right_outer, partner, bitmap, tile_counts,
+                                                                  left_outer ? matched->as<uint32_t>() : nullptr));
                 } else
-                    TIMED_LAUNCH(ex, "join_probe_match", launch_join_probe_match(cfg, bs->table, rkeys->as<uint64_t>(), rselp, (uint32_t)n_right, right_outer, partner,
-                                                      bitmap, tile_counts, left_outer ? matched->as<uint32_t>() : nullptr));
+                    TIMED_LAUNCH_N(ex, "join_probe_match", n_right,
+                                   launch_join_probe_match(cfg, bs->table, rkeys->as<uint64_t>(), rselp, (uint32_t)n_right, right_outer, partner,
+                                                           bitmap, tile_counts, left_outer ? matched->as<uint32_t>() : nullptr));
                 HIP_CHECK(exclusive_scan_u32_u64(ex.stream, tile_counts, n_tiles, tile_off, false, total, scan_tmp));
                 n_out = read_device(ex, total);
                 if (n_out == 0) return;
                 lidx = tmp.get<uint32_t>((size_t)n_out);
                 ridx = tmp.get<uint32_t>((size_t)n_out);
-                TIMED_LAUNCH(ex, "select_indices", launch_select_indices(cfg, bitmap, tile_off, n_right, ridx));
-                TIMED_LAUNCH(ex, "take_fixed", launch_take_fixed(cfg, partner, 4, ridx, (int64_t)n_out, lidx));
+                TIMED_LAUNCH_N(ex, "select_indices", n_right, launch_select_indices(cfg, bitmap, tile_off, n_right, ridx));
+                if (need_left) TIMED_LAUNCH_N(ex, "take_fixed", n_out, launch_take_fixed(cfg, partner, 4, ridx, (int64_t)n_out, lidx));
             } else {
                 uint32_t* counts = tmp.get<uint32_t>((size_t)n_right + 1);
                 uint64_t* offsets = tmp.get<uint64_t>((size_t)n_right + 1);
                 void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes(n_right));
-                TIMED_LAUNCH(ex, "join_probe_count", launch_join_probe_count(cfg, bs->table, rkeys->as<uint64_t>(), rselp, (uint32_t)n_right, right_outer, counts));
+                TIMED_LAUNCH_N(ex, "join_probe_count", n_right,
+                               launch_join_probe_count(cfg, bs->table, rkeys->as<uint64_t>(), rselp, (uint32_t)n_right, right_outer, counts));
                 HIP_CHECK(exclusive_scan_u32_u64(ex.stream, counts, n_right, offsets, false, total, scan_tmp));
                 n_out = read_device(ex, total);
                 if (n_out > 0xFFFFFFF0ull) fail(BHIP_EEXEC, "join output of one probe batch exceeds 2^32 rows");
                 if (n_out == 0) return;
                 lidx = tmp.get<uint32_t>((size_t)n_out);
                 ridx = tmp.get<uint32_t>((size_t)n_out);
-                TIMED_LAUNCH(ex, "join_probe_emit", launch_join_probe_emit(cfg, bs->table, rkeys->as<uint64_t>(), rselp, (uint32_t)n_right, right_outer, offsets,
-                                                 lidx, ridx, left_outer ? matched->as<uint32_t>() : nullptr));
+                TIMED_LAUNCH_N(ex, "join_probe_emit", n_right,
+                               launch_join_probe_emit(cfg, bs->table, rkeys->as<uint64_t>(), rselp, (uint32_t)n_right, right_outer, offsets,
+                                                      lidx, ridx, left_outer ? matched->as<uint32_t>() : nullptr));
             }
             if (remap) {
                 uint32_t* orig = tmp.get<uint32_t>((size_t)n_out);
-                TIMED_LAUNCH(ex, "take_fixed", launch_take_fixed(cfg, remap, 4, ridx, (int64_t)n_out, orig));
+                TIMED_LAUNCH_N(ex, "take_fixed", n_out, launch_take_fixed(cfg, remap, 4, ridx, (int64_t)n_out, orig));
                 ridx = orig;
             }
-            emit(outsrc, lidx, ridx, (int64_t)n_out);
+            emit(outsrc, rmap, lidx, ridx, (int64_t)n_out);
             HIP_CHECK(hipStreamSynchronize(ex.stream));   // index scratch is released at the end of the iteration
         };
 
-        // Late materialisation of the probe side: when it is a column projection over a filter (Q3: lineitem, orders),
-        // only the join-key columns of the surviving rows are gathered before the probe; the other output columns are
-        // gathered once, for the MATCHING rows only, straight from the unfiltered batch (index composition).
-        const ProjectionExec* proj = dynamic_cast<const ProjectionExec*>(self->right_.get());
-        const ExecutionPlan* below = proj ? proj->children()[0].get() : nullptr;
-        while (below && dynamic_cast<const CoalesceBatchesExec*>(below)) below = below->children()[0].get();
-        const FilterExec* flt = below ? dynamic_cast<const FilterExec*>(below) : nullptr;
-        bool late = flt != nullptr;
-        if (late)
-            for (auto& en : proj->exprs()) late = late && en.first->kind == BHIP_EXPR_COLUMN;
-        if (late) {
-            PlanPtr src = flt->children()[0];
-            const SchemaPtr src_schema = src->schema();
+        // ---- one pass over the unfiltered batch: ranges -> key-set bitmap -> narrow table (kernels_join.hip) ----------------
+        auto process_fused = [&](const Batch& b, const ProbeFilter& F, const Column& kc, const std::vector<int>& rmap) {
+            const int64_t n = b.n_rows;
+            const int64_t n_tiles = (n + SEL_TILE - 1) / SEL_TILE;
+            Temp tmp(ex);
+            uint64_t* bitmap = tmp.get<uint64_t>((size_t)(n + 63) / 64 + 1);
+            uint32_t* tile_counts = tmp.get<uint32_t>((size_t)n_tiles + 1);
+            uint64_t* tile_off = tmp.get<uint64_t>((size_t)n_tiles + 1);
+            uint64_t* total = tmp.get<uint64_t>(1);
+            void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes(n_tiles));
+            uint32_t* staging = need_left ? tmp.get<uint32_t>((size_t)n_tiles * SEL_TILE) : nullptr;
+            TIMED_LAUNCH_N(ex, "join_filter_probe", n,
+                           launch_join_filter_probe(cfg, bs->ntable, F, kc.data->ptr(), bs->narrow_width,
+                                                    kc.validity ? kc.validity->as<uint64_t>() : nullptr, (uint32_t)n, right_outer, bitmap,
+                                                    tile_counts, staging, left_outer ? matched->as<uint32_t>() : nullptr));
+            HIP_CHECK(exclusive_scan_u32_u64(ex.stream, tile_counts, n_tiles, tile_off, false, total, scan_tmp));
+            const uint64_t n_out = read_device(ex, total);
+            if (n_out == 0) return;
+            uint32_t* ridx = tmp.get<uint32_t>((size_t)n_out);
+            uint32_t* lidx = need_left ? tmp.get<uint32_t>((size_t)n_out) : nullptr;
+            TIMED_LAUNCH_N(ex, "select_indices", n, launch_select_indices(cfg, bitmap, tile_off, n, ridx));
+            if (need_left) TIMED_LAUNCH_N(ex, "join_compact_staged", n, launch_join_compact_staged(cfg, staging, tile_off, n_out, n_tiles, lidx));
+            emit(&b, &rmap, lidx, ridx, (int64_t)n_out);
+            HIP_CHECK(hipStreamSynchronize(ex.stream));
+        };
+
+        const ProbeChain chain = probe_chain(self->right_);
+        static const bool fused_disabled = [] { const char* v = getenv("BHIP_NO_FUSED_PROBE"); return v && atoi(v) != 0; }();
+        if (chain.ok) {
             const SchemaPtr out_schema = self->right_->schema();
-            std::vector<int> src_of;                       // projection output i -> source column
-            for (auto& en : proj->exprs()) src_of.push_back(src_schema->index_of(en.first->name));
-            auto key_schema = std::make_shared<Schema>();
+            std::vector<int> rmap;                             // right OUTPUT column k -> source column
+            for (int ci : self->right_cols_) rmap.push_back(chain.src_of[ci]);
             std::vector<int> key_src;
+            auto key_schema = std::make_shared<Schema>();
             for (auto& rc : rcols) {
                 const int j = out_schema->index_of(rc);
                 key_schema->fields.push_back(out_schema->fields[j]);
-                key_src.push_back(src_of[j]);
+                key_src.push_back(chain.src_of[j]);
             }
-            auto ss = src->execute(partition, ex);
+            auto ss = chain.src->execute(partition, ex);
             while (BatchPtr b = ss->next()) {
                 if (b->n_rows == 0) continue;
-                BufferPtr sel;
-                const int64_t n_sel = filter_indices(ex, *b, flt->predicate(), sel);
-                if (n_sel == 0) continue;
-                Batch pv;                                  // the projection's view of the unfiltered batch
-                pv.schema = out_schema;
-                pv.ctx = b->ctx;
-                pv.n_rows = b->n_rows;
-                for (int ci : src_of) pv.cols.push_back(b->cols[ci]);
-                if (bs->narrow) {                          // the probe reads the key column through the selection
-                    process(pv, &pv, sel->as<uint32_t>(), &b->cols[key_src[0]], n_sel);
+                ProbeFilter F;
+                if (bs->narrow && !fused_disabled && b->n_rows <= 0xFFFFF000ll && int_ranges_of(chain.pred, *b, F)) {
+                    process_fused(*b, F, b->cols[key_src[0]], rmap);
                     continue;
                 }
-                auto kb = std::make_shared<Batch>();
+                if (!chain.pred) {
+                    Batch kv;                                  // the key columns under their probe-side names
+                    kv.schema = key_schema;
+                    kv.ctx = b->ctx;
+                    kv.n_rows = b->n_rows;
+                    for (int ci : key_src) kv.cols.push_back(b->cols[ci]);
+                    process(kv, b.get(), &rmap, nullptr);
+                    continue;
+                }
+                BufferPtr sel;
+                const int64_t n_sel = filter_indices(ex, *b, chain.pred, sel);
+                if (n_sel == 0) continue;
+                auto kb = std::make_shared<Batch>();           // key columns of the surviving rows only
                 kb->schema = key_schema;
                 kb->ctx = b->ctx;
                 kb->n_rows = n_sel;
                 for (int ci : key_src) kb->cols.push_back(take_batch_column(ex, b->cols[ci], sel->as<uint32_t>(), n_sel));
-                process(*kb, &pv, sel->as<uint32_t>());
+                process(*kb, b.get(), &rmap, sel->as<uint32_t>());
             }
         } else {
             auto rs = self->right_->execute(partition, ex);
-            while (BatchPtr rb = rs->next()) process(*rb, rb.get(), nullptr);
+            while (BatchPtr rb = rs->next()) process(*rb, rb.get(), nullptr, nullptr);
         }
         if (left_outer && n_left > 0) {
             // left rows no probe row matched: right columns NULL
@@ -410,7 +531,7 @@ StreamPtr HashJoinExec::execute(int partition, const Exec& ex) const {
             if (n_un) {
                 uint32_t* lidx = tmp.get<uint32_t>((size_t)n_un);
                 TIMED_LAUNCH(ex, "compact_flags", launch_compact_flags(cfg, flags, offsets, (uint32_t)n_left, lidx));
-                emit(nullptr, lidx, nullptr, (int64_t)n_un);
+                emit(nullptr, nullptr, lidx, nullptr, (int64_t)n_un);
                 HIP_CHECK(hipStreamSynchronize(ex.stream));
             }
         }

@@ -218,6 +218,10 @@ public:
     std::vector<PlanPtr> children() const override { return {left_, right_}; }
     PlanPtr with_new_children(const std::vector<PlanPtr>& c) const override;
     StreamPtr execute(int partition, const Exec& ex) const override;
+    // the same stream with only the output columns a parent reads materialised (needed[i]: column i of schema()); the other
+    // columns of the batches are placeholders without buffers.  Called by ProjectionExec / HashAggregateExec above a join
+    // (the reference's join copies every column of both sides and the parent then drops most of them).
+    StreamPtr execute_needed(int partition, const Exec& ex, const std::vector<bool>& needed) const;
     std::string describe() const override;
 private:
     std::shared_ptr<const JoinBuildSide> build_side(const Exec& ex) const;

@@ -632,19 +632,24 @@ class MemoryExec(ExecutionPlan):
 
 
 class ArrowStreamExec(ExecutionPlan):
-    """bhip_plan_arrow_stream: leaf over a host-side Arrow C stream (e.g. a pyarrow.RecordBatchReader) — the C image
-    of a CPU child operator's RecordBatchStream (rust/core/src/memory_stream.rs:57-92).  The stream is moved into the
-    plan, drained on the first execute and replayed afterwards; one output partition."""
+    """bhip_plan_arrow_stream(s): leaf over host-side Arrow C streams (e.g. pyarrow.RecordBatchReader) — the C image of a CPU
+    child operator's RecordBatchStream (rust/core/src/memory_stream.rs:57-92), one stream per output partition.  The streams
+    are moved into the plan, a partition is drained on its first execute and replayed afterwards."""
 
-    def __init__(self, reader, ctx: Context):
-        c_stream = _ArrowArrayStream()
-        reader._export_to_c(C.addressof(c_stream))
+    def __init__(self, readers, ctx: Context):
+        if not isinstance(readers, (list, tuple)):
+            readers = [readers]
+        c_streams = [_ArrowArrayStream() for _ in readers]
+        for r, cs in zip(readers, c_streams):
+            r._export_to_c(C.addressof(cs))
+        arr = (C.c_void_p * len(c_streams))(*[C.addressof(cs) for cs in c_streams])
         h = C.c_void_p()
         try:
-            L.check(L.lib().bhip_plan_arrow_stream(ctx._h, C.addressof(c_stream), C.byref(h)))
+            L.check(L.lib().bhip_plan_arrow_streams(ctx._h, len(c_streams), arr, C.byref(h)))
         finally:
-            if c_stream.release:                       # not taken over (an error): release our export
-                C.CFUNCTYPE(None, C.c_void_p)(c_stream.release)(C.addressof(c_stream))
+            for cs in c_streams:
+                if cs.release:                         # not taken over (an error): release our export
+                    C.CFUNCTYPE(None, C.c_void_p)(cs.release)(C.addressof(cs))
         super().__init__(h, ctx)
 
 

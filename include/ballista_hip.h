@@ -236,6 +236,9 @@ bhip_status bhip_plan_memory(bhip_ctx* ctx, int32_t n_partitions, const int32_t*
  * (rust/core/src/memory_stream.rs:57-92): the stream is MOVED into the plan, drained on the first execute (each batch
  * imported to the device) and replayed on later executes.  One output partition. */
 bhip_status bhip_plan_arrow_stream(bhip_ctx* ctx, struct ArrowArrayStream* stream, bhip_plan** out);
+/* the same with one stream per output partition of the CPU child (all moved into the plan): partition p of the leaf is
+ * streams[p]; a join above drains every partition of its build side, as the reference's collect-left join does */
+bhip_status bhip_plan_arrow_streams(bhip_ctx* ctx, int32_t n_partitions, struct ArrowArrayStream* const* streams, bhip_plan** out);
 bhip_status bhip_plan_empty(bhip_ctx* ctx, int32_t n_cols, const bhip_column_desc* schema, int32_t produce_one_row,
                             bhip_plan** out);
 bhip_status bhip_plan_filter(bhip_plan* input, const bhip_expr* predicate, bhip_plan** out);          /* :81-92  */
