@@ -139,6 +139,13 @@ SYMBOLS = {
     "bhip_stream_drain": (C.c_int32, [_P, _P, _P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "bhip_batch_hash_partition": (C.c_int32, [_P, C.c_int32, C.POINTER(Expr), C.c_int32, _PP]),
     "bhip_batch_concat": (C.c_int32, [_P, C.c_int32, _PP, _PP]),
+    "bhip_comm_unique_id": (C.c_int32, [C.c_char_p]),
+    "bhip_comm_create": (C.c_int32, [_P, C.c_char_p, C.c_int32, C.c_int32, _PP]),
+    "bhip_comm_release": (None, [_P]),
+    "bhip_comm_all_gather": (C.c_int32, [_P, _P, _PP]),
+    "bhip_comm_all_to_all": (C.c_int32, [_P, _PP, _PP]),
+    "bhip_batch_pack": (C.c_int32, [_P, C.POINTER(C.c_int64), C.c_int32, _P, C.c_int64, C.POINTER(C.c_int64)]),
+    "bhip_batch_unpack": (C.c_int32, [_P, C.c_int32, C.POINTER(ColumnDesc), C.POINTER(C.c_int64), _P, _PP]),
     "bhip_tpch_lineitem": (C.c_int32, [_P, C.c_double, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32, _PP]),
     "bhip_tpch_orders": (C.c_int32, [_P, C.c_double, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32, _PP]),
 }

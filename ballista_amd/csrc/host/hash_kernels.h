@@ -55,31 +55,38 @@ hipError_t launch_join_probe_match(const LaunchCfg& cfg, const JoinTable& T, con
                                    uint32_t* matched);
 // one Int32 / Date32 key column, unique build side: key and build row share the slot (kernels_hash.hip)
 struct NarrowJoinTable {
-    uint64_t* slots;          // key width 4: [capacity] key | (build row + 1) << 32, 0 = empty
-                              // key width 8: [capacity] {key, build row + 1 (low half of the second word)}, 16 bytes per slot
+    // CAS table (sparse keys): key width 4: [capacity] key | (build row + 1) << 32, 0 = empty;
+    // key width 8: [capacity] {key, build row + 1 (low half of the second word)}, 16 bytes per slot.  Null in rank mode.
+    uint64_t* slots;
     uint64_t mask;
     uint32_t* dup_flag;       // set when two build rows share a key: the host falls back to JoinTable
-    // optional: the exact set of build keys, one bit per value of [kmin, kmin + krange] (null: absent);
-    // kmin for key width 4, kmin64 for key width 8
+    // optional with the CAS table: the exact set of build keys, one bit per value of [kmin64, kmin64 + krange] (null: absent)
     const uint32_t* present;
     uint32_t kmin, krange;
-    uint64_t kmin64;
+    uint64_t kmin64;          // first key of the window as raw key bits (32-bit keys: zero- or sign-extension does not matter, the
+                              // offset is taken modulo 2^32)
+    // rank map (kernels_join.hip; keys inside a window of <= 2^30 values): rbits = key set, 64 keys per word;
+    // rprefix[w] = set bits before word w; rank -> build row through rperm (null: the build side is sorted by key, rank = row)
+    const uint64_t* rbits;
+    const uint32_t* rprefix;
+    const uint32_t* rperm;
 };
-// the same for 64-bit keys: mm[] holds min / max of key ^ 2^63 (seeded with ~0 / 0)
-hipError_t launch_join_key_minmax64(const LaunchCfg& cfg, const uint64_t* keys, const uint64_t* sel, uint32_t n, uint64_t* mm);
+// one pass over the build keys (kernels_join.hip): stats[0] / [1] = min / max of (key ^ sign bit) as unsigned (seed ~0 / 0),
+// stats[2] != 0 when the keys are not strictly increasing (or some are NULL)
+hipError_t launch_join_key_stats(const LaunchCfg& cfg, const void* keys, int key_width, const uint64_t* sel, uint32_t n, uint64_t* stats);
+// rank map build: key-set bits (zeroed by the caller), popcounts per word (scanned by the caller into rprefix), perm
+hipError_t launch_rank_bits(const LaunchCfg& cfg, const void* keys, int key_width, const uint64_t* sel, uint32_t n, uint64_t kmin, bool sorted,
+                            uint64_t* bits, uint32_t* dup_flag);
+hipError_t launch_rank_popcount(const LaunchCfg& cfg, const uint64_t* bits, int64_t n_words, uint32_t* counts);
+hipError_t launch_rank_perm(const LaunchCfg& cfg, const void* keys, int key_width, const uint64_t* sel, uint32_t n, uint64_t kmin,
+                            const uint64_t* bits, const uint32_t* prefix, uint32_t* perm);
+// the key-set bitmap in front of the CAS table (round-1 design; kept as the A/B partner of the rank map, BHIP_JOIN_TABLE=1)
 hipError_t launch_join_key_present64(const LaunchCfg& cfg, const uint64_t* keys, const uint64_t* sel, uint32_t n, uint64_t kmin,
                                      uint32_t* present);
-// signed min / max of the build keys (mm[0], mm[1] seeded with INT32_MAX / INT32_MIN), then the presence bits
-hipError_t launch_join_key_minmax(const LaunchCfg& cfg, const int32_t* keys, const uint64_t* sel, uint32_t n, int32_t* mm);
 hipError_t launch_join_key_present(const LaunchCfg& cfg, const uint32_t* keys, const uint64_t* sel, uint32_t n, uint32_t kmin,
                                    uint32_t* present);
 hipError_t launch_join_build_narrow(const LaunchCfg& cfg, const NarrowJoinTable& T, const void* keys, int key_width,
                                     const uint64_t* sel, uint32_t n_left);
-// gather (may be null): probe row i reads key / validity row gather[i] — the probe runs over a selection of the key
-// column without materialising it
-hipError_t launch_join_probe_match_narrow(const LaunchCfg& cfg, const NarrowJoinTable& T, const void* rkeys, int key_width,
-                                          const uint64_t* rsel, const uint32_t* gather, uint32_t n_right, bool right_outer,
-                                          uint32_t* partner, uint64_t* bitmap, uint32_t* tile_counts, uint32_t* matched);
 // the probe side as one pass over the UNFILTERED batch (kernels_join.hip): AND of integer ranges over NULL-free
 // Int32 / Date32 columns (n = 0: no filter) -> key-set bitmap -> table.  One wave owns a whole 1024-row tile: tile_counts[] are
 // plain stores (no memset needed), staging[tile * 1024 + j] = build row of the tile's j-th emitted row (staging may be null:

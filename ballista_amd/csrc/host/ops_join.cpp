@@ -23,7 +23,7 @@ struct JoinBuildSide {
     bool unique = false;            // no two build rows share a key: probe rows have at most one partner
     bool narrow = false;            // ONE integer key, unique: NarrowJoinTable instead of JoinTable
     int narrow_width = 0;           // its key bytes (4: Int32 / Date32, 8: Int64 / UInt64)
-    BufferPtr slots, present;
+    BufferPtr slots, present, rbits, rprefix, rperm;
     NarrowJoinTable ntable;
 };
 
@@ -164,69 +164,103 @@ std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) co
     uint64_t cap = 1024;
     while (cap < 2ull * (uint64_t)n) cap <<= 1;
     static const bool narrow_disabled = [] { const char* v = getenv("BHIP_NO_NARROW_JOIN"); return v && atoi(v) != 0; }();
+    // BHIP_JOIN_TABLE=1: always the CAS table (+ key-set bitmap), the round-1 design — the A/B partner of the rank map
+    static const bool force_table = [] { const char* v = getenv("BHIP_JOIN_TABLE"); return v && atoi(v) != 0; }();
     const int nkw = narrow_disabled ? 0 : narrow_key_width();
-    if (nkw) {
+    if (nkw && n > 0) {
         // optimistic: the build side of a key join is almost always unique
         const Column& kc = bs->batch->cols[bs->batch->schema->index_of(lcols[0])];
-        const size_t slot_bytes = nkw == 4 ? 8 : 16;
-        bs->slots = make_buffer(ex, cap * slot_bytes);
-        bs->dup = make_buffer(ex, 8);
-        HIP_CHECK(hipMemsetAsync(bs->slots->ptr(), 0, cap * slot_bytes, ex.stream));
-        HIP_CHECK(hipMemsetAsync(bs->dup->ptr(), 0, 8, ex.stream));
-        bs->ntable = NarrowJoinTable{bs->slots->as<uint64_t>(), cap - 1, bs->dup->as<uint32_t>(), nullptr, 0, 0, 0};
+        const uint64_t* ksel = kc.validity ? kc.validity->as<uint64_t>() : nullptr;
+        memset(&bs->ntable, 0, sizeof(bs->ntable));
         bs->narrow_width = nkw;
-        TIMED_LAUNCH_N(ex, "join_build_narrow", n, launch_join_build_narrow(ex.cfg(), bs->ntable, kc.data->ptr(), nkw,
-                                           kc.validity ? kc.validity->as<uint64_t>() : nullptr, (uint32_t)n));
-        if (read_device(ex, bs->dup->as<uint32_t>()) == 0) {
-            bs->narrow = bs->unique = true;
-            bs->ntable.dup_flag = nullptr;
-            // a table that outgrows the caches gets the exact key set as a bitmap in front of it (keys whose value window
-            // is at most 2^30 wide = 128 MB of bits): probes without a partner stop there
-            static const bool present_disabled = [] { const char* v = getenv("BHIP_NO_JOIN_BITMAP"); return v && atoi(v) != 0; }();
-            if (!present_disabled && n >= (1 << 18)) {
-                const uint64_t* ksel = kc.validity ? kc.validity->as<uint64_t>() : nullptr;
-                Temp tmp(ex);
-                uint64_t* mm = tmp.get<uint64_t>(2);
-                uint64_t host_mm[2];                                 // min / max of the keys with the sign bit flipped
-                if (nkw == 4) {
-                    const int32_t seed[2] = {2147483647, -2147483647 - 1};
-                    HIP_CHECK(hipMemcpyAsync(mm, seed, 8, hipMemcpyHostToDevice, ex.stream));
-                    TIMED_LAUNCH_N(ex, "join_key_minmax", n, launch_join_key_minmax(ex.cfg(), kc.data->as<int32_t>(), ksel, (uint32_t)n, reinterpret_cast<int32_t*>(mm)));
-                    int32_t got[2];
-                    HIP_CHECK(hipMemcpyAsync(got, mm, 8, hipMemcpyDeviceToHost, ex.stream));
-                    HIP_CHECK(hipStreamSynchronize(ex.stream));
-                    host_mm[0] = (uint64_t)(int64_t)got[0] ^ (1ull << 63);
-                    host_mm[1] = (uint64_t)(int64_t)got[1] ^ (1ull << 63);
-                } else {
-                    const uint64_t seed[2] = {~0ull, 0};
-                    HIP_CHECK(hipMemcpyAsync(mm, seed, 16, hipMemcpyHostToDevice, ex.stream));
-                    TIMED_LAUNCH_N(ex, "join_key_minmax64", n, launch_join_key_minmax64(ex.cfg(), kc.data->as<uint64_t>(), ksel, (uint32_t)n, mm));
-                    HIP_CHECK(hipMemcpyAsync(host_mm, mm, 16, hipMemcpyDeviceToHost, ex.stream));
-                    HIP_CHECK(hipStreamSynchronize(ex.stream));
-                }
-                if (host_mm[0] <= host_mm[1] && host_mm[1] - host_mm[0] <= (1ull << 30)) {
-                    const uint64_t range = host_mm[1] - host_mm[0];
-                    const uint64_t kmin = host_mm[0] ^ (1ull << 63);
-                    const size_t words = (size_t)range / 32 + 2;
-                    bs->present = make_buffer(ex, words * 4);
-                    HIP_CHECK(hipMemsetAsync(bs->present->ptr(), 0, words * 4, ex.stream));
-                    if (nkw == 4)
-                        TIMED_LAUNCH_N(ex, "join_key_present", n, launch_join_key_present(ex.cfg(), kc.data->as<uint32_t>(), ksel, (uint32_t)n, (uint32_t)kmin,
-                                                          bs->present->as<uint32_t>()));
-                    else
-                        TIMED_LAUNCH_N(ex, "join_key_present64", n, launch_join_key_present64(ex.cfg(), kc.data->as<uint64_t>(), ksel, (uint32_t)n, kmin,
-                                                            bs->present->as<uint32_t>()));
-                    HIP_CHECK(hipStreamSynchronize(ex.stream));
-                    bs->ntable.present = bs->present->as<uint32_t>();
-                    bs->ntable.kmin = (uint32_t)kmin;
-                    bs->ntable.kmin64 = kmin;
-                    bs->ntable.krange = (uint32_t)range;
+        bs->dup = make_buffer(ex, 8);
+        HIP_CHECK(hipMemsetAsync(bs->dup->ptr(), 0, 8, ex.stream));
+        // one pass: min / max / "strictly increasing"
+        Temp tmp(ex);
+        uint64_t* stats = tmp.get<uint64_t>(3);
+        const uint64_t seed[3] = {~0ull, 0ull, 0ull};
+        uint64_t host_stats[3];
+        HIP_CHECK(hipMemcpyAsync(stats, seed, sizeof(seed), hipMemcpyHostToDevice, ex.stream));
+        TIMED_LAUNCH_N(ex, "join_key_stats", n, launch_join_key_stats(ex.cfg(), kc.data->ptr(), nkw, ksel, (uint32_t)n, stats));
+        HIP_CHECK(hipMemcpyAsync(host_stats, stats, sizeof(host_stats), hipMemcpyDeviceToHost, ex.stream));
+        HIP_CHECK(hipStreamSynchronize(ex.stream));
+        const uint64_t bias = nkw == 4 ? 0x80000000ull : (1ull << 63);
+        const bool any_key = host_stats[0] <= host_stats[1];
+        const uint64_t range = any_key ? host_stats[1] - host_stats[0] : 0;
+        const uint64_t kmin = (host_stats[0] ^ bias);                        // raw key bits of the smallest key
+        const bool sorted = host_stats[2] == 0;
+        bs->ntable.kmin64 = kmin;
+        bs->ntable.kmin = (uint32_t)kmin;
+        // a window of at most 2^30 values that is not absurdly sparse (<= 1 KiB of map per build row)
+        const bool window_ok = any_key && range <= (1ull << 30) && range / 4096 <= (uint64_t)n + 256;
+        if (window_ok && !force_table) {
+            // ---- rank map ----------------------------------------------------------------------------------------------
+            const int64_t n_words = (int64_t)(range >> 6) + 1;
+            bs->rbits = make_buffer(ex, (size_t)n_words * 8 + 8);
+            bs->rprefix = make_buffer(ex, (size_t)n_words * 4 + 8);
+            HIP_CHECK(hipMemsetAsync(bs->rbits->ptr(), 0, (size_t)n_words * 8, ex.stream));
+            TIMED_LAUNCH_N(ex, sorted ? "rank_bits_sorted" : "rank_bits_any", n,
+                           launch_rank_bits(ex.cfg(), kc.data->ptr(), nkw, ksel, (uint32_t)n, kmin, sorted, bs->rbits->as<uint64_t>(), bs->dup->as<uint32_t>()));
+            uint32_t* counts = tmp.get<uint32_t>((size_t)n_words + 1);
+            void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes(n_words));
+            uint64_t* total = tmp.get<uint64_t>(1);
+            TIMED_LAUNCH_N(ex, "rank_popcount", n_words, launch_rank_popcount(ex.cfg(), bs->rbits->as<uint64_t>(), n_words, counts));
+            HIP_CHECK(exclusive_scan_u32_i32(ex.stream, counts, n_words, bs->rprefix->as<int32_t>(), false, total, scan_tmp));
+            bool dup = false;
+            if (!sorted) {
+                dup = read_device(ex, bs->dup->as<uint32_t>()) != 0;           // duplicates would collide in perm[]
+                if (!dup) {
+                    bs->rperm = make_buffer(ex, (size_t)n * 4 + 8);
+                    TIMED_LAUNCH_N(ex, "rank_perm", n, launch_rank_perm(ex.cfg(), kc.data->ptr(), nkw, ksel, (uint32_t)n, kmin, bs->rbits->as<uint64_t>(),
+                                                                       bs->rprefix->as<uint32_t>(), bs->rperm->as<uint32_t>()));
                 }
             }
-            cache_->built = bs;
-            return bs;
+            if (!dup) {
+                HIP_CHECK(hipStreamSynchronize(ex.stream));                 // other tasks (other streams) read the map: complete before it is published
+                bs->ntable.rbits = bs->rbits->as<uint64_t>();
+                bs->ntable.rprefix = bs->rprefix->as<uint32_t>();
+                bs->ntable.rperm = bs->rperm ? bs->rperm->as<uint32_t>() : nullptr;
+                bs->ntable.krange = (uint32_t)range;
+                bs->narrow = bs->unique = true;
+                cache_->built = bs;
+                return bs;
+            }
+            bs->rbits.reset();
+            bs->rprefix.reset();
+        } else {
+            // ---- CAS table (sparse keys), with the key set as a bitmap in front of it when the window allows -------------
+            const size_t slot_bytes = nkw == 4 ? 8 : 16;
+            bs->slots = make_buffer(ex, cap * slot_bytes);
+            HIP_CHECK(hipMemsetAsync(bs->slots->ptr(), 0, cap * slot_bytes, ex.stream));
+            bs->ntable.slots = bs->slots->as<uint64_t>();
+            bs->ntable.mask = cap - 1;
+            bs->ntable.dup_flag = bs->dup->as<uint32_t>();
+            TIMED_LAUNCH_N(ex, "join_build_narrow", n, launch_join_build_narrow(ex.cfg(), bs->ntable, kc.data->ptr(), nkw, ksel, (uint32_t)n));
+            if (any_key && range <= (1ull << 30) && n >= (1 << 18)) {
+                const size_t words = (size_t)range / 32 + 2;
+                bs->present = make_buffer(ex, words * 4);
+                HIP_CHECK(hipMemsetAsync(bs->present->ptr(), 0, words * 4, ex.stream));
+                if (nkw == 4)
+                    TIMED_LAUNCH_N(ex, "join_key_present", n, launch_join_key_present(ex.cfg(), kc.data->as<uint32_t>(), ksel, (uint32_t)n, (uint32_t)kmin,
+                                                                                     bs->present->as<uint32_t>()));
+                else
+                    TIMED_LAUNCH_N(ex, "join_key_present64", n, launch_join_key_present64(ex.cfg(), kc.data->as<uint64_t>(), ksel, (uint32_t)n, kmin,
+                                                                                         bs->present->as<uint32_t>()));
+            }
+            if (read_device(ex, bs->dup->as<uint32_t>()) == 0) {
+                bs->ntable.dup_flag = nullptr;
+                if (bs->present) {
+                    bs->ntable.present = bs->present->as<uint32_t>();
+                    bs->ntable.krange = (uint32_t)range;
+                }
+                bs->narrow = bs->unique = true;
+                cache_->built = bs;
+                return bs;
+            }
+            bs->slots.reset();
+            bs->present.reset();
         }
-        bs->slots.reset();
+        memset(&bs->ntable, 0, sizeof(bs->ntable));
     }
     side_keys(ex, *bs->batch, lcols, bs->keys, bs->sel, bs->has_sel);
     bs->owner = make_buffer(ex, cap * 8);
@@ -391,7 +425,7 @@ StreamPtr HashJoinExec::execute_needed(int partition, const Exec& ex, const std:
             if (n_right == 0) return;
             BufferPtr rkeys, rsel;
             bool has_rsel = false;
-            if (!bs->narrow) side_keys(ex, probe, rcols, rkeys, rsel, has_rsel);
+            side_keys(ex, probe, rcols, rkeys, rsel, has_rsel);
             Temp tmp(ex);
             const uint64_t* rselp = has_rsel ? rsel->as<uint64_t>() : nullptr;
             uint64_t* total = tmp.get<uint64_t>(1);
@@ -405,17 +439,9 @@ StreamPtr HashJoinExec::execute_needed(int partition, const Exec& ex, const std:
                 uint32_t* tile_counts = tmp.get<uint32_t>((size_t)n_tiles + 1);
                 uint64_t* tile_off = tmp.get<uint64_t>((size_t)n_tiles + 1);
                 void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes(n_tiles));
-                if (bs->narrow) {
-                    const Column& kc = probe.cols[probe.schema->index_of(rcols[0])];
-                    TIMED_LAUNCH_N(ex, "join_probe_match_narrow", n_right,
-                                   launch_join_probe_match_narrow(cfg, bs->ntable, kc.data->ptr(), bs->narrow_width,
-                                                                  kc.validity ? kc.validity->as<uint64_t>() : nullptr, nullptr, (uint32_t)n_right,
-                                                                  right_outer, partner, bitmap, tile_counts,
-                                                                  left_outer ? matched->as<uint32_t>() : nullptr));
-                } else
-                    TIMED_LAUNCH_N(ex, "join_probe_match", n_right,
-                                   launch_join_probe_match(cfg, bs->table, rkeys->as<uint64_t>(), rselp, (uint32_t)n_right, right_outer, partner,
-                                                           bitmap, tile_counts, left_outer ? matched->as<uint32_t>() : nullptr));
+                TIMED_LAUNCH_N(ex, "join_probe_match", n_right,
+                               launch_join_probe_match(cfg, bs->table, rkeys->as<uint64_t>(), rselp, (uint32_t)n_right, right_outer, partner,
+                                                       bitmap, tile_counts, left_outer ? matched->as<uint32_t>() : nullptr));
                 HIP_CHECK(exclusive_scan_u32_u64(ex.stream, tile_counts, n_tiles, tile_off, false, total, scan_tmp));
                 n_out = read_device(ex, total);
                 if (n_out == 0) return;
@@ -448,9 +474,11 @@ StreamPtr HashJoinExec::execute_needed(int partition, const Exec& ex, const std:
             HIP_CHECK(hipStreamSynchronize(ex.stream));   // index scratch is released at the end of the iteration
         };
 
-        // ---- one pass over the unfiltered batch: ranges -> key-set bitmap -> narrow table (kernels_join.hip) ----------------
-        auto process_fused = [&](const Batch& b, const ProbeFilter& F, const Column& kc, const std::vector<int>& rmap) {
-            const int64_t n = b.n_rows;
+        // ---- narrow build side: one pass over the probe rows: ranges -> key-set bit -> rank map / table (kernels_join.hip) -----
+        // n probe rows whose keys are `kc`; output columns come from `outsrc` (row remap[i] of it for probe row i; nullptr: row i)
+        auto process_fused = [&](int64_t n, const ProbeFilter& F, const Column& kc, const Batch* outsrc, const std::vector<int>* rmap,
+                                 const uint32_t* remap) {
+            if (n == 0) return;
             const int64_t n_tiles = (n + SEL_TILE - 1) / SEL_TILE;
             Temp tmp(ex);
             uint64_t* bitmap = tmp.get<uint64_t>((size_t)(n + 63) / 64 + 1);
@@ -470,9 +498,16 @@ StreamPtr HashJoinExec::execute_needed(int partition, const Exec& ex, const std:
             uint32_t* lidx = need_left ? tmp.get<uint32_t>((size_t)n_out) : nullptr;
             TIMED_LAUNCH_N(ex, "select_indices", n, launch_select_indices(cfg, bitmap, tile_off, n, ridx));
             if (need_left) TIMED_LAUNCH_N(ex, "join_compact_staged", n, launch_join_compact_staged(cfg, staging, tile_off, n_out, n_tiles, lidx));
-            emit(&b, &rmap, lidx, ridx, (int64_t)n_out);
+            if (remap) {
+                uint32_t* orig = tmp.get<uint32_t>((size_t)n_out);
+                TIMED_LAUNCH_N(ex, "take_fixed", n_out, launch_take_fixed(cfg, remap, 4, ridx, (int64_t)n_out, orig));
+                ridx = orig;
+            }
+            emit(outsrc, rmap, lidx, ridx, (int64_t)n_out);
             HIP_CHECK(hipStreamSynchronize(ex.stream));
         };
+        ProbeFilter no_filter;
+        memset(&no_filter, 0, sizeof(no_filter));
 
         const ProbeChain chain = probe_chain(self->right_);
         static const bool fused_disabled = [] { const char* v = getenv("BHIP_NO_FUSED_PROBE"); return v && atoi(v) != 0; }();
@@ -491,32 +526,34 @@ StreamPtr HashJoinExec::execute_needed(int partition, const Exec& ex, const std:
             while (BatchPtr b = ss->next()) {
                 if (b->n_rows == 0) continue;
                 ProbeFilter F;
-                if (bs->narrow && !fused_disabled && b->n_rows <= 0xFFFFF000ll && int_ranges_of(chain.pred, *b, F)) {
-                    process_fused(*b, F, b->cols[key_src[0]], rmap);
+                if (bs->narrow && !fused_disabled && int_ranges_of(chain.pred, *b, F)) {
+                    process_fused(b->n_rows, F, b->cols[key_src[0]], b.get(), &rmap, nullptr);
                     continue;
                 }
-                if (!chain.pred) {
-                    Batch kv;                                  // the key columns under their probe-side names
-                    kv.schema = key_schema;
-                    kv.ctx = b->ctx;
-                    kv.n_rows = b->n_rows;
-                    for (int ci : key_src) kv.cols.push_back(b->cols[ci]);
-                    process(kv, b.get(), &rmap, nullptr);
-                    continue;
-                }
+                const uint32_t* remap = nullptr;
                 BufferPtr sel;
-                const int64_t n_sel = filter_indices(ex, *b, chain.pred, sel);
-                if (n_sel == 0) continue;
-                auto kb = std::make_shared<Batch>();           // key columns of the surviving rows only
+                auto kb = std::make_shared<Batch>();           // the key columns under their probe-side names ...
                 kb->schema = key_schema;
                 kb->ctx = b->ctx;
-                kb->n_rows = n_sel;
-                for (int ci : key_src) kb->cols.push_back(take_batch_column(ex, b->cols[ci], sel->as<uint32_t>(), n_sel));
-                process(*kb, b.get(), &rmap, sel->as<uint32_t>());
+                kb->n_rows = b->n_rows;
+                if (chain.pred) {                              // ... of the surviving rows only
+                    const int64_t n_sel = filter_indices(ex, *b, chain.pred, sel);
+                    if (n_sel == 0) continue;
+                    kb->n_rows = n_sel;
+                    remap = sel->as<uint32_t>();
+                    for (int ci : key_src) kb->cols.push_back(take_batch_column(ex, b->cols[ci], remap, n_sel));
+                } else {
+                    for (int ci : key_src) kb->cols.push_back(b->cols[ci]);
+                }
+                if (bs->narrow) process_fused(kb->n_rows, no_filter, kb->cols[0], b.get(), &rmap, remap);
+                else process(*kb, b.get(), &rmap, remap);
             }
         } else {
             auto rs = self->right_->execute(partition, ex);
-            while (BatchPtr rb = rs->next()) process(*rb, rb.get(), nullptr, nullptr);
+            while (BatchPtr rb = rs->next()) {
+                if (bs->narrow) process_fused(rb->n_rows, no_filter, rb->cols[rb->schema->index_of(rcols[0])], rb.get(), nullptr, nullptr);
+                else process(*rb, rb.get(), nullptr, nullptr);
+            }
         }
         if (left_outer && n_left > 0) {
             // left rows no probe row matched: right columns NULL

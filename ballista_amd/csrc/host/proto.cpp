@@ -175,7 +175,7 @@ SchemaPtr decode_schema(Pb r) {
 // ---- expressions -----------------------------------------------------------------------------------------------------------
 ExprPtr decode_expr(Pb r);
 
-ExprPtr new_literal(int dtype) {
+[[maybe_unused]] ExprPtr new_literal(int dtype) {
     auto e = std::make_shared<Expr>();
     e->kind = BHIP_EXPR_LITERAL;
     e->dtype = dtype;

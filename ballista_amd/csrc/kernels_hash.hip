@@ -302,118 +302,6 @@ join_build_narrow_kernel(NarrowJoinTable T, const uint32_t* keys, const uint64_t
     }
 }
 
-// PROBE_ROWS rows per lane and pass: the key loads, then the presence-bit loads, of all of them are in flight together
-// (the chain key -> bit -> slot is latency, not bandwidth: one row per pass left the kernel at 1.6 TB/s on Q5's 600 M probes)
-template <int PROBE_ROWS>   // 4: Q3 / Q5 SF100 5.39 / 5.65 ms; 2: 5.40 / 5.73; 8: 5.85 / 6.30 (registers)
-__global__ void __launch_bounds__(BLOCK)
-join_probe_match_narrow_kernel(NarrowJoinTable T, const uint32_t* rkeys, const uint64_t* rsel, const uint32_t* gather,
-                               uint32_t n_right, int right_outer, uint32_t* partner, uint64_t* bitmap, uint32_t* tile_counts,
-                               uint32_t* matched) {
-    static_assert(SEL_TILE % (64 * PROBE_ROWS) == 0, "the rows of one pass of a wave lie in one selection tile");
-    const int lane = threadIdx.x & 63;
-    const uint64_t n_round = ((uint64_t)n_right + 63u) & ~(uint64_t)63;          // rows covered by bitmap words
-    const uint64_t wave_rows = 64ull * PROBE_ROWS;
-    const uint64_t wave_id = (uint64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
-    const uint64_t n_waves = (uint64_t)gridDim.x * (BLOCK / 64);
-    for (uint64_t wbase = wave_id * wave_rows; wbase < n_round; wbase += n_waves * wave_rows) {
-        uint32_t key[PROBE_ROWS], m[PROBE_ROWS], pbit[PROBE_ROWS];
-        bool in[PROBE_ROWS], live[PROBE_ROWS];
-#pragma unroll
-        for (int k = 0; k < PROBE_ROWS; ++k) {
-            const uint64_t row64 = wbase + 64ull * k + lane;
-            in[k] = row64 < n_right;
-            const uint32_t src = (in[k] && gather) ? gather[(uint32_t)row64] : (uint32_t)row64;   // probe row -> row of the key column
-            live[k] = in[k] && bit_at(rsel, src);
-            key[k] = live[k] ? rkeys[src] : 0u;
-            m[k] = 0xFFFFFFFFu;
-        }
-        // the exact set of build keys as one bit per value of [kmin, kmin + krange]: a probe that cannot match stops
-        // at a 32x smaller, mostly cache-resident structure and never touches the table
-        if (T.present) {
-#pragma unroll
-            for (int k = 0; k < PROBE_ROWS; ++k) {
-                const uint32_t d = key[k] - T.kmin;
-                live[k] = live[k] && d <= T.krange;
-                pbit[k] = live[k] ? (T.present[d >> 5] >> (d & 31)) & 1u : 0u;
-            }
-#pragma unroll
-            for (int k = 0; k < PROBE_ROWS; ++k) live[k] = live[k] && pbit[k];
-        }
-        // (loading the first slot of all four rows before looking at any was tried: the extra live registers cost more than
-        // the overlap gains — Q3's probe 1.10 -> 1.33 ms under rocprofv3)
-#pragma unroll
-        for (int k = 0; k < PROBE_ROWS; ++k) {
-            if (live[k]) {
-                uint64_t slot = narrow_hash(key[k]) & T.mask;
-                for (;;) {
-                    const uint64_t v = T.slots[slot];
-                    if (v == 0) break;
-                    if ((uint32_t)v == key[k]) { m[k] = (uint32_t)(v >> 32) - 1u; break; }
-                    slot = (slot + 1) & T.mask;
-                }
-                if (matched && m[k] != 0xFFFFFFFFu) atomicOr(&matched[m[k] >> 5], 1u << (m[k] & 31));
-            }
-        }
-        uint32_t emitted = 0;
-#pragma unroll
-        for (int k = 0; k < PROBE_ROWS; ++k) {
-            const uint64_t row64 = wbase + 64ull * k + lane;
-            const bool emit = in[k] && (right_outer || m[k] != 0xFFFFFFFFu);
-            if (emit) partner[(uint32_t)row64] = m[k];               // only emitted rows are ever read back (through the index list)
-            const uint64_t word = __ballot(emit);
-            if (lane == 0 && wbase + 64ull * k < n_round) bitmap[(wbase >> 6) + k] = word;
-            emitted += (uint32_t)__popcll(word);
-        }
-        if (lane == 0 && emitted) atomicAdd(&tile_counts[wbase / SEL_TILE], emitted);
-    }
-}
-
-// signed minimum / maximum of the build keys (mm[0] = min, mm[1] = max; the host seeds them with INT_MAX / INT_MIN)
-__global__ void __launch_bounds__(BLOCK)
-join_key_minmax_kernel(const int32_t* keys, const uint64_t* sel, uint32_t n, int32_t* mm) {
-    int32_t lo = 2147483647, hi = -2147483647 - 1;
-    for (uint32_t row = blockIdx.x * BLOCK + threadIdx.x; row < n; row += gridDim.x * BLOCK)
-        if (bit_at(sel, row)) { const int32_t k = keys[row]; lo = k < lo ? k : lo; hi = k > hi ? k : hi; }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const int32_t l2 = __shfl_down(lo, d, 64), h2 = __shfl_down(hi, d, 64);
-        lo = l2 < lo ? l2 : lo;
-        hi = h2 > hi ? h2 : hi;
-    }
-    // one pair of atomics per workgroup (same-address atomics serialise: thousands of them cost more than the scan of the keys)
-    __shared__ int32_t s_lo[BLOCK / 64], s_hi[BLOCK / 64];
-    if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < BLOCK / 64; ++w) { lo = s_lo[w] < lo ? s_lo[w] : lo; hi = s_hi[w] > hi ? s_hi[w] : hi; }
-        atomicMin(&mm[0], lo);
-        atomicMax(&mm[1], hi);
-    }
-}
-
-// 64-bit keys: mm[0] = min, mm[1] = max of key ^ 2^63 (signed order as unsigned; seeded with ~0 / 0)
-__global__ void __launch_bounds__(BLOCK)
-join_key_minmax64_kernel(const uint64_t* keys, const uint64_t* sel, uint32_t n, unsigned long long* mm) {
-    const uint64_t bias = 1ull << 63;
-    uint64_t lo = ~0ull, hi = 0;
-    for (uint32_t row = blockIdx.x * BLOCK + threadIdx.x; row < n; row += gridDim.x * BLOCK)
-        if (bit_at(sel, row)) { const uint64_t k = keys[row] ^ bias; lo = k < lo ? k : lo; hi = k > hi ? k : hi; }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const uint64_t l2 = __shfl_down((unsigned long long)lo, d, 64), h2 = __shfl_down((unsigned long long)hi, d, 64);
-        lo = l2 < lo ? l2 : lo;
-        hi = h2 > hi ? h2 : hi;
-    }
-    __shared__ uint64_t s_lo[BLOCK / 64], s_hi[BLOCK / 64];
-    if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < BLOCK / 64; ++w) { lo = s_lo[w] < lo ? s_lo[w] : lo; hi = s_hi[w] > hi ? s_hi[w] : hi; }
-        atomicMin(&mm[0], (unsigned long long)lo);
-        atomicMax(&mm[1], (unsigned long long)hi);
-    }
-}
-
 __global__ void __launch_bounds__(BLOCK)
 join_key_present64_kernel(const uint64_t* keys, const uint64_t* sel, uint32_t n, uint64_t kmin, uint32_t* present) {
     for (uint32_t row = blockIdx.x * BLOCK + threadIdx.x; row < n; row += gridDim.x * BLOCK)
@@ -506,69 +394,6 @@ join_build_narrow64_kernel(NarrowJoinTable T, const uint64_t* keys, const uint64
 }
 
 __global__ void __launch_bounds__(BLOCK)
-join_probe_match_narrow64_kernel(NarrowJoinTable T, const uint64_t* rkeys, const uint64_t* rsel, const uint32_t* gather,
-                                 uint32_t n_right, int right_outer, uint32_t* partner, uint64_t* bitmap, uint32_t* tile_counts,
-                                 uint32_t* matched) {
-    constexpr int PROBE_ROWS = 4;                                    // as join_probe_match_narrow_kernel
-    static_assert(SEL_TILE % (64 * PROBE_ROWS) == 0, "the rows of one pass of a wave lie in one selection tile");
-    const ulonglong2* slots = reinterpret_cast<const ulonglong2*>(T.slots);
-    const int lane = threadIdx.x & 63;
-    const uint64_t n_round = ((uint64_t)n_right + 63u) & ~(uint64_t)63;
-    const uint64_t wave_rows = 64ull * PROBE_ROWS;
-    const uint64_t wave_id = (uint64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
-    const uint64_t n_waves = (uint64_t)gridDim.x * (BLOCK / 64);
-    for (uint64_t wbase = wave_id * wave_rows; wbase < n_round; wbase += n_waves * wave_rows) {
-        uint64_t key[PROBE_ROWS];
-        uint32_t m[PROBE_ROWS], pbit[PROBE_ROWS];
-        bool in[PROBE_ROWS], live[PROBE_ROWS];
-#pragma unroll
-        for (int k = 0; k < PROBE_ROWS; ++k) {
-            const uint64_t row64 = wbase + 64ull * k + lane;
-            in[k] = row64 < n_right;
-            const uint32_t src = (in[k] && gather) ? gather[(uint32_t)row64] : (uint32_t)row64;
-            live[k] = in[k] && bit_at(rsel, src);
-            key[k] = live[k] ? rkeys[src] : 0ull;
-            m[k] = 0xFFFFFFFFu;
-        }
-        if (T.present) {
-#pragma unroll
-            for (int k = 0; k < PROBE_ROWS; ++k) {
-                const uint64_t d = key[k] - T.kmin64;
-                live[k] = live[k] && d <= T.krange;
-                pbit[k] = live[k] ? (T.present[d >> 5] >> (d & 31)) & 1u : 0u;
-            }
-#pragma unroll
-            for (int k = 0; k < PROBE_ROWS; ++k) live[k] = live[k] && pbit[k];
-        }
-#pragma unroll
-        for (int k = 0; k < PROBE_ROWS; ++k) {
-            if (live[k]) {
-                uint64_t slot = mix64(key[k]) & T.mask;
-                for (;;) {
-                    const ulonglong2 v = slots[slot];                // {key, row1 | pad << 32}
-                    const uint32_t r = (uint32_t)v.y;
-                    if (r == 0) break;
-                    if (v.x == key[k]) { m[k] = r - 1u; break; }
-                    slot = (slot + 1) & T.mask;
-                }
-                if (matched && m[k] != 0xFFFFFFFFu) atomicOr(&matched[m[k] >> 5], 1u << (m[k] & 31));
-            }
-        }
-        uint32_t emitted = 0;
-#pragma unroll
-        for (int k = 0; k < PROBE_ROWS; ++k) {
-            const uint64_t row64 = wbase + 64ull * k + lane;
-            const bool emit = in[k] && (right_outer || m[k] != 0xFFFFFFFFu);
-            if (emit) partner[(uint32_t)row64] = m[k];
-            const uint64_t word = __ballot(emit);
-            if (lane == 0 && wbase + 64ull * k < n_round) bitmap[(wbase >> 6) + k] = word;
-            emitted += (uint32_t)__popcll(word);
-        }
-        if (lane == 0 && emitted) atomicAdd(&tile_counts[wbase / SEL_TILE], emitted);
-    }
-}
-
-__global__ void __launch_bounds__(BLOCK)
 join_unmatched_flags_kernel(const uint32_t* matched, uint32_t n_left, uint32_t* flags) {
     for (uint32_t row = blockIdx.x * BLOCK + threadIdx.x; row < n_left; row += gridDim.x * BLOCK)
         flags[row] = ((matched[row >> 5] >> (row & 31)) & 1u) ? 0u : 1u;
@@ -634,17 +459,6 @@ hipError_t launch_wide_key_assign(const LaunchCfg& cfg, const WideKeyCols& K, co
     hipLaunchKernelGGL(wide_key_assign_kernel, dim3(grid_rows(cfg, n)), dim3(BLOCK), 0, cfg.stream, K, hashes, table, mask, n, rep);
     return hipGetLastError();
 }
-hipError_t launch_join_key_minmax(const LaunchCfg& cfg, const int32_t* keys, const uint64_t* sel, uint32_t n, int32_t* mm) {
-    if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(join_key_minmax_kernel, dim3(grid_rows(cfg, n)), dim3(BLOCK), 0, cfg.stream, keys, sel, n, mm);
-    return hipGetLastError();
-}
-hipError_t launch_join_key_minmax64(const LaunchCfg& cfg, const uint64_t* keys, const uint64_t* sel, uint32_t n, uint64_t* mm) {
-    if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(join_key_minmax64_kernel, dim3(grid_rows(cfg, n)), dim3(BLOCK), 0, cfg.stream, keys, sel, n,
-                       reinterpret_cast<unsigned long long*>(mm));
-    return hipGetLastError();
-}
 hipError_t launch_join_key_present64(const LaunchCfg& cfg, const uint64_t* keys, const uint64_t* sel, uint32_t n, uint64_t kmin,
                                      uint32_t* present) {
     if (n == 0) return hipSuccess;
@@ -655,21 +469,6 @@ hipError_t launch_join_key_present(const LaunchCfg& cfg, const uint32_t* keys, c
                                    uint32_t* present) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(join_key_present_kernel, dim3(grid_rows(cfg, n)), dim3(BLOCK), 0, cfg.stream, keys, sel, n, kmin, present);
-    return hipGetLastError();
-}
-hipError_t launch_join_probe_match_narrow(const LaunchCfg& cfg, const NarrowJoinTable& T, const void* rkeys, int key_width,
-                                          const uint64_t* rsel, const uint32_t* gather, uint32_t n_right, bool right_outer,
-                                          uint32_t* partner, uint64_t* bitmap, uint32_t* tile_counts, uint32_t* matched) {
-    if (n_right == 0) return hipSuccess;
-    const size_t n_tiles = ((size_t)n_right + SEL_TILE - 1) / SEL_TILE;
-    hipError_t e = hipMemsetAsync(tile_counts, 0, n_tiles * 4, cfg.stream);
-    if (e != hipSuccess) return e;
-    if (key_width == 4)
-        hipLaunchKernelGGL(join_probe_match_narrow_kernel<4>, dim3(grid_rows(cfg, n_right)), dim3(BLOCK), 0, cfg.stream, T,
-                           (const uint32_t*)rkeys, rsel, gather, n_right, right_outer ? 1 : 0, partner, bitmap, tile_counts, matched);
-    else
-        hipLaunchKernelGGL(join_probe_match_narrow64_kernel, dim3(grid_rows(cfg, n_right)), dim3(BLOCK), 0, cfg.stream, T,
-                           (const uint64_t*)rkeys, rsel, gather, n_right, right_outer ? 1 : 0, partner, bitmap, tile_counts, matched);
     return hipGetLastError();
 }
 hipError_t launch_join_unmatched_flags(const LaunchCfg& cfg, const uint32_t* matched, uint32_t n_left, uint32_t* flags) {

@@ -1,16 +1,22 @@
-// kernels_join.hip — the probe side of HashJoinExec (rust/core/src/serde/physical_plan/from_proto.rs:253-276) as ONE pass over
-// the UNFILTERED probe batch when the build side is the narrow table of kernels_hash.hip (one integer key, unique):
+// kernels_join.hip — HashJoinExec (rust/core/src/serde/physical_plan/from_proto.rs:253-276) for ONE integer key and a unique
+// build side — every join of TPC-H Q3 / Q5 but Q5's two-column supplier join.
 //
-//     FilterExec(AND of integer ranges)  ->  [ProjectionExec(columns)]  ->  HashJoinExec probe
+// BUILD.  `join_key_stats` reads the build keys once: min, max, "strictly increasing" (= sorted and unique).
+//   * Keys inside a window of <= 2^30 values (dense surrogate keys: o_orderkey, c_custkey, ...) get a RANK MAP instead of a hash
+//     table: bits[] = the exact key set, one bit per value of the window; prefix[w] = set bits before 64-bit word w.  The rank of
+//     a present key (prefix + popcount of the lower bits of its word) IS its build row when the build side arrives sorted by key
+//     (a table stored in key order stays sorted under FilterExec); otherwise perm[rank] = build row.  No CAS, no collisions, no
+//     load factor: a sorted build side is written with plain stores (a wave combines the bits of a word; only words that straddle
+//     two waves take an atomicOr), an unsorted one with one atomicOr per key (which also finds duplicate keys).  A probe that
+//     cannot match ends at the bit — the same single random read the round-1 key-set bitmap cost — and a probe that matches reads
+//     one more 4-byte word (and perm[] for unsorted builds) instead of walking a 2x-oversized table of 8-byte slots.
+//   * Sparse keys keep the CAS table of kernels_hash.hip (join_build_narrow_kernel).
 //
-// is what TPC-H Q3 / Q5 put on the probe side of every large join (l_shipdate > d, o_orderdate < d, o_orderdate in a year).
-// The reference runs it as three operators with a materialised batch between each; the round-1 path here ran it as
-// predicate bitmap -> index list -> probe THROUGH the index list -> second index list.  This kernel reads the predicate
-// columns and the key column once, coalesced, tests the ranges, the build side's key-set bitmap and the table, and leaves
-//   * the selection bitmap of the rows that are emitted (bit = row of the unfiltered batch),
-//   * their number per 1024-row tile (a plain store: one wave owns a whole tile, no atomics, deterministic),
-//   * the build row of every emitted row, compacted per tile (staging[tile * 1024 + rank in tile]),
-// so the passes after it are the FilterExec index pass (row indices) and one copy that strings the staged partners together.
+// PROBE.  `join_filter_probe_kernel` walks the UNFILTERED probe batch once: AND of integer ranges (the FilterExec under the join:
+// l_shipdate > d, o_orderdate < d, ...) -> key-set bit -> rank / table.  One wave owns a 1024-row tile: the per-tile counts are
+// plain stores, the build rows of the emitted rows are staged compacted per tile, results are deterministic.  Inside a 256-row
+// pass the rows that survive the bit test (Q3: ~5 % of lineitem) are packed into consecutive lanes through LDS before the
+// dependent reads, so a pass pays ONE round trip for all of them instead of one per row slot.
 // Algorithmic bytes per probe row: predicate columns + key column once, + 1 bit; per emitted row 4 B partner twice.
 #include <hip/hip_runtime.h>
 #include "host/hash_kernels.h"
@@ -22,18 +28,136 @@ namespace {
 
 __device__ inline bool jbit_at(const uint64_t* bm, uint64_t i) { return bm == nullptr || ((bm[i >> 6] >> (i & 63)) & 1ull); }
 
-constexpr int FP_ROWS = 4;                       // rows per lane and pass: their loads are in flight together
-constexpr int FP_CHUNK = 64 * FP_ROWS;           // rows of one pass of a wave
-static_assert(SEL_TILE % FP_CHUNK == 0, "a tile is a whole number of passes");
-
 template <int KW> struct KeyT;
 template <> struct KeyT<4> { using type = uint32_t; };
 template <> struct KeyT<8> { using type = uint64_t; };
 
-struct alignas(16) Slot64 { uint64_t key; uint64_t row1; };
+// key -> offset in the window [kmin, kmin + range]; keys are compared in SIGNED order (Int32 / Int64 / Date32; UInt64 keys above
+// 2^63 wrap, which only makes the window test fail safely into "absent" for keys the build side cannot hold either)
+template <int KW>
+__device__ inline uint64_t key_offset(typename KeyT<KW>::type key, uint64_t kmin) {
+    if constexpr (KW == 4) return (uint64_t)(uint32_t)(key - (uint32_t)kmin);
+    else return key - kmin;
+}
+
+// ---- build ---------------------------------------------------------------------------------------------------------------
+// stats[0] = min, stats[1] = max of (key ^ sign bit) as unsigned 64-bit (seeded ~0 / 0); stats[2] |= 1 when some key is not
+// greater than its predecessor; rows with a NULL key (sel) are skipped and make the side "unsorted"
+template <int KW>
+__global__ void __launch_bounds__(BLOCK)
+join_key_stats_kernel(const void* __restrict__ keys_v, const uint64_t* __restrict__ sel, uint32_t n, unsigned long long* stats) {
+    using K = typename KeyT<KW>::type;
+    const K* __restrict__ keys = static_cast<const K*>(keys_v);
+    const uint64_t bias = KW == 4 ? 0x80000000ull : (1ull << 63);
+    uint64_t lo = ~0ull, hi = 0;
+    uint32_t unsorted = sel != nullptr ? 1u : 0u;
+    for (uint32_t row = blockIdx.x * BLOCK + threadIdx.x; row < n; row += gridDim.x * BLOCK) {
+        if (!jbit_at(sel, row)) continue;
+        const K k = keys[row];
+        const uint64_t b = ((uint64_t)k ^ bias) & (KW == 4 ? 0xFFFFFFFFull : ~0ull);
+        lo = b < lo ? b : lo;
+        hi = b > hi ? b : hi;
+        if (row + 1 < n) {
+            const uint64_t nb = ((uint64_t)keys[row + 1] ^ bias) & (KW == 4 ? 0xFFFFFFFFull : ~0ull);
+            if (nb <= b) unsorted = 1u;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint64_t l2 = __shfl_down((unsigned long long)lo, d, 64), h2 = __shfl_down((unsigned long long)hi, d, 64);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    const bool any_unsorted = __ballot(unsorted != 0) != 0ull;
+    __shared__ uint64_t s_lo[BLOCK / 64], s_hi[BLOCK / 64];
+    __shared__ uint32_t s_un[BLOCK / 64];
+    if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; s_un[threadIdx.x >> 6] = any_unsorted; }
+    __syncthreads();
+    if (threadIdx.x == 0) {      // one set of atomics per workgroup
+        uint32_t un = s_un[0];
+        for (int w = 1; w < BLOCK / 64; ++w) { lo = s_lo[w] < lo ? s_lo[w] : lo; hi = s_hi[w] > hi ? s_hi[w] : hi; un |= s_un[w]; }
+        atomicMin(&stats[0], (unsigned long long)lo);
+        atomicMax(&stats[1], (unsigned long long)hi);
+        if (un) atomicOr(&stats[2], 1ull);
+    }
+}
+
+// sorted, unique build keys: lanes whose keys fall into the same 64-bit word are neighbours; the last lane of each run writes
+// the combined bits — with a plain store when the run lies strictly inside the wave (then no other wave holds a key of that
+// word), with an atomicOr when it touches the wave's first or last lane
+template <int KW>
+__global__ void __launch_bounds__(BLOCK)
+rank_bits_sorted_kernel(const void* __restrict__ keys_v, uint32_t n, uint64_t kmin, unsigned long long* __restrict__ bits) {
+    using K = typename KeyT<KW>::type;
+    const K* __restrict__ keys = static_cast<const K*>(keys_v);
+    const int lane = threadIdx.x & 63;
+    const uint32_t n_round = (n + 63u) & ~63u;
+    for (uint32_t row = blockIdx.x * BLOCK + threadIdx.x; row < n_round; row += gridDim.x * BLOCK) {
+        const bool in = row < n;
+        const uint64_t d = in ? key_offset<KW>(keys[row], kmin) : 0;
+        const uint64_t wi = in ? (d >> 6) : ~0ull;
+        uint64_t m = in ? (1ull << (d & 63)) : 0ull;
+        // inclusive segmented OR over runs of equal wi (runs are contiguous: the keys increase)
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint64_t pm = __shfl_up((unsigned long long)m, off, 64);
+            const uint64_t pw = __shfl_up((unsigned long long)wi, off, 64);
+            if (lane >= off && pw == wi) m |= pm;
+        }
+        const uint64_t next_wi = __shfl_down((unsigned long long)wi, 1, 64);
+        const uint64_t first_wi = __shfl((unsigned long long)wi, 0, 64);     // outside the branch: every lane takes part in a shuffle
+        const bool last_of_run = in && (lane == 63 || next_wi != wi);
+        if (last_of_run) {
+            const bool touches_edge = lane == 63 || first_wi == wi || row + 1 >= n;
+            if (touches_edge) atomicOr(&bits[wi], (unsigned long long)m);
+            else bits[wi] = m;
+        }
+    }
+}
+
+// any order: one atomicOr per key; a bit that was already set is a duplicate key
+template <int KW>
+__global__ void __launch_bounds__(BLOCK)
+rank_bits_any_kernel(const void* __restrict__ keys_v, const uint64_t* __restrict__ sel, uint32_t n, uint64_t kmin,
+                     unsigned long long* __restrict__ bits, uint32_t* dup_flag) {
+    using K = typename KeyT<KW>::type;
+    const K* __restrict__ keys = static_cast<const K*>(keys_v);
+    for (uint32_t row = blockIdx.x * BLOCK + threadIdx.x; row < n; row += gridDim.x * BLOCK) {
+        if (!jbit_at(sel, row)) continue;
+        const uint64_t d = key_offset<KW>(keys[row], kmin);
+        const unsigned long long bit = 1ull << (d & 63);
+        if (atomicOr(&bits[d >> 6], bit) & bit) *dup_flag = 1u;
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK)
+rank_popcount_kernel(const uint64_t* __restrict__ bits, int64_t n_words, uint32_t* __restrict__ counts) {
+    for (int64_t w = (int64_t)blockIdx.x * BLOCK + threadIdx.x; w < n_words; w += (int64_t)gridDim.x * BLOCK)
+        counts[w] = (uint32_t)__popcll(bits[w]);
+}
+
+// unsorted build side: perm[rank of key] = build row
+template <int KW>
+__global__ void __launch_bounds__(BLOCK)
+rank_perm_kernel(const void* __restrict__ keys_v, const uint64_t* __restrict__ sel, uint32_t n, uint64_t kmin,
+                 const uint64_t* __restrict__ bits, const uint32_t* __restrict__ prefix, uint32_t* __restrict__ perm) {
+    using K = typename KeyT<KW>::type;
+    const K* __restrict__ keys = static_cast<const K*>(keys_v);
+    for (uint32_t row = blockIdx.x * BLOCK + threadIdx.x; row < n; row += gridDim.x * BLOCK) {
+        if (!jbit_at(sel, row)) continue;
+        const uint64_t d = key_offset<KW>(keys[row], kmin);
+        const uint64_t w = bits[d >> 6];
+        perm[prefix[d >> 6] + (uint32_t)__popcll(w & ((1ull << (d & 63)) - 1ull))] = row;
+    }
+}
+
+// ---- probe ---------------------------------------------------------------------------------------------------------------
+constexpr int FP_ROWS = 4;                       // rows per lane and pass: their loads are in flight together
+constexpr int FP_CHUNK = 64 * FP_ROWS;           // rows of one pass of a wave
+static_assert(SEL_TILE % FP_CHUNK == 0, "a tile is a whole number of passes");
 
 template <int KW>
-__device__ inline uint32_t narrow_lookup(const NarrowJoinTable& T, typename KeyT<KW>::type key) {
+__device__ inline uint32_t table_lookup(const NarrowJoinTable& T, typename KeyT<KW>::type key) {
     if constexpr (KW == 4) {
         uint64_t slot = mix64((uint64_t)key) & T.mask;
         for (;;) {
@@ -55,12 +179,20 @@ __device__ inline uint32_t narrow_lookup(const NarrowJoinTable& T, typename KeyT
     }
 }
 
+// per-wave LDS scratch of the lookup compaction: up to FP_CHUNK packed items
+struct WaveScratch {
+    uint64_t a[FP_CHUNK];        // rank map: word index; table: the key
+    uint32_t b[FP_CHUNK];        // rank map: popcount of the lower bits; then: the result (build row)
+};
+
 template <int KW>
 __global__ void __launch_bounds__(BLOCK)
 join_filter_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void* __restrict__ rkeys_v, const uint64_t* __restrict__ rsel,
                          uint32_t n_right, int right_outer, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts,
                          uint32_t* __restrict__ staging, uint32_t* matched) {
     using K = typename KeyT<KW>::type;
+    __shared__ WaveScratch scratch[BLOCK / 64];
+    WaveScratch& S = scratch[threadIdx.x >> 6];
     const K* __restrict__ rkeys = static_cast<const K*>(rkeys_v);
     const int lane = threadIdx.x & 63;
     const uint64_t lane_lt = (1ull << lane) - 1ull;
@@ -68,6 +200,7 @@ join_filter_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const voi
     const uint64_t n_words = ((uint64_t)n_right + 63) / 64;
     const uint32_t wave_id = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (BLOCK / 64);
+    const bool ranked = T.rbits != nullptr;
     for (uint32_t t = wave_id; t < n_tiles; t += n_waves) {
         const uint64_t tile_base = (uint64_t)t * SEL_TILE;
         uint32_t tile_cnt = 0;
@@ -82,7 +215,7 @@ join_filter_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const voi
             }
             K key[FP_ROWS];
             int32_t f[JOIN_FILTER_MAX][FP_ROWS];
-            bool in[FP_ROWS], pass[FP_ROWS];
+            bool in[FP_ROWS], pass[FP_ROWS], live[FP_ROWS];
             uint32_t m[FP_ROWS];
 #pragma unroll
             for (int k = 0; k < FP_ROWS; ++k) {
@@ -101,37 +234,66 @@ join_filter_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const voi
                     if (j < F.n) p = p && f[j][k] >= F.lo[j] && f[j][k] <= F.hi[j];
                 pass[k] = p;
                 m[k] = 0xFFFFFFFFu;
+                live[k] = p && jbit_at(rsel, base + 64ull * k + lane);          // NULL keys never match
             }
-            bool live[FP_ROWS];
-#pragma unroll
-            for (int k = 0; k < FP_ROWS; ++k) live[k] = pass[k] && jbit_at(rsel, base + 64ull * k + lane);      // NULL keys never match
-            if (T.present) {
-                uint32_t pbit[FP_ROWS];
+            // ---- the exact key set: one bit per value of the window (rank map: rbits, CAS table: present) ----------------
+            uint64_t d[FP_ROWS], word[FP_ROWS];
+            if (ranked || T.present) {
 #pragma unroll
                 for (int k = 0; k < FP_ROWS; ++k) {
-                    uint64_t d;
-                    if constexpr (KW == 4) d = (uint32_t)(key[k] - T.kmin);
-                    else d = key[k] - T.kmin64;
-                    live[k] = live[k] && d <= T.krange;
-                    pbit[k] = live[k] ? (T.present[d >> 5] >> (d & 31)) & 1u : 0u;
+                    d[k] = key_offset<KW>(key[k], T.kmin64);
+                    live[k] = live[k] && d[k] <= T.krange;
+                    if (ranked) word[k] = live[k] ? T.rbits[d[k] >> 6] : 0ull;
+                    else word[k] = live[k] ? (uint64_t)T.present[d[k] >> 5] << (d[k] & 32) : 0ull;      // the 32-bit word at its place in the 64-bit one
                 }
 #pragma unroll
-                for (int k = 0; k < FP_ROWS; ++k) live[k] = live[k] && pbit[k];
+                for (int k = 0; k < FP_ROWS; ++k) live[k] = live[k] && ((word[k] >> (d[k] & 63)) & 1ull);
             }
+            // ---- pack the surviving row slots into consecutive lanes, one round of dependent reads for all of them ---------
+            uint64_t lw[FP_ROWS];
+            uint32_t before[FP_ROWS], total = 0;
 #pragma unroll
-            for (int k = 0; k < FP_ROWS; ++k) {
-                if (live[k]) {
-                    m[k] = narrow_lookup<KW>(T, key[k]);
-                    if (matched && m[k] != 0xFFFFFFFFu) atomicOr(&matched[m[k] >> 5], 1u << (m[k] & 31));
+            for (int k = 0; k < FP_ROWS; ++k) { lw[k] = __ballot(live[k]); before[k] = total; total += (uint32_t)__popcll(lw[k]); }
+            if (total) {                                                // wave-uniform
+                uint32_t idx[FP_ROWS];
+#pragma unroll
+                for (int k = 0; k < FP_ROWS; ++k) {
+                    idx[k] = before[k] + (uint32_t)__popcll(lw[k] & lane_lt);
+                    if (live[k]) {
+                        if (ranked) { S.a[idx[k]] = d[k] >> 6; S.b[idx[k]] = (uint32_t)__popcll(word[k] & ((1ull << (d[k] & 63)) - 1ull)); }
+                        else S.a[idx[k]] = (uint64_t)key[k];
+                    }
                 }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t j = lane; j < total; j += 64) {
+                    uint32_t r;
+                    if (ranked) {
+                        r = T.rprefix[S.a[j]] + S.b[j];
+                        if (T.rperm) r = T.rperm[r];
+                    } else {
+                        r = table_lookup<KW>(T, (K)S.a[j]);
+                    }
+                    S.b[j] = r;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int k = 0; k < FP_ROWS; ++k) {
+                    if (live[k]) {
+                        m[k] = S.b[idx[k]];
+                        if (matched && m[k] != 0xFFFFFFFFu) atomicOr(&matched[m[k] >> 5], 1u << (m[k] & 31));
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();                        // the next pass overwrites the scratch
             }
 #pragma unroll
             for (int k = 0; k < FP_ROWS; ++k) {
                 const bool emit = pass[k] && (right_outer || m[k] != 0xFFFFFFFFu);
-                const uint64_t word = __ballot(emit);
-                if (lane == 0 && (base >> 6) + k < n_words) bitmap[(base >> 6) + k] = word;
-                if (emit && staging) staging[tile_base + tile_cnt + (uint32_t)__popcll(word & lane_lt)] = m[k];
-                tile_cnt += (uint32_t)__popcll(word);
+                const uint64_t wd = __ballot(emit);
+                if (lane == 0 && (base >> 6) + k < n_words) bitmap[(base >> 6) + k] = wd;
+                if (emit && staging) staging[tile_base + tile_cnt + (uint32_t)__popcll(wd & lane_lt)] = m[k];
+                tile_cnt += (uint32_t)__popcll(wd);
             }
         }
         if (lane == 0) tile_counts[t] = tile_cnt;
@@ -153,14 +315,60 @@ join_compact_staged_kernel(const uint32_t* __restrict__ staging, const uint64_t*
     }
 }
 
+int rows_grid(const LaunchCfg& cfg, size_t n) {
+    size_t g = (n + BLOCK - 1) / BLOCK;
+    const size_t cap = (size_t)cfg.device_cus * 16;
+    if (g > cap) g = cap;
+    return g < 1 ? 1 : (int)g;
+}
+
 }  // namespace
+
+hipError_t launch_join_key_stats(const LaunchCfg& cfg, const void* keys, int key_width, const uint64_t* sel, uint32_t n, uint64_t* stats) {
+    if (n == 0) return hipSuccess;
+    auto st = reinterpret_cast<unsigned long long*>(stats);
+    if (key_width == 4) hipLaunchKernelGGL(join_key_stats_kernel<4>, dim3(rows_grid(cfg, n)), dim3(BLOCK), 0, cfg.stream, keys, sel, n, st);
+    else hipLaunchKernelGGL(join_key_stats_kernel<8>, dim3(rows_grid(cfg, n)), dim3(BLOCK), 0, cfg.stream, keys, sel, n, st);
+    return hipGetLastError();
+}
+
+hipError_t launch_rank_bits(const LaunchCfg& cfg, const void* keys, int key_width, const uint64_t* sel, uint32_t n, uint64_t kmin, bool sorted,
+                            uint64_t* bits, uint32_t* dup_flag) {
+    if (n == 0) return hipSuccess;
+    auto b = reinterpret_cast<unsigned long long*>(bits);
+    const int grid = rows_grid(cfg, n);
+    if (sorted) {
+        if (key_width == 4) hipLaunchKernelGGL(rank_bits_sorted_kernel<4>, dim3(grid), dim3(BLOCK), 0, cfg.stream, keys, n, kmin, b);
+        else hipLaunchKernelGGL(rank_bits_sorted_kernel<8>, dim3(grid), dim3(BLOCK), 0, cfg.stream, keys, n, kmin, b);
+    } else {
+        if (key_width == 4) hipLaunchKernelGGL(rank_bits_any_kernel<4>, dim3(grid), dim3(BLOCK), 0, cfg.stream, keys, sel, n, kmin, b, dup_flag);
+        else hipLaunchKernelGGL(rank_bits_any_kernel<8>, dim3(grid), dim3(BLOCK), 0, cfg.stream, keys, sel, n, kmin, b, dup_flag);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_rank_popcount(const LaunchCfg& cfg, const uint64_t* bits, int64_t n_words, uint32_t* counts) {
+    if (n_words == 0) return hipSuccess;
+    hipLaunchKernelGGL(rank_popcount_kernel, dim3(rows_grid(cfg, (size_t)n_words)), dim3(BLOCK), 0, cfg.stream, bits, n_words, counts);
+    return hipGetLastError();
+}
+
+hipError_t launch_rank_perm(const LaunchCfg& cfg, const void* keys, int key_width, const uint64_t* sel, uint32_t n, uint64_t kmin,
+                            const uint64_t* bits, const uint32_t* prefix, uint32_t* perm) {
+    if (n == 0) return hipSuccess;
+    const int grid = rows_grid(cfg, n);
+    if (key_width == 4) hipLaunchKernelGGL(rank_perm_kernel<4>, dim3(grid), dim3(BLOCK), 0, cfg.stream, keys, sel, n, kmin, bits, prefix, perm);
+    else hipLaunchKernelGGL(rank_perm_kernel<8>, dim3(grid), dim3(BLOCK), 0, cfg.stream, keys, sel, n, kmin, bits, prefix, perm);
+    return hipGetLastError();
+}
 
 hipError_t launch_join_filter_probe(const LaunchCfg& cfg, const NarrowJoinTable& T, const ProbeFilter& F, const void* rkeys, int key_width,
                                     const uint64_t* rsel, uint32_t n_right, bool right_outer, uint64_t* bitmap, uint32_t* tile_counts,
                                     uint32_t* staging, uint32_t* matched) {
     if (n_right == 0) return hipSuccess;
     const int64_t n_tiles = ((int64_t)n_right + SEL_TILE - 1) / SEL_TILE;
-    int64_t grid = (int64_t)cfg.device_cus * 8;
+    static const int per_cu = [] { const char* v = getenv("BHIP_PROBE_BLOCKS_PER_CU"); return v && atoi(v) > 0 ? atoi(v) : 8; }();
+    int64_t grid = (int64_t)cfg.device_cus * per_cu;
     const int64_t need = (n_tiles + BLOCK / 64 - 1) / (BLOCK / 64);
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;

@@ -19,7 +19,7 @@ The flows are written against two small interfaces so that the SAME code runs un
 
   Engine  — how one rank computes: ProductEngine = the plans of ballista_amd.plan on the HIP library.
   Group   — how batches travel: RcclGroup (bhip_comm_*: RCCL on device buffers, inside libballista_hip.so),
-            GlooGroup (Arrow IPC bytes over torch.distributed gloo: rehearsal and CPU tests), SingleGroup.
+            GlooGroup (the same blocks through host memory over torch.distributed gloo: rehearsal and CPU tests), SingleGroup.
 """
 from __future__ import annotations
 
@@ -78,11 +78,18 @@ class ProductEngine:
     def nbytes(self, batch):
         return batch.memory_size()
 
-    def to_arrow(self, batch):
-        return batch.to_pyarrow()
+    def to_wire(self, batch):
+        """the block form the library's exchange moves (bhip_batch_pack), as host bytes: header words, then the block"""
+        import numpy as np
+        header, block = self.P.pack_batch(batch)
+        return np.concatenate([np.array([header.size], np.int64).view(np.uint8), header.view(np.uint8), block])
 
-    def from_arrow(self, rb):
-        return self.P.RecordBatch.from_pyarrow(self.ctx, rb)
+    def from_wire(self, raw, like):
+        import numpy as np
+        raw = np.ascontiguousarray(raw, np.uint8)
+        n = int(raw[:8].view(np.int64)[0])
+        header = raw[8:8 + 8 * n].view(np.int64).copy()
+        return self.P.unpack_batch(self.ctx, like.schema3(), header, raw[8 + 8 * n:])
 
 
 # ---- groups ----------------------------------------------------------------------------------------------------
@@ -113,7 +120,8 @@ class SingleGroup:
 
 
 class GlooGroup:
-    """torch.distributed (gloo) for control AND payload: batches travel as Arrow IPC stream bytes through host memory.
+    """torch.distributed (gloo) for control AND payload: batches travel through host memory in the engine's wire form
+    (ProductEngine: the packed block of bhip_batch_pack; the CPU tests' oracle engine: Arrow IPC stream bytes).
     The CPU tests' transport; on a GPU box it rehearses the N-rank flow with ranks sharing the GPU."""
     backend = "gloo"
 
@@ -144,27 +152,10 @@ class GlooGroup:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
-    @staticmethod
-    def _ipc(rb):
-        import numpy as np
-        import pyarrow as pa
-        sink = pa.BufferOutputStream()
-        with pa.ipc.new_stream(sink, rb.schema) as w:
-            w.write_batch(rb)
-        return np.frombuffer(sink.getvalue(), dtype=np.uint8)
-
-    @staticmethod
-    def _unipc(raw, schema):
-        import pyarrow as pa
-        t = pa.ipc.open_stream(pa.py_buffer(raw)).read_all()
-        b = t.combine_chunks().to_batches()
-        return b[0] if b else pa.RecordBatch.from_pylist([], schema=schema)
-
     def all_gather(self, eng, batch):
         """every rank's batch, in rank order (the order MergeExec concatenates partitions in)"""
         import torch
-        rb = eng.to_arrow(batch)
-        raw = self._ipc(rb)
+        raw = eng.to_wire(batch)
         size = torch.tensor([raw.size], dtype=torch.int64)
         sizes = [torch.empty_like(size) for _ in range(self.world)]
         self.dist.all_gather(sizes, size)
@@ -175,15 +166,14 @@ class GlooGroup:
         out = torch.empty(self.world * cap, dtype=torch.uint8)
         self.dist.all_gather_into_tensor(out, buf)
         host = out.numpy().reshape(self.world, cap)
-        return [batch if r == self.rank else eng.from_arrow(self._unipc(host[r, :sizes[r]].tobytes(), rb.schema)) for r in range(self.world)]
+        return [batch if r == self.rank else eng.from_wire(host[r, :sizes[r]], batch) for r in range(self.world)]
 
     def all_to_all(self, eng, parts):
         """parts[d] goes to rank d; returns what every rank holds for me, in source-rank order"""
         import torch
         if len(parts) != self.world:
             raise ValueError(f"need one outgoing batch per rank ({self.world}), got {len(parts)}")
-        rbs = [eng.to_arrow(p) for p in parts]
-        payload = [self._ipc(rb) for rb in rbs]
+        payload = [eng.to_wire(p) for p in parts]
         sizes = torch.tensor([p.size for p in payload], dtype=torch.int64)
         all_sizes = [torch.empty_like(sizes) for _ in range(self.world)]
         self.dist.all_gather(all_sizes, sizes)
@@ -199,8 +189,7 @@ class GlooGroup:
         if ops:
             for req in self.dist.batch_isend_irecv(ops):
                 req.wait()
-        return [parts[s] if s == self.rank else eng.from_arrow(self._unipc(recv[s].numpy().tobytes(), rbs[0].schema))
-                for s in range(self.world)]
+        return [parts[s] if s == self.rank else eng.from_wire(recv[s].numpy(), parts[s]) for s in range(self.world)]
 
     def close(self):
         self.dist.destroy_process_group()
@@ -440,12 +429,15 @@ class Workload:
     def result_check(self, result):
         if not result:
             return {}
-        d = result[0].to_pydict() if result[0].num_rows <= 64 else None
         n_rows = sum(b.num_rows for b in result)
         out = {"result_rows": n_rows}
-        if d is not None and "count_order" in d:
+        head = result[0]
+        if head.num_rows > 64:
+            head = self.eng.run(self.eng.P.GlobalLimitExec(self.eng.leaf(head), 8))
+        d = head.to_pydict()
+        if "count_order" in d:
             out["groups"] = len(d["count_order"])
             out["rows_counted"] = int(sum(d["count_order"]))
-        elif d is not None and "revenue" in d:
+        elif "revenue" in d:
             out["revenue"] = d["revenue"][:8]
         return out

@@ -390,6 +390,10 @@ class RecordBatch:
     def schema(self):
         return [(self.column_info(i)[0], self.column_info(i)[1]) for i in range(self.num_columns)]
 
+    def schema3(self):
+        """[(name, dtype, nullable)]"""
+        return [self.column_info(i)[:3] for i in range(self.num_columns)]
+
     def column_device(self, i):
         d, o, v = C.c_void_p(), C.c_void_p(), C.c_void_p()
         L.check(L.lib().bhip_batch_column_device(self._h, i, C.byref(d), C.byref(o), C.byref(v)))
@@ -783,6 +787,78 @@ class LocalLimitExec(ExecutionPlan):
         L.check(L.lib().bhip_plan_local_limit(input._h, limit, C.byref(h)))
         super().__init__(h, input.ctx, [input])
         self.input, self.limit = input, limit
+
+
+class Communicator:
+    """bhip_comm: the library's own RCCL communicator (one per process and GPU).  All calls are collective."""
+    UNIQUE_ID_BYTES = 128
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(Communicator.UNIQUE_ID_BYTES)
+        L.check(L.lib().bhip_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, ctx: Context, unique_id: bytes, world: int, rank: int):
+        if len(unique_id) != self.UNIQUE_ID_BYTES:
+            raise ValueError("unique id must be 128 bytes")
+        h = C.c_void_p()
+        L.check(L.lib().bhip_comm_create(ctx._h, unique_id, world, rank, C.byref(h)))
+        self._h, self.ctx, self.world, self.rank = h, ctx, world, rank
+
+    def all_gather(self, batch: "RecordBatch") -> List["RecordBatch"]:
+        out = (C.c_void_p * self.world)()
+        L.check(L.lib().bhip_comm_all_gather(self._h, batch._h, out))
+        return [RecordBatch(C.c_void_p(out[i]), self.ctx) for i in range(self.world)]
+
+    def all_to_all(self, parts: Sequence["RecordBatch"]) -> List["RecordBatch"]:
+        if len(parts) != self.world:
+            raise ValueError(f"need one outgoing batch per rank ({self.world}), got {len(parts)}")
+        arr = (C.c_void_p * self.world)(*[p._h for p in parts])
+        out = (C.c_void_p * self.world)()
+        L.check(L.lib().bhip_comm_all_to_all(self._h, arr, out))
+        return [RecordBatch(C.c_void_p(out[i]), self.ctx) for i in range(self.world)]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.lib().bhip_comm_release(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def pack_batch(batch: "RecordBatch"):
+    """bhip_batch_pack -> (header int64[], block uint8[]): the block form the exchange moves (host copies)"""
+    n_words = 2 + 3 * batch.num_columns
+    header = np.zeros(n_words, np.int64)
+    nbytes = C.c_int64()
+    hp = header.ctypes.data_as(C.POINTER(C.c_int64))
+    L.check(L.lib().bhip_batch_pack(batch._h, hp, n_words, None, 0, C.byref(nbytes)))
+    block = np.zeros(max(1, nbytes.value), np.uint8)
+    L.check(L.lib().bhip_batch_pack(batch._h, hp, n_words, block.ctypes.data, block.size, C.byref(nbytes)))
+    return header, block[:nbytes.value]
+
+
+def unpack_batch(ctx: Context, schema, header, block) -> "RecordBatch":
+    """bhip_batch_unpack: schema = [(name, dtype, nullable)]"""
+    descs, keep = [], []
+    for name, dtype, nullable in schema:
+        d = L.ColumnDesc()
+        nb = name.encode()
+        keep.append(nb)
+        d.name, d.dtype, d.nullable = nb, DTYPE_ID[dtype], 1 if nullable else 0
+        descs.append(d)
+    arr = (L.ColumnDesc * max(1, len(descs)))(*descs)
+    header = np.ascontiguousarray(header, np.int64)
+    block = np.ascontiguousarray(block, np.uint8)
+    h = C.c_void_p()
+    L.check(L.lib().bhip_batch_unpack(ctx._h, len(descs), arr, header.ctypes.data_as(C.POINTER(C.c_int64)),
+                                      block.ctypes.data if block.size else None, C.byref(h)))
+    return RecordBatch(h, ctx)
 
 
 # ---- batch-level helpers used by the multi-GPU exchange ---------------------------------------------------

@@ -349,6 +349,32 @@ bhip_status bhip_batch_hash_partition(bhip_batch* batch, int32_t n_exprs, const 
                                       bhip_batch** out /* n handles */);
 bhip_status bhip_batch_concat(bhip_ctx* ctx, int32_t n, bhip_batch* const* batches, bhip_batch** out);
 
+/* ---- exchange between the GPUs of one node (RCCL over xGMI, inside the library) -----------------------------
+ * What a stage boundary is in the reference — partitions written as IPC files (rust/core/src/utils.rs:49-84) and pulled by
+ * ShuffleReaderExec over Flight (rust/core/src/execution_plans/shuffle_reader.rs:77-99) — between processes that each
+ * own one GPU of the node: batches move device to device.  One communicator per process and GPU; the 128-byte id made
+ * by rank 0 (bhip_comm_unique_id) reaches the other ranks by whatever channel they share.  Collective calls: every rank
+ * of the communicator must make the same call, with batches of ONE schema.  librccl is loaded at the first call. */
+#define BHIP_COMM_ID_BYTES 128
+typedef struct bhip_comm bhip_comm;
+bhip_status bhip_comm_unique_id(uint8_t* id /* BHIP_COMM_ID_BYTES */);
+bhip_status bhip_comm_create(bhip_ctx* ctx, const uint8_t* id, int32_t world, int32_t rank, bhip_comm** out);
+void bhip_comm_release(bhip_comm* comm);
+/* the MergeExec side of a stage boundary: out[r] = rank r's batch, r = 0 .. world-1 (out[rank] is `mine`); the caller
+ * releases every handle.  Small batches (partial aggregate states) travel in ONE ncclAllGather. */
+bhip_status bhip_comm_all_gather(bhip_comm* comm, bhip_batch* mine, bhip_batch** out /* world handles */);
+/* the shuffle of RepartitionExec(Hash(keys), world): parts[d] (bhip_batch_hash_partition) goes to rank d;
+ * out[s] = what rank s held for this rank.  One grouped ncclSend / ncclRecv per peer pair. */
+bhip_status bhip_comm_all_to_all(bhip_comm* comm, bhip_batch* const* parts /* world */, bhip_batch** out /* world handles */);
+/* The block form the exchange moves, for transports other than RCCL: header = 2 + 3 * columns int64 words (rows, block
+ * bytes, then per column: data bytes, has offsets, has validity); the block holds every buffer, 64-byte aligned.
+ * host_block NULL: only the header and *block_bytes are produced.  bhip_batch_unpack is the inverse (one copy to the
+ * device; the columns are slices of it). */
+bhip_status bhip_batch_pack(bhip_batch* batch, int64_t* header, int32_t header_cap, void* host_block, int64_t block_cap,
+                            int64_t* block_bytes);
+bhip_status bhip_batch_unpack(bhip_ctx* ctx, int32_t n_cols, const bhip_column_desc* schema, const int64_t* header,
+                              const void* host_block, bhip_batch** out);
+
 /* ---- synthetic TPC-H data (bench / tests) -------------------------------------------------- */
 /* lineitem rows [row0,row0+n) at scale factor `sf` generated on the device; key64: Int64 order keys
  * (SF1000).  Columns: l_orderkey l_suppkey l_quantity l_extendedprice l_discount l_tax

@@ -223,3 +223,55 @@ def q6_partial_port(a, n_partitions, n_threads):
         ctypes.c_int32(n_partitions), ctypes.c_int32(n_threads),
         _p(s, ctypes.c_double), _p(c, ctypes.c_uint64))
     return s, c
+
+
+class JoinQueryPort:
+    """bench.py's cpu_baseline for Q3 / Q5: lineitem rows [0, sample_rows) with the matching prefix of orders (the generator
+    gives every 7 orders 28 lines) and the whole small tables (`dims` = ballista_amd.tpch.dimension_arrays(sf)), through
+    oracle_ops.c::oracle_q3_join_port / oracle_q5_join_port.  Everything, both hash-join builds included, runs inside run()."""
+
+    SEGMENTS = ["AUTOMOBILE", "BUILDING", "FURNITURE", "MACHINERY", "HOUSEHOLD"]
+
+    def __init__(self, query, sf, sample_rows, dims, key64=False):
+        self.query, self.key64 = query, key64
+        n_ord = min(cardinalities(sf)["orders"], (sample_rows + 27) // 28 * 7 + 7)
+        self.li = lineitem_arrays(sf, 0, sample_rows, key64=key64)
+        self.od = orders_arrays(sf, 0, n_ord, key64=key64)
+        c = dims["customer"]
+        self.c_custkey, self.c_nationkey = np.ascontiguousarray(c["c_custkey"]), np.ascontiguousarray(c["c_nationkey"])
+        seg = [s.encode() for s in self.SEGMENTS]
+        lens = np.array([len(s) for s in seg], np.int32)[c["c_mktsegment"]]
+        self.seg_off = np.zeros(len(lens) + 1, np.int32)
+        np.cumsum(lens, out=self.seg_off[1:])
+        table = np.frombuffer(b"".join(s.ljust(10) for s in seg), np.uint8).reshape(5, 10)
+        mask = np.arange(10)[None, :] < lens[:, None]
+        self.seg_data = np.ascontiguousarray(table[c["c_mktsegment"]][mask])
+        s = dims["supplier"]
+        self.s_suppkey, self.s_nationkey = np.ascontiguousarray(s["s_suppkey"]), np.ascontiguousarray(s["s_nationkey"])
+        self.nation_region = np.array([r for _, r in NATIONS], np.int32)
+
+    def run(self, n_partitions, n_threads):
+        L = lib()
+        kt = ctypes.c_void_p
+        li, od = self.li, self.od
+        if self.query == "q3":
+            L.oracle_q3_join_port.restype = ctypes.c_int64
+            total = ctypes.c_double()
+            n = L.oracle_q3_join_port(
+                _p(self.c_custkey, ctypes.c_int32), _p(self.seg_off, ctypes.c_int32), _p(self.seg_data, ctypes.c_uint8), ctypes.c_int64(len(self.c_custkey)),
+                kt(od["o_orderkey"].ctypes.data), _p(od["o_custkey"], ctypes.c_int32), _p(od["o_orderdate"], ctypes.c_int32),
+                _p(od["o_shippriority"], ctypes.c_int32), ctypes.c_int64(len(od["o_custkey"])),
+                kt(li["l_orderkey"].ctypes.data), _p(li["l_extendedprice"], ctypes.c_double), _p(li["l_discount"], ctypes.c_double),
+                _p(li["l_shipdate"], ctypes.c_int32), ctypes.c_int64(len(li["l_shipdate"])), ctypes.c_int32(1 if self.key64 else 0),
+                ctypes.c_int32(9204), ctypes.c_int32(n_partitions), ctypes.c_int32(n_threads), ctypes.byref(total))
+            return n, total.value
+        rev = np.zeros(25, np.float64)
+        L.oracle_q5_join_port(
+            _p(self.nation_region, ctypes.c_int32), ctypes.c_int32(2),
+            _p(self.c_custkey, ctypes.c_int32), _p(self.c_nationkey, ctypes.c_int32), ctypes.c_int64(len(self.c_custkey)),
+            _p(self.s_suppkey, ctypes.c_int32), _p(self.s_nationkey, ctypes.c_int32), ctypes.c_int64(len(self.s_suppkey)),
+            kt(od["o_orderkey"].ctypes.data), _p(od["o_custkey"], ctypes.c_int32), _p(od["o_orderdate"], ctypes.c_int32), ctypes.c_int64(len(od["o_custkey"])),
+            kt(li["l_orderkey"].ctypes.data), _p(li["l_suppkey"], ctypes.c_int32), _p(li["l_extendedprice"], ctypes.c_double),
+            _p(li["l_discount"], ctypes.c_double), ctypes.c_int64(len(li["l_suppkey"])), ctypes.c_int32(1 if self.key64 else 0),
+            ctypes.c_int32(8766), ctypes.c_int32(9131), ctypes.c_int32(n_partitions), ctypes.c_int32(n_threads), _p(rev, ctypes.c_double))
+        return rev

@@ -220,3 +220,260 @@ void oracle_q6_partial(const double *l_quantity, const double *l_extendedprice,
         free(a); free(b); free(price); free(disc); free(prod);
     }
 }
+
+/* ---- TPC-H Q3 / Q5 in DataFusion's structure (bench.py cpu_baseline, kind "port") --------------------
+ * rust/benchmarks/tpch/queries/q3.sql, q5.sql.  Collect-left hash joins (from_proto.rs:253-276): the build side
+ * is drained into one hash map (key -> row), every probe partition (one per thread at a time) walks its rows in
+ * 32768-row batches: predicate array, filter copy of the projected columns, probe, gather of both sides, then the
+ * partial aggregate by hash map; the partial states are merged at the end (Final).  Unique build keys (every
+ * TPC-H join here), so the maps hold one row per key. */
+typedef struct { int64_t *key; int32_t *row; uint64_t mask; } imap;
+
+static uint64_t mix64u(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static void imap_init(imap *m, int64_t n) {
+    uint64_t cap = 1024;
+    while (cap < 2ull * (uint64_t)n) cap <<= 1;
+    m->mask = cap - 1;
+    m->key = (int64_t *)malloc(sizeof(int64_t) * cap);
+    m->row = (int32_t *)malloc(sizeof(int32_t) * cap);
+    for (uint64_t i = 0; i < cap; i++) m->row[i] = -1;
+}
+static void imap_free(imap *m) { free(m->key); free(m->row); }
+static void imap_put(imap *m, int64_t k, int32_t row) {
+    uint64_t s = mix64u((uint64_t)k) & m->mask;
+    while (m->row[s] >= 0 && m->key[s] != k) s = (s + 1) & m->mask;
+    m->key[s] = k; m->row[s] = row;
+}
+static int32_t imap_get(const imap *m, int64_t k) {
+    uint64_t s = mix64u((uint64_t)k) & m->mask;
+    while (m->row[s] >= 0) { if (m->key[s] == k) return m->row[s]; s = (s + 1) & m->mask; }
+    return -1;
+}
+static int64_t key_at(const void *keys, int32_t key64, int64_t i) {
+    return key64 ? ((const int64_t *)keys)[i] : (int64_t)((const int32_t *)keys)[i];
+}
+
+/* Q3: customer(BUILDING) |x| orders(< cutoff) |x| lineitem(> cutoff), GROUP BY l_orderkey, o_orderdate, o_shippriority.
+ * Returns the number of groups; *revenue_total = sum of the group sums (a checksum for the caller). */
+int64_t oracle_q3_join_port(const int32_t *c_custkey, const int32_t *seg_off, const uint8_t *seg_data, int64_t n_cust,
+                            const void *o_orderkey, const int32_t *o_custkey, const int32_t *o_orderdate,
+                            const int32_t *o_shippriority, int64_t n_ord,
+                            const void *l_orderkey, const double *l_extendedprice, const double *l_discount,
+                            const int32_t *l_shipdate, int64_t n_li, int32_t key64, int32_t cutoff,
+                            int32_t n_partitions, int32_t n_threads, double *revenue_total)
+{
+    /* build 1: FilterExec(c_mktsegment = 'BUILDING') -> projection c_custkey */
+    imap cust;
+    int64_t n_b = 0;
+    for (int64_t i = 0; i < n_cust; i++)
+        n_b += (seg_off[i + 1] - seg_off[i] == 8 && memcmp(seg_data + seg_off[i], "BUILDING", 8) == 0);
+    imap_init(&cust, n_b);
+    for (int64_t i = 0; i < n_cust; i++)
+        if (seg_off[i + 1] - seg_off[i] == 8 && memcmp(seg_data + seg_off[i], "BUILDING", 8) == 0) imap_put(&cust, c_custkey[i], (int32_t)i);
+    /* probe 1 (orders partitions) -> j1 rows (o_orderkey, o_orderdate, o_shippriority), per partition, then concatenated */
+    int64_t per = (n_ord + n_partitions - 1) / n_partitions;
+    int64_t **j1_key = (int64_t **)calloc((size_t)n_partitions, sizeof(void *));
+    int32_t **j1_date = (int32_t **)calloc((size_t)n_partitions, sizeof(void *));
+    int32_t **j1_prio = (int32_t **)calloc((size_t)n_partitions, sizeof(void *));
+    int64_t *j1_n = (int64_t *)calloc((size_t)n_partitions, sizeof(int64_t));
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
+    for (int32_t p = 0; p < n_partitions; p++) {
+        int64_t r0 = per * p, r1 = r0 + per < n_ord ? r0 + per : n_ord;
+        if (r1 <= r0) continue;
+        int64_t cap = r1 - r0, m = 0;
+        int64_t *k = (int64_t *)malloc(sizeof(int64_t) * (size_t)cap);
+        int32_t *d = (int32_t *)malloc(sizeof(int32_t) * (size_t)cap), *s = (int32_t *)malloc(sizeof(int32_t) * (size_t)cap);
+        uint8_t pred[BATCH];
+        int64_t fk[BATCH]; int32_t fc[BATCH], fd[BATCH], fs[BATCH];
+        for (int64_t b0 = r0; b0 < r1; b0 += BATCH) {
+            int32_t bn = (int32_t)(b0 + BATCH < r1 ? BATCH : r1 - b0), fm = 0;
+            for (int32_t i = 0; i < bn; i++) pred[i] = o_orderdate[b0 + i] < cutoff;
+            for (int32_t i = 0; i < bn; i++) {                          /* filter copies every column */
+                if (!pred[i]) continue;
+                fk[fm] = key_at(o_orderkey, key64, b0 + i); fc[fm] = o_custkey[b0 + i]; fd[fm] = o_orderdate[b0 + i]; fs[fm] = o_shippriority[b0 + i]; fm++;
+            }
+            for (int32_t i = 0; i < fm; i++)
+                if (imap_get(&cust, fc[i]) >= 0) { k[m] = fk[i]; d[m] = fd[i]; s[m] = fs[i]; m++; }
+        }
+        j1_key[p] = k; j1_date[p] = d; j1_prio[p] = s; j1_n[p] = m;
+    }
+    imap_free(&cust);
+    int64_t n_j1 = 0;
+    for (int32_t p = 0; p < n_partitions; p++) n_j1 += j1_n[p];
+    int64_t *bk = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n_j1 + 1));
+    int32_t *bd = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_j1 + 1)), *bp = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_j1 + 1));
+    int64_t at = 0;
+    for (int32_t p = 0; p < n_partitions; p++) {
+        if (!j1_n[p]) { free(j1_key[p]); free(j1_date[p]); free(j1_prio[p]); continue; }
+        memcpy(bk + at, j1_key[p], sizeof(int64_t) * (size_t)j1_n[p]);
+        memcpy(bd + at, j1_date[p], sizeof(int32_t) * (size_t)j1_n[p]);
+        memcpy(bp + at, j1_prio[p], sizeof(int32_t) * (size_t)j1_n[p]);
+        at += j1_n[p];
+        free(j1_key[p]); free(j1_date[p]); free(j1_prio[p]);
+    }
+    free(j1_key); free(j1_date); free(j1_prio); free(j1_n);
+    /* build 2 */
+    imap ords;
+    imap_init(&ords, n_j1);
+    for (int64_t i = 0; i < n_j1; i++) imap_put(&ords, bk[i], (int32_t)i);
+    /* probe 2 + partial aggregate per lineitem partition: the group is the build row (unique order key) */
+    double *gsum = (double *)calloc((size_t)(n_j1 + 1), sizeof(double));
+    uint8_t *ghas = (uint8_t *)calloc((size_t)(n_j1 + 1), 1);
+    per = (n_li + n_partitions - 1) / n_partitions;
+    double **psum = (double **)calloc((size_t)n_partitions, sizeof(void *));
+    int32_t **prow = (int32_t **)calloc((size_t)n_partitions, sizeof(void *));
+    int64_t *pn = (int64_t *)calloc((size_t)n_partitions, sizeof(int64_t));
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
+    for (int32_t p = 0; p < n_partitions; p++) {
+        int64_t r0 = per * p, r1 = r0 + per < n_li ? r0 + per : n_li;
+        if (r1 <= r0) continue;
+        /* partial state of this partition: hash map build row -> slot */
+        imap part;
+        imap_init(&part, (r1 - r0) / 2 + 16);
+        int64_t cap = (r1 - r0) / 2 + 16, ng = 0;
+        double *sum = (double *)malloc(sizeof(double) * (size_t)cap);
+        int32_t *row = (int32_t *)malloc(sizeof(int32_t) * (size_t)cap);
+        uint8_t pred[BATCH];
+        int64_t fk[BATCH]; double fp[BATCH], fdisc[BATCH], one_minus[BATCH], rev[BATCH];
+        int32_t hit[BATCH];
+        for (int64_t b0 = r0; b0 < r1; b0 += BATCH) {
+            int32_t bn = (int32_t)(b0 + BATCH < r1 ? BATCH : r1 - b0), fm = 0, hm = 0;
+            for (int32_t i = 0; i < bn; i++) pred[i] = l_shipdate[b0 + i] > cutoff;
+            for (int32_t i = 0; i < bn; i++) {
+                if (!pred[i]) continue;
+                fk[fm] = key_at(l_orderkey, key64, b0 + i); fp[fm] = l_extendedprice[b0 + i]; fdisc[fm] = l_discount[b0 + i]; fm++;
+            }
+            for (int32_t i = 0; i < fm; i++) {                          /* probe + gather of the matching rows */
+                int32_t r = imap_get(&ords, fk[i]);
+                if (r < 0) continue;
+                hit[hm] = r; fp[hm] = fp[i]; fdisc[hm] = fdisc[i]; hm++;
+            }
+            for (int32_t i = 0; i < hm; i++) one_minus[i] = 1.0 - fdisc[i];
+            for (int32_t i = 0; i < hm; i++) rev[i] = fp[i] * one_minus[i];
+            for (int32_t i = 0; i < hm; i++) {
+                int32_t s = imap_get(&part, hit[i]);
+                if (s < 0) {
+                    if (ng == cap) { cap *= 2; sum = (double *)realloc(sum, sizeof(double) * (size_t)cap); row = (int32_t *)realloc(row, sizeof(int32_t) * (size_t)cap); }
+                    s = (int32_t)ng++; imap_put(&part, hit[i], s); sum[s] = rev[i]; row[s] = hit[i];
+                } else sum[s] = sum[s] + rev[i];
+            }
+        }
+        imap_free(&part);
+        psum[p] = sum; prow[p] = row; pn[p] = ng;
+    }
+    /* Final: merge the partial states in partition order */
+    int64_t n_groups = 0;
+    double total = 0.0;
+    for (int32_t p = 0; p < n_partitions; p++) {
+        for (int64_t i = 0; i < pn[p]; i++) {
+            int32_t r = prow[p][i];
+            if (!ghas[r]) { ghas[r] = 1; gsum[r] = psum[p][i]; n_groups++; } else gsum[r] = gsum[r] + psum[p][i];
+        }
+        free(psum[p]); free(prow[p]);
+    }
+    for (int64_t i = 0; i < n_j1; i++) if (ghas[i]) total += gsum[i];
+    free(psum); free(prow); free(pn); free(gsum); free(ghas); free(bk); free(bd); free(bp);
+    imap_free(&ords);
+    if (revenue_total) *revenue_total = total;
+    return n_groups;
+}
+
+/* Q5: region(ASIA=2) |x| nation |x| customer |x| orders(in [d0,d1)) |x| lineitem |x| supplier(on suppkey, nationkey),
+ * GROUP BY nation.  nation_region[25]; revenue[25] out (0 for nations outside the region). */
+void oracle_q5_join_port(const int32_t *nation_region, int32_t region,
+                         const int32_t *c_custkey, const int32_t *c_nationkey, int64_t n_cust,
+                         const int32_t *s_suppkey, const int32_t *s_nationkey, int64_t n_supp,
+                         const void *o_orderkey, const int32_t *o_custkey, const int32_t *o_orderdate, int64_t n_ord,
+                         const void *l_orderkey, const int32_t *l_suppkey, const double *l_extendedprice, const double *l_discount,
+                         int64_t n_li, int32_t key64, int32_t d0, int32_t d1, int32_t n_partitions, int32_t n_threads, double *revenue)
+{
+    /* nation |x| region, then customer probe (build = the region's nations) */
+    imap cust;
+    int64_t n_c = 0;
+    for (int64_t i = 0; i < n_cust; i++) n_c += nation_region[c_nationkey[i]] == region;
+    imap_init(&cust, n_c);
+    for (int64_t i = 0; i < n_cust; i++)
+        if (nation_region[c_nationkey[i]] == region) imap_put(&cust, c_custkey[i], c_nationkey[i]);     /* value = nation */
+    imap supp;
+    imap_init(&supp, n_supp);
+    for (int64_t i = 0; i < n_supp; i++) imap_put(&supp, s_suppkey[i], s_nationkey[i]);
+    /* orders probe -> (o_orderkey, nation) */
+    int64_t per = (n_ord + n_partitions - 1) / n_partitions;
+    int64_t **ok = (int64_t **)calloc((size_t)n_partitions, sizeof(void *));
+    int32_t **on = (int32_t **)calloc((size_t)n_partitions, sizeof(void *));
+    int64_t *cnt = (int64_t *)calloc((size_t)n_partitions, sizeof(int64_t));
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
+    for (int32_t p = 0; p < n_partitions; p++) {
+        int64_t r0 = per * p, r1 = r0 + per < n_ord ? r0 + per : n_ord, m = 0;
+        if (r1 <= r0) continue;
+        int64_t *k = (int64_t *)malloc(sizeof(int64_t) * (size_t)(r1 - r0));
+        int32_t *nn = (int32_t *)malloc(sizeof(int32_t) * (size_t)(r1 - r0));
+        uint8_t a[BATCH], b[BATCH];
+        int64_t fk[BATCH]; int32_t fc[BATCH];
+        for (int64_t b0 = r0; b0 < r1; b0 += BATCH) {
+            int32_t bn = (int32_t)(b0 + BATCH < r1 ? BATCH : r1 - b0), fm = 0;
+            for (int32_t i = 0; i < bn; i++) a[i] = o_orderdate[b0 + i] >= d0;
+            for (int32_t i = 0; i < bn; i++) b[i] = o_orderdate[b0 + i] < d1;
+            for (int32_t i = 0; i < bn; i++) a[i] = a[i] & b[i];
+            for (int32_t i = 0; i < bn; i++) { if (!a[i]) continue; fk[fm] = key_at(o_orderkey, key64, b0 + i); fc[fm] = o_custkey[b0 + i]; fm++; }
+            for (int32_t i = 0; i < fm; i++) { int32_t nat = imap_get(&cust, fc[i]); if (nat >= 0) { k[m] = fk[i]; nn[m] = nat; m++; } }
+        }
+        ok[p] = k; on[p] = nn; cnt[p] = m;
+    }
+    int64_t n_co = 0;
+    for (int32_t p = 0; p < n_partitions; p++) n_co += cnt[p];
+    imap ords;
+    imap_init(&ords, n_co);
+    for (int32_t p = 0; p < n_partitions; p++) {
+        for (int64_t i = 0; i < cnt[p]; i++) imap_put(&ords, ok[p][i], on[p][i]);
+        free(ok[p]); free(on[p]);
+    }
+    free(ok); free(on); free(cnt);
+    imap_free(&cust);
+    /* lineitem probe, supplier probe on (suppkey, nation), partial aggregate by nation */
+    per = (n_li + n_partitions - 1) / n_partitions;
+    double *part = (double *)calloc((size_t)n_partitions * 25, sizeof(double));
+    uint8_t *phas = (uint8_t *)calloc((size_t)n_partitions * 25, 1);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
+    for (int32_t p = 0; p < n_partitions; p++) {
+        int64_t r0 = per * p, r1 = r0 + per < n_li ? r0 + per : n_li;
+        double fp[BATCH], fdisc[BATCH], one_minus[BATCH], rev[BATCH];
+        int32_t fs[BATCH], fnat[BATCH];
+        for (int64_t b0 = r0; b0 < r1; b0 += BATCH) {
+            int32_t bn = (int32_t)(b0 + BATCH < r1 ? BATCH : r1 - b0), hm = 0, sm = 0;
+            for (int32_t i = 0; i < bn; i++) {
+                int32_t nat = imap_get(&ords, key_at(l_orderkey, key64, b0 + i));
+                if (nat < 0) continue;
+                fnat[hm] = nat; fs[hm] = l_suppkey[b0 + i]; fp[hm] = l_extendedprice[b0 + i]; fdisc[hm] = l_discount[b0 + i]; hm++;
+            }
+            for (int32_t i = 0; i < hm; i++) {
+                if (imap_get(&supp, fs[i]) != fnat[i]) continue;
+                fnat[sm] = fnat[i]; fp[sm] = fp[i]; fdisc[sm] = fdisc[i]; sm++;
+            }
+            for (int32_t i = 0; i < sm; i++) one_minus[i] = 1.0 - fdisc[i];
+            for (int32_t i = 0; i < sm; i++) rev[i] = fp[i] * one_minus[i];
+            double bs[25]; uint8_t bh[25];
+            memset(bh, 0, 25);
+            for (int32_t i = 0; i < sm; i++) { int g = fnat[i]; if (!bh[g]) { bh[g] = 1; bs[g] = rev[i]; } else bs[g] = bs[g] + rev[i]; }
+            for (int g = 0; g < 25; g++) {
+                if (!bh[g]) continue;
+                if (!phas[p * 25 + g]) { phas[p * 25 + g] = 1; part[p * 25 + g] = bs[g]; } else part[p * 25 + g] = part[p * 25 + g] + bs[g];
+            }
+        }
+    }
+    for (int g = 0; g < 25; g++) {
+        revenue[g] = 0.0;
+        int has = 0;
+        for (int32_t p = 0; p < n_partitions; p++) {
+            if (!phas[p * 25 + g]) continue;
+            revenue[g] = has ? revenue[g] + part[p * 25 + g] : part[p * 25 + g];
+            has = 1;
+        }
+    }
+    free(part); free(phas);
+    imap_free(&ords); imap_free(&supp);
+}

@@ -1,12 +1,13 @@
-"""N > 1 path of bench.py on CPU: two gloo ranks, each owning one shard of the seeded lineitem table,
-exchange their partial-state batches with ballista_amd.exchange.all_gather_batches (the same call the
-RCCL run makes) and merge them.  The scan / aggregate arithmetic here is the ORACLE's (no GPU in this
-tier) — what is under test is the product's exchange: framing, rank order, schema fidelity, and that
-merge(partials of shards) == aggregate(whole table), the property the weak-scaling bench relies on
-(reference: stage 1 Partial -> MergeExec -> Final, rust/scheduler/src/planner.rs:136-171)."""
+"""The N > 1 flows of ballista_amd/distributed.py on CPU: two gloo ranks, each owning one row block of the seeded tables, run
+EXACTLY the functions `bench.py --gpus N` runs (q1_distributed / q3_distributed / q5_distributed over GlooGroup) with the ORACLE
+as the engine — there is no GPU in this tier.  Under test: row-block sharding, hash routing, source-rank order, the
+shuffle-vs-broadcast variants, framing of the batches on the wire, and the property the strong-scaling bench relies on:
+    answer(2 ranks) == answer(1 rank)      (reference: stage 1 Partial -> exchange -> Final, rust/scheduler/src/planner.rs:136-171;
+                                            RepartitionExec(Hash), rust/core/src/serde/physical_plan/from_proto.rs:133-147)."""
 import os
 import socket
 import sys
+from collections import OrderedDict
 
 import numpy as np
 import pytest
@@ -21,173 +22,252 @@ def _free_port():
         return s.getsockname()[1]
 
 
-_PA = {"Int32": "int32", "Int64": "int64", "UInt64": "uint64", "Float64": "float64", "Utf8": "string", "Date32": "date32",
+_PA = {"Int32": "int32", "Int64": "int64", "UInt64": "uint64", "UInt8": "uint8", "Float64": "float64", "Utf8": "string", "Date32": "date32",
        "Boolean": "bool_"}
 
 
-def _to_arrow(batch):
+def to_arrow(batch):
     import pyarrow as pa
     arrays, names = [], []
     for name, c in batch.items():
         vals = c.to_pylist()
         if c.dtype == "Date32":
-            arrays.append(pa.array(np.asarray([0 if v is None else v for v in vals], dtype=np.int32), type=pa.int32()).cast(pa.date32()))
+            arrays.append(pa.array([None if v is None else int(v) for v in vals], type=pa.int32()).cast(pa.date32()))
         else:
             arrays.append(pa.array(vals, type=getattr(pa, _PA[c.dtype])()))
         names.append(name)
     return pa.RecordBatch.from_arrays(arrays, names=names)
 
 
-def _from_arrow(rb):
-    from collections import OrderedDict
-    from oracle.engine import OCol
-    inv = {"int32": "Int32", "int64": "Int64", "uint64": "UInt64", "double": "Float64", "string": "Utf8", "bool": "Boolean"}
-    out = OrderedDict()
+def from_arrow(rb):
     import pyarrow as pa
+    from oracle.engine import OCol
+    inv = {"int32": "Int32", "int64": "Int64", "uint64": "UInt64", "uint8": "UInt8", "double": "Float64", "string": "Utf8", "bool": "Boolean"}
+    out = OrderedDict()
     for name, col in zip(rb.schema.names, rb.columns):
         if pa.types.is_date32(col.type):
-            out[name] = OCol("Date32", np.asarray(col.cast(pa.int32()).to_pylist(), dtype=np.int32))
-            continue
-        vals = col.to_pylist()
-        dt = inv[str(col.type)]
+            vals = col.cast(pa.int32()).to_pylist()
+            dt = "Date32"
+        else:
+            vals = col.to_pylist()
+            dt = inv[str(col.type)]
         valid = None if col.null_count == 0 else np.array([v is not None for v in vals])
         if dt == "Utf8":
             out[name] = OCol(dt, ["" if v is None else v for v in vals], valid)
         else:
-            out[name] = OCol(dt, np.array([0 if v is None else v for v in vals]), valid)
+            np_t = {"Int32": np.int32, "Date32": np.int32, "Int64": np.int64, "UInt64": np.uint64, "UInt8": np.uint8, "Float64": np.float64,
+                    "Boolean": np.bool_}[dt]
+            out[name] = OCol(dt, np.array([0 if v is None else v for v in vals], np_t), valid)
     return out
 
 
-def _rank_main(rank, world, port, query, q):
-    sys.path.insert(0, ROOT)
+class OracleEngine:
+    """the Engine interface of ballista_amd/distributed.py over oracle/ (plans are tests/plan_nodes.py trees)"""
+
+    def leaf(self, partitions):
+        import plan_nodes as N
+        if not isinstance(partitions, (list, tuple)):
+            partitions = [partitions]
+        return N.MemoryExec([[b] for b in partitions])
+
+    def run(self, plan):
+        from oracle import plan_eval, engine as og
+        from oracle.engine import OCol
+        got = plan_eval.collect(plan)
+        if got:
+            return got
+        out = OrderedDict()                       # no batch at all: an empty one with the plan's schema
+        for name, dtype, _ in plan.schema():
+            out[name] = OCol(dtype, [] if dtype == "Utf8" else np.zeros(0, {"Float64": np.float64, "Int64": np.int64, "UInt64": np.uint64}.get(dtype, np.int32)))
+        return out
+
+    def hash_partition(self, batch, key, n):
+        from oracle import engine as og
+        from ballista_amd.expr import col
+        return og.repartition_hash(batch, [col(key)], n)
+
+    def concat(self, batches):
+        from oracle import engine as og
+        live = [b for b in batches if og.batch_len(b)]
+        return og.concat_batches(live) if live else batches[0]
+
+    def num_rows(self, batch):
+        from oracle import engine as og
+        return og.batch_len(batch)
+
+    def nbytes(self, batch):
+        return 0
+
+    def to_wire(self, batch):
+        """Arrow IPC stream bytes of the batch"""
+        import pyarrow as pa
+        rb = to_arrow(batch)
+        sink = pa.BufferOutputStream()
+        with pa.ipc.new_stream(sink, rb.schema) as w:
+            w.write_batch(rb)
+        return np.frombuffer(sink.getvalue(), dtype=np.uint8)
+
+    def from_wire(self, raw, like):
+        import pyarrow as pa
+        t = pa.ipc.open_stream(pa.py_buffer(np.ascontiguousarray(raw).tobytes())).read_all()
+        b = t.combine_chunks().to_batches()
+        return from_arrow(b[0]) if b else OrderedDict((k, c.take(np.zeros(0, np.int64))) for k, c in like.items())
+
+
+def _tables(rank, world):
+    """replicated small tables, row blocks of orders / lineitem (the sharding of distributed.Workload._block)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    import torch.distributed as dist
-    from ballista_amd import expr as E, tpch
-    from ballista_amd.exchange import all_gather_batches
-    from oracle import engine as og, gen
     import helpers
-    try:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-        li = gen.lineitem(SF)
-        n = og.batch_len(li)
+    from oracle import gen, engine as og
+
+    def block(b):
+        n = og.batch_len(b)
         per = (n + world - 1) // world
-        shard = helpers.slice_batch(li, rank * per, min(n, (rank + 1) * per))
-        parts = tpch.q1_parts(tpch.LINEITEM_SCHEMA) if query == "q1" else tpch.q6_parts(tpch.LINEITEM_SCHEMA)
-        partial = og.hash_aggregate(og.filter_batch(shard, parts["predicate"]), "Partial", parts["group"], parts["aggs"])
-        gathered = all_gather_batches(dist, _to_arrow(partial), device="cpu")
-        assert len(gathered) == world
-        # rank order and payload fidelity: my own slot comes back bit-identical
-        assert gathered[rank].equals(_to_arrow(partial))
-        merged = og.concat_batches([_from_arrow(b) for b in gathered])
-        if query == "q1":
-            fin = og.hash_aggregate(merged, "Final", parts["group"], tpch.q1_final_aggs())
-            fin = og.sort_batch(fin, [E.PhysicalSortExpr(E.col("l_returnflag")), E.PhysicalSortExpr(E.col("l_linestatus"))])
-        else:
-            fin = og.hash_aggregate(merged, "Final", [], [E.AggregateExpr("SUM", E.col("revenue[sum]"), "revenue")])
-        # the same answer as one rank scanning the whole table
-        whole = og.hash_aggregate(og.filter_batch(li, parts["predicate"]), "Partial", parts["group"], parts["aggs"])
-        if query == "q1":
-            ref = og.hash_aggregate(whole, "Final", parts["group"], tpch.q1_final_aggs())
-            ref = og.sort_batch(ref, [E.PhysicalSortExpr(E.col("l_returnflag")), E.PhysicalSortExpr(E.col("l_linestatus"))])
-        else:
-            ref = og.hash_aggregate(whole, "Final", [], [E.AggregateExpr("SUM", E.col("revenue[sum]"), "revenue")])
-        helpers.assert_rows_equal(fin, ref, ordered=(query == "q1"), float_rtol=1e-9)
-        dist.barrier()
-        dist.destroy_process_group()
-        q.put((rank, "ok"))
-    except BaseException as e:          # noqa: BLE001 - reported to the parent
-        import traceback
-        q.put((rank, "".join(traceback.format_exception(type(e), e, e.__traceback__))))
+        lo = min(n, rank * per)
+        return helpers.slice_batch(b, lo, min(n, lo + per))
+
+    full = dict(lineitem=gen.lineitem(SF), orders=gen.orders(SF), customer=gen.customer(SF), supplier=gen.supplier(SF), nation=gen.nation(),
+                region=gen.region())
+    mine = dict(full)
+    mine["lineitem"], mine["orders"] = block(full["lineitem"]), block(full["orders"])
+    return full, mine
 
 
-@pytest.mark.parametrize("query", ["q1", "q6"])
-def test_two_rank_partial_state_exchange_gloo(query):
-    pytest.importorskip("pyarrow")
-    import torch.multiprocessing as mp
-    mpc = mp.get_context("spawn")
-    q = mpc.Queue()
-    port = _free_port()
-    procs = [mpc.Process(target=_rank_main, args=(r, 2, port, query, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    results = [q.get(timeout=240) for _ in procs]
-    for p in procs:
-        p.join(60)
-    for rank, msg in sorted(results):
-        assert msg == "ok", f"rank {rank}:\n{msg}"
-
-
-def _join_rank_main(rank, world, port, q):
-    """repartitioned join: both sides sharded by row block, exchanged by hash(join key) % world, joined locally"""
+def _rank_main(rank, world, port, query, join_exchange, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    import torch.distributed as dist
-    from ballista_amd import expr as E
-    from ballista_amd.exchange import all_to_all_batches
-    from oracle import engine as og, gen
-    import helpers
     try:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-        od, li = gen.orders(SF), helpers.slice_batch(gen.lineitem(SF), 0, 9000)
+        import plan_nodes as N
+        import helpers
+        from ballista_amd import tpch, distributed as D
+        tpch.P = N                                       # the plan builders over GPU-free plan descriptions
+        group = D.ProcessGroup.from_env("gloo")
+        assert (group.rank, group.world) == (rank, world)
+        eng = OracleEngine()
+        full, mine = _tables(rank, world)
+        L = lambda t, k: eng.leaf(t[k])
+        stats = D.ExchangeStats()
 
-        def shard(b):
-            n = og.batch_len(b)
-            per = (n + world - 1) // world
-            return helpers.slice_batch(b, rank * per, min(n, (rank + 1) * per))
+        def run(g, t):
+            stats_ = stats if g is group else None
+            if query in ("q1", "q6"):
+                return D.q1_distributed(eng, g, L(t, "lineitem"), query)
+            if query == "q3":
+                return D.q3_distributed(eng, g, L(t, "customer"), L(t, "orders"), L(t, "lineitem"), join_exchange, stats_)
+            return D.q5_distributed(eng, g, L(t, "customer"), L(t, "orders"), L(t, "lineitem"), L(t, "supplier"), L(t, "nation"), L(t, "region"),
+                                    join_exchange, stats_)
 
-        def exchange(b, key):
-            parts = og.repartition_hash(b, [E.col(key)], world)          # the row-hash spec of DESIGN.md §6
-            got = all_to_all_batches(dist, [_to_arrow(p) for p in parts], device="cpu")
-            assert len(got) == world
-            return og.concat_batches([_from_arrow(g) for g in got if g.num_rows] or [_from_arrow(got[0])])
-
-        mine_o, mine_l = exchange(shard(od), "o_orderkey"), exchange(shard(li), "l_orderkey")
-        # co-location: every key I hold hashes to me
-        for b, key in ((mine_o, "o_orderkey"), (mine_l, "l_orderkey")):
-            h = og.row_hash([b[key]], og.batch_len(b))
-            assert all(int(x) % world == rank for x in h)
-        local = og.hash_join(mine_o, mine_l, [("o_orderkey", "l_orderkey")], "Inner")
-        whole = og.hash_join(od, li, [("o_orderkey", "l_orderkey")], "Inner")
-        hw = og.row_hash([whole["o_orderkey"]], og.batch_len(whole))
-        keep = [i for i, x in enumerate(hw) if int(x) % world == rank]
-        want = helpers.slice_batch(whole, 0, 0) if not keep else type(whole)((k, c.take(np.array(keep))) for k, c in whole.items())
-        helpers.assert_rows_equal(local, want, ordered=False)
-        dist.barrier()
-        dist.destroy_process_group()
+        got = run(group, mine)
+        want = run(D.ProcessGroup.single(), full)        # the same flow on one rank over the whole tables
+        key = {"q1": ["l_returnflag", "l_linestatus"], "q6": None, "q3": ["l_orderkey"], "q5": ["n_name"]}[query]
+        helpers.assert_rows_equal(got, want, ordered=False, float_rtol=1e-9, key_cols=key)
+        assert eng.num_rows(got) > 0
+        if query in ("q3", "q5"):
+            assert stats.calls == (1 if join_exchange == "broadcast" else 2)
+            # ORDER BY survives the distribution (every rank sorts the gathered states itself)
+            rev = got["revenue"].to_pylist()
+            assert all(a >= b for a, b in zip(rev, rev[1:]))
+        group.barrier()
+        assert group.max_over_ranks(float(rank)) == float(world - 1)
+        group.close()
         q.put((rank, "ok"))
     except BaseException as e:          # noqa: BLE001 - reported to the parent
         import traceback
         q.put((rank, "".join(traceback.format_exception(type(e), e, e.__traceback__))))
 
 
-def test_two_rank_repartitioned_join_gloo():
-    pytest.importorskip("pyarrow")
+def _spawn(world, *args):
     import torch.multiprocessing as mp
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
     port = _free_port()
-    procs = [mpc.Process(target=_join_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    procs = [mpc.Process(target=_rank_main, args=(r, world, port) + args + (q,)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=240) for _ in procs]
+    results = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(60)
     for rank, msg in sorted(results):
         assert msg == "ok", f"rank {rank}:\n{msg}"
 
 
-def test_exchange_slot_roundtrip_and_overflow():
-    pa = pytest.importorskip("pyarrow")
-    from ballista_amd.exchange import pack_batch, unpack_batch, SLOT_BYTES
-    rb = pa.RecordBatch.from_arrays([pa.array(["A", "N", None]), pa.array([1.5, -0.0, 3.0]), pa.array([1, 2, 3], type=pa.uint64())],
-                                    names=["k", "s[sum]", "c[count]"])
-    slot = pack_batch(rb)
-    assert slot.dtype == np.uint8 and slot.size == SLOT_BYTES
-    assert unpack_batch(slot).equals(rb)
-    big = pa.RecordBatch.from_arrays([pa.array(np.arange(10000, dtype=np.int64))], names=["x"])
-    with pytest.raises(ValueError):
-        pack_batch(big)
-    with pytest.raises(ValueError):
-        unpack_batch(np.zeros(SLOT_BYTES, dtype=np.uint8))
+@pytest.mark.parametrize("query,join_exchange", [("q1", "-"), ("q6", "-"), ("q3", "shuffle"), ("q3", "broadcast"), ("q5", "shuffle"),
+                                                 ("q5", "broadcast")])
+def test_two_rank_flows_equal_one_rank_gloo(query, join_exchange):
+    pytest.importorskip("pyarrow")
+    _spawn(2, query, join_exchange)
+
+
+def _routing_main(rank, world, port, _a, _b, q):
+    """GlooGroup.all_to_all / all_gather: who gets what, in which order, empty parts included"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    try:
+        from oracle.engine import OCol
+        from ballista_amd import distributed as D
+        group = D.ProcessGroup.from_env("gloo")
+        eng = OracleEngine()
+
+        def batch(src, dst, n):
+            return OrderedDict([("src", OCol("Int32", np.full(n, src, np.int32))), ("dst", OCol("Int32", np.full(n, dst, np.int32))),
+                                ("s", OCol("Utf8", [f"{src}->{dst}#{i}" for i in range(n)], None if n == 0 else np.arange(n) % 3 != 0)),
+                                ("x", OCol("Float64", np.arange(n) * 0.5 + src))])
+
+        sizes = lambda s, d: 0 if (s + d) % 3 == 0 else 5 + 7 * s + 3 * d      # some parts are empty
+        parts = [batch(rank, d, sizes(rank, d)) for d in range(world)]
+        got = group.all_to_all(eng, parts)
+        assert len(got) == world
+        for s, b in enumerate(got):                                               # source-rank order, payload intact
+            want = batch(s, rank, sizes(s, rank))
+            assert eng.num_rows(b) == sizes(s, rank)
+            assert b["s"].to_pylist() == want["s"].to_pylist() and list(b["x"].values) == list(want["x"].values)
+            assert all(v == s for v in b["src"].values) and all(v == rank for v in b["dst"].values)
+        gathered = group.all_gather(eng, batch(rank, -1, 3 + rank))
+        assert [eng.num_rows(b) for b in gathered] == [3 + r for r in range(world)]
+        assert all(all(v == r for v in b["src"].values) for r, b in enumerate(gathered))
+        group.close()
+        q.put((rank, "ok"))
+    except BaseException as e:          # noqa: BLE001
+        import traceback
+        q.put((rank, "".join(traceback.format_exception(type(e), e, e.__traceback__))))
+
+
+def test_three_rank_routing_gloo():
+    pytest.importorskip("pyarrow")
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_routing_main, args=(r, 3, port, None, None, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for rank, msg in sorted(results):
+        assert msg == "ok", f"rank {rank}:\n{msg}"
+
+
+def test_bench_self_launches_its_ranks(monkeypatch):
+    """`python bench.py --gpus N` without a launcher spawns torch.distributed.run as a child and relays rank 0's line"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    class Done:
+        returncode = 0
+        stdout = 'noise\n{"metric": "tpch_q1_sf100_rows_per_sec", "value": 1.0}\n'
+
+    def fake_run(cmd, **kw):
+        seen["cmd"] = cmd
+        return Done()
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
+    assert bench.self_launch(bench.parse(["--gpus", "4", "--steps", "2"])) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "2"]

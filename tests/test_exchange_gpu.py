@@ -1,68 +1,100 @@
-"""Device-to-device exchange of partition columns through RCCL (ballista_amd/exchange.py::all_to_all_device).
-A one-GPU box can only form a world of ONE rank: this checks the plumbing the N-rank run relies on — device
-pointers of partition slices seen as torch tensors, uneven-split all_to_all into one receive buffer per column,
-the received buffers wrapped as a batch without a copy and usable as operator input.  The N-rank routing logic
-(who sends what to whom, source-rank order) is covered by the two-rank gloo test of the host-staged variant
-(tests/test_distributed_cpu.py), which shares the count exchange and the ordering rules.
+"""The library's own exchange (ballista_amd/csrc/host/exchange.cpp) on a one-GPU box:
 
-Runs in a child process that imports torch BEFORE the library, as bench.py does: PyTorch-ROCm ships its own HIP
-runtime and must be the first to initialise the GPU in a process."""
+  * bhip_batch_pack / bhip_batch_unpack — the block form every transport moves — round-trips every column type, NULLs, empty
+    batches; an unpacked batch is ordinary operator input;
+  * bhip_comm_* over RCCL with a world of ONE rank (all a one-GPU box can form; RCCL refuses two ranks on one device): the
+    unique id, communicator creation through dlopen'ed librccl, all_gather / all_to_all return the caller's batches;
+  * `bench.py --gpus 2 --backend gloo`: the N-rank flow of the bench end to end — self-launch, row-block sharding, stage 1 on
+    the device, exchange (pack -> gloo -> unpack), Final — with both ranks sharing the GPU, against the one-rank answer.
+The N-rank routing itself is covered on CPU by tests/test_distributed_cpu.py with the same flow functions."""
+import json
 import os
 import subprocess
 import sys
+from collections import OrderedDict
 
+import numpy as np
 import pytest
+
+import ballista_amd as ba
+from ballista_amd import expr as E
+from ballista_amd.expr import col
+from oracle import plan_eval
+from oracle.engine import OCol
+
+import helpers
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-CHILD = r'''
-import os, socket, sys
-import numpy as np
-import torch
-import torch.distributed as dist
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-from collections import OrderedDict
-with socket.socket() as s:
-    s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
-os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
-torch.cuda.set_device(0)
-dist.init_process_group("nccl", rank=0, world_size=1)
-import ballista_amd as ba
-from ballista_amd import expr as E
-from ballista_amd.exchange import all_to_all_device
-from ballista_amd.expr import col
-from oracle import plan_eval
-from oracle.engine import OCol
-import helpers
-ctx = ba.Context(0)
-rng = np.random.default_rng(4)
-n = 50_001
-t = OrderedDict([("k", OCol("Int32", rng.integers(0, 10 ** 6, n).astype(np.int32))), ("a", OCol("Float64", rng.random(n))),
-                 ("c", OCol("Int64", rng.integers(0, 10 ** 12, n)))])
-parts = ba.plan.hash_partition(helpers.to_device(ctx, t), [col("k")], 1)
-got = all_to_all_device(dist, parts, ctx, "cuda:0")
-assert got.num_rows == n
-helpers.assert_rows_equal(helpers.from_device(got), t, ordered=True)
-src = ba.MemoryExec([[got]], ctx)                      # the received batch is ordinary operator input
-src._oracle_partitions = [[t]]
-plan = ba.HashAggregateExec(ba.plan.PARTIAL, [], [E.Sum(col("a"), "s"), E.Count(E.lit(1, E.UINT8), "n")], src)
-helpers.assert_rows_equal(helpers.concat(helpers.collect_product(plan)), plan_eval.collect(plan), ordered=False, float_rtol=1e-9)
-empty = ba.plan.hash_partition(helpers.to_device(ctx, helpers.slice_batch(t, 0, 0)), [col("k")], 1)
-assert all_to_all_device(dist, empty, ctx, "cuda:0").num_rows == 0      # an empty partition travels too
-# the bench's exchange (bench.py --gpus N): one RCCL all_gather of the packed partial-state batches, device buffers
-import pyarrow as pa
-from ballista_amd.exchange import all_gather_batches
-state = pa.RecordBatch.from_arrays([pa.array(["A", "N", "R"]), pa.array([1.5, 2.5, 3.5]), pa.array([7, 8, 9], pa.uint64())],
-                                   names=["l_returnflag", "sum_qty[sum]", "count_order[count]"])
-back = all_gather_batches(dist, state, device="cuda:0")
-assert len(back) == 1 and back[0].equals(state)
-dist.destroy_process_group()
-print("EXCHANGE OK")
-'''
+
+def mixed_batch(n, seed=3):
+    rng = np.random.default_rng(seed)
+    valid = rng.random(n) > 0.2
+    return OrderedDict([
+        ("i", OCol("Int32", rng.integers(-10 ** 6, 10 ** 6, n).astype(np.int32))),
+        ("l", OCol("Int64", rng.integers(-10 ** 12, 10 ** 12, n), valid)),
+        ("f", OCol("Float64", rng.random(n))),
+        ("s", OCol("Utf8", ["" if i % 5 == 0 else f"str-{i % 17}-{'x' * (i % 9)}" for i in range(n)], rng.random(n) > 0.1)),
+        ("d", OCol("Date32", rng.integers(8000, 11000, n).astype(np.int32))),
+        ("b", OCol("Boolean", rng.random(n) > 0.5, rng.random(n) > 0.3)),
+        ("u", OCol("UInt64", rng.integers(0, 2 ** 62, n).astype(np.uint64)))])
 
 
-def test_all_to_all_device_world_of_one():
-    pytest.importorskip("torch")
-    r = subprocess.run([sys.executable, "-c", f"ROOT = {ROOT!r}\n" + CHILD], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "EXCHANGE OK" in r.stdout, r.stdout[-2000:] + "\n" + r.stderr[-4000:]
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 1000, 70_001])
+def test_pack_unpack_roundtrip(ctx, n):
+    t = mixed_batch(n)
+    dev = helpers.to_device(ctx, t)
+    header, block = ba.plan.pack_batch(dev)
+    assert header[0] == n and header[1] == block.size and block.size % 64 == 0
+    back = ba.plan.unpack_batch(ctx, dev.schema3(), header, block)
+    helpers.assert_rows_equal(helpers.from_device(back), t, ordered=True)
+    if n:
+        src = ba.MemoryExec([[back]], ctx)              # slices of one block are ordinary operator input
+        src._oracle_partitions = [[t]]
+        plan = ba.HashAggregateExec(ba.plan.PARTIAL, [(col("d"), "d")], [E.Sum(col("f"), "sf"), E.Count(col("l"), "cl")],
+                                    ba.FilterExec(E.IsNotNullExpr(col("s")), src))
+        helpers.assert_rows_equal(helpers.concat(helpers.collect_product(plan)), plan_eval.collect(plan), ordered=False, float_rtol=1e-9,
+                                  key_cols=["d"])
+
+
+def test_rccl_communicator_world_of_one(ctx):
+    uid = ba.plan.Communicator.unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = ba.plan.Communicator(ctx, uid, 1, 0)
+    t = mixed_batch(5000)
+    dev = helpers.to_device(ctx, t)
+    got = comm.all_gather(dev)
+    assert len(got) == 1
+    helpers.assert_rows_equal(helpers.from_device(got[0]), t, ordered=True)
+    parts = ba.plan.hash_partition(dev, [col("i")], 1)
+    back = comm.all_to_all(parts)
+    assert len(back) == 1 and back[0].num_rows == 5000
+    helpers.assert_rows_equal(helpers.from_device(back[0]), t, ordered=True)
+    with pytest.raises(ValueError):
+        comm.all_to_all(parts + parts)
+    comm.close()
+    with pytest.raises(ba.BallistaError):
+        ba.plan.Communicator(ctx, uid, 2, 5)            # rank outside the world
+
+
+@pytest.mark.parametrize("query,extra", [("q1", []), ("q3", ["--join-exchange", "shuffle"]), ("q5", ["--join-exchange", "broadcast"])])
+def test_bench_two_ranks_share_the_gpu_gloo(query, extra):
+    """answer(2 ranks) == answer(1 rank) through bench.py itself, small tables"""
+    def run(gpus):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--backend", "gloo", "--query", query, "--sf", "0.05",
+               "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-weak"] + extra
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert r.returncode == 0 and lines, r.stdout[-2000:] + "\n" + r.stderr[-4000:]
+        return json.loads(lines[-1])
+    one, two = run(1), run(2)
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and one["n_gpus"] == 1
+    a, b = one["result_check"], two["result_check"]
+    assert a["result_rows"] == b["result_rows"] > 0
+    if query == "q1":
+        assert a["rows_counted"] == b["rows_counted"] and a["groups"] == b["groups"] == 4
+    else:
+        assert np.allclose(a.get("revenue", []), b.get("revenue", []), rtol=1e-9)
+    if query != "q1":
+        assert two["exchange"]["calls"] > 0

@@ -128,3 +128,51 @@ def test_build_key_set_bitmap(ctx, jt, shape, key_type):
     right = OrderedDict([("rk", OCol(key_type, rk.astype(np_t))), ("ry", OCol("Int64", rng.integers(0, 10 ** 9, n_right)))])
     plan = ba.HashJoinExec(helpers.memory_exec(ctx, [[left]]), helpers.memory_exec(ctx, [[right]]), [("lk", "rk")], jt)
     check(plan, ["lk", "rk", "ry", "lx"])
+
+
+@pytest.mark.parametrize("jt", JOIN_TYPES)
+@pytest.mark.parametrize("order", ["sorted", "shuffled", "sorted_with_gap_words"])
+@pytest.mark.parametrize("key_type", ["Int32", "Int64"])
+def test_rank_map_build_orders(ctx, jt, order, key_type):
+    """the rank map (kernels_join.hip): a build side sorted by key is written with plain stores and rank = row; any other order
+    goes through atomicOr + perm[].  Keys cross many 64-key words, some words hold one key, some 64, runs straddle waves."""
+    rng = np.random.default_rng(21)
+    if order == "sorted_with_gap_words":
+        lk = np.concatenate([np.arange(0, 200), np.arange(1000, 1064), [5000, 5001, 70000], np.arange(70064, 72000, 3)]).astype(np.int64)
+    else:
+        lk = np.sort(rng.choice(40_000, 9_000, replace=False)).astype(np.int64)
+    if order == "shuffled":
+        lk = rng.permutation(lk)
+    lk = lk - 3000 + (10 ** 11 if key_type == "Int64" else 0)
+    n_left, n_right = len(lk), 30_000
+    rk = np.where(rng.random(n_right) < 0.4, lk[rng.integers(0, n_left, n_right)], rng.integers(lk.min() - 50, lk.max() + 50, n_right))
+    np_t = np.int64 if key_type == "Int64" else np.int32
+    left = OrderedDict([("lk", OCol(key_type, lk.astype(np_t))), ("lx", OCol("Float64", rng.random(n_left))), ("ls", OCol("Utf8", [f"L{i % 7}" for i in range(n_left)]))])
+    right = OrderedDict([("rk", OCol(key_type, rk.astype(np_t))), ("ry", OCol("Int64", rng.integers(0, 10 ** 9, n_right))),
+                         ("rd", OCol("Date32", rng.integers(9000, 10000, n_right).astype(np.int32)))])
+    schema = {"rk": key_type, "ry": "Int64", "rd": "Date32"}
+    rm = helpers.memory_exec(ctx, [[helpers.slice_batch(right, 0, 12_345), helpers.slice_batch(right, 12_345, n_right)]])
+    lm = helpers.memory_exec(ctx, [[left]])
+    check(ba.HashJoinExec(lm, rm, [("lk", "rk")], jt), ["lk", "rk", "ry", "lx"])
+    # the same under a range filter on the probe side (the fused filter + probe pass), two ranges on two columns
+    pred = E.coerce((col("rd") >= E.date32("1995-01-01")).and_(col("rd") < E.date32("1996-06-01")).and_(col("rk") > lit(int(lk.min()) + 10, key_type)), schema)
+    if key_type == "Int32":
+        flt = ba.FilterExec(pred, rm)
+    else:
+        flt = ba.FilterExec(E.coerce((col("rd") >= E.date32("1995-01-01")).and_(col("rd") < E.date32("1996-06-01")), schema), rm)
+    check(ba.HashJoinExec(lm, flt, [("lk", "rk")], jt), ["lk", "rk", "ry", "lx"])
+
+
+@pytest.mark.parametrize("jt", JOIN_TYPES)
+def test_parents_that_read_only_some_join_columns(ctx, jt):
+    """ProjectionExec / HashAggregateExec above a join ask it for the columns they read only (HashJoinExec::execute_needed):
+    no left column at all (a semi-join: no partners are staged), no right column, and an aggregate over one of each"""
+    left, right = sides(700, 6000, "Int32", True, False, seed=31)
+    lm, rm = helpers.memory_exec(ctx, [[left]]), helpers.memory_exec(ctx, [[helpers.slice_batch(right, 0, 2500)], [helpers.slice_batch(right, 2500, 6000)]])
+    j = ba.HashJoinExec(lm, rm, [("lk", "rk")], jt)
+    check(ba.ProjectionExec([(col("ry"), "ry"), (col("rd"), "rd")], j), ["ry", "rd"])
+    check(ba.ProjectionExec([(col("ls"), "ls"), (col("lx"), "lx")], j), ["ls", "lx"])
+    check(ba.ProjectionExec([(col("ry") + lit(1), "y1"), (col("lk"), "k")], j), ["k", "y1"])
+    agg = ba.HashAggregateExec(ba.plan.PARTIAL, [(col("ls"), "ls")], [E.Sum(col("ry"), "s"), E.Count(lit(1, E.UINT8), "n")], j)
+    fin = ba.HashAggregateExec(ba.plan.FINAL, [(col("ls"), "ls")], [E.Sum(col("ry"), "s"), E.Count(lit(1, E.UINT8), "n")], ba.MergeExec(agg))
+    check(fin, ["ls"])
