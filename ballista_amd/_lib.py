@@ -139,6 +139,10 @@ SYMBOLS = {
     "bhip_stream_drain": (C.c_int32, [_P, _P, _P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "bhip_batch_hash_partition": (C.c_int32, [_P, C.c_int32, C.POINTER(Expr), C.c_int32, _PP]),
     "bhip_batch_concat": (C.c_int32, [_P, C.c_int32, _PP, _PP]),
+    "bhip_stream_write_ipc": (C.c_int32, [_P, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "bhip_plan_ipc_files": (C.c_int32, [_P, C.c_int32, C.POINTER(C.c_char_p), _PP]),
+    "bhip_ipc_write_file": (C.c_int32, [_P, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "bhip_ipc_open_file": (C.c_int32, [C.c_char_p, _P]),
     "bhip_comm_unique_id": (C.c_int32, [C.c_char_p]),
     "bhip_comm_create": (C.c_int32, [_P, C.c_char_p, C.c_int32, C.c_int32, _PP]),
     "bhip_comm_release": (None, [_P]),

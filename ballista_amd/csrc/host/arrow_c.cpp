@@ -14,21 +14,20 @@
 
 using namespace bhip;
 
-namespace {
-
+// Arrow C Data Interface format strings <-> bhip_dtype (shared with ipc.cpp)
+namespace bhip {
 int dtype_from_format(const char* f) {
-    if (!strcmp(f, "i")) return DT_INT32;
-    if (!strcmp(f, "l")) return DT_INT64;
-    if (!strcmp(f, "C")) return DT_UINT8;
-    if (!strcmp(f, "L")) return DT_UINT64;
-    if (!strcmp(f, "g")) return DT_FLOAT64;
-    if (!strcmp(f, "tdD")) return DT_DATE32;
-    if (!strcmp(f, "b")) return DT_BOOLEAN;
-    if (!strcmp(f, "u")) return DT_UTF8;
+    if (!f) return 0;
+    static const struct { const char* fmt; int dt; } table[] = {
+        {"i", DT_INT32}, {"l", DT_INT64}, {"C", DT_UINT8}, {"L", DT_UINT64}, {"g", DT_FLOAT64}, {"tdD", DT_DATE32}, {"b", DT_BOOLEAN},
+        {"u", DT_UTF8}, {"c", DT_INT8}, {"s", DT_INT16}, {"S", DT_UINT16}, {"I", DT_UINT32}, {"f", DT_FLOAT32}, {"tdm", DT_DATE64},
+        {"tss:", DT_TIMESTAMP_S}, {"tsm:", DT_TIMESTAMP_MS}, {"tsu:", DT_TIMESTAMP_US}, {"tsn:", DT_TIMESTAMP_NS}};
+    for (auto& e : table)
+        if (!strcmp(f, e.fmt)) return e.dt;
     return 0;
 }
 
-const char* format_of(int dt) {
+const char* format_of_dtype(int dt) {
     switch (dt) {
         case DT_INT32: return "i";
         case DT_INT64: return "l";
@@ -37,9 +36,24 @@ const char* format_of(int dt) {
         case DT_FLOAT64: return "g";
         case DT_DATE32: return "tdD";
         case DT_BOOLEAN: return "b";
+        case DT_INT8: return "c";
+        case DT_INT16: return "s";
+        case DT_UINT16: return "S";
+        case DT_UINT32: return "I";
+        case DT_FLOAT32: return "f";
+        case DT_DATE64: return "tdm";
+        case DT_TIMESTAMP_S: return "tss:";
+        case DT_TIMESTAMP_MS: return "tsm:";
+        case DT_TIMESTAMP_US: return "tsu:";
+        case DT_TIMESTAMP_NS: return "tsn:";
         default: return "u";
     }
 }
+}  // namespace bhip
+
+namespace {
+
+const char* format_of(int dt) { return format_of_dtype(dt); }
 
 // copy n bits starting at bit `off` of src into a fresh, zero-padded bitmap
 std::vector<uint8_t> realign_bits(const uint8_t* src, int64_t off, int64_t n) {

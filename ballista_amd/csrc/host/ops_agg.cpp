@@ -372,7 +372,12 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
     int gmax = group_.empty() ? 1 : 4;
     const int hint = path_hint_.load();
     if (hint == 8 || hint == -1) gmax = hint;
-    if (n_acc > AGG_NACC) gmax = -1;
+    int64_t rows_in = 0;
+    for (auto& b : inputs) rows_in += b->n_rows;
+    // more than 8 accumulators: the hash path — except over a tiny input (the Final aggregate over a few partial-state rows
+    // per rank), where the 16-accumulator variant of the register kernel is ONE launch instead of a dozen
+    const bool wide_acc = n_acc > AGG_NACC;
+    if (wide_acc && (rows_in > 65536 || hint == -1)) gmax = -1;
 
     // A plan that has not run yet does not know how many groups there are.  With a large input the ladder below (4 groups per
     // workgroup -> 8 -> hash table) is first walked on the leading 32 Ki rows only: an aggregate with many groups (Q3: one per
@@ -442,7 +447,7 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
         }
         check_scan_flags(st);
         if (st.flags & SCAN_OVERFLOW_GROUPS) {
-            gmax = gmax == 4 ? 8 : -1;       // more groups than the register path holds: widen, then hash
+            gmax = (gmax == 4 && !wide_acc) ? 8 : -1;       // more groups than the register path holds: widen, then hash
             path_hint_.store(gmax);
             if (gmax == -1) sample.clear();
             continue;

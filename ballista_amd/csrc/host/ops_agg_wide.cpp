@@ -22,7 +22,51 @@ bool key_width_error(const Error& e) {
 }
 }  // namespace
 
+bool HashAggregateExec::run_single_partial(const Exec& ex, std::vector<BatchPtr>& out) const {
+    static const bool disabled = [] { const char* v = getenv("BHIP_NO_FINAL_ELISION"); return v && atoi(v) != 0; }();
+    if (disabled || mode_ != BHIP_AGG_FINAL) return false;
+    const ExecutionPlan* p = input_.get();
+    PlanPtr below;
+    while (true) {
+        if (auto m = dynamic_cast<const MergeExec*>(p)) { below = m->input(); p = below.get(); continue; }
+        if (auto c = dynamic_cast<const CoalesceBatchesExec*>(p)) { below = c->input(); p = below.get(); continue; }
+        break;
+    }
+    auto pa = dynamic_cast<const HashAggregateExec*>(p);
+    if (!pa || !below || pa->mode_ != BHIP_AGG_PARTIAL || pa->output_partitioning().count != 1) return false;
+    if (pa->group_.size() != group_.size() || pa->aggr_.size() != aggr_.size()) return false;
+    const Schema& ps = *pa->schema();
+    // this operator's keys must be the partial's key columns, in order, and the functions must be the same
+    for (size_t i = 0; i < group_.size(); ++i)
+        if (group_[i].first->kind != BHIP_EXPR_COLUMN || group_[i].first->name != ps.fields[i].name) return false;
+    for (size_t i = 0; i < aggr_.size(); ++i)
+        if (aggr_[i].fn != pa->aggr_[i].fn) return false;
+    std::vector<std::pair<ExprPtr, std::string>> exprs;
+    for (size_t i = 0; i < group_.size(); ++i) exprs.push_back({make_column(ps.fields[i].name), group_[i].second});
+    size_t pos = group_.size();
+    for (auto& a : aggr_) {
+        if (a.fn == BHIP_AGG_AVG) {
+            auto cast = std::make_shared<Expr>();
+            cast->kind = BHIP_EXPR_CAST;
+            cast->dtype = DT_FLOAT64;
+            cast->args = {make_column(ps.fields[pos].name)};                          // [count]
+            exprs.push_back({make_binary(make_column(ps.fields[pos + 1].name), "Divide", ExprPtr(cast)), a.name});
+            pos += 2;
+        } else {
+            exprs.push_back({make_column(ps.fields[pos].name), a.name});
+            pos += 1;
+        }
+    }
+    auto s = below->execute(0, ex);
+    while (BatchPtr b = s->next()) out.push_back(project_batch(ex, *b, exprs, schema_));
+    return true;
+}
+
 std::vector<BatchPtr> HashAggregateExec::run(int partition, const Exec& ex) const {
+    {
+        std::vector<BatchPtr> out;
+        if (run_single_partial(ex, out)) return out;
+    }
     if (!group_.empty() && wide_keys_.load()) return run_wide(partition, ex);
     try {
         return run_packed(partition, ex);

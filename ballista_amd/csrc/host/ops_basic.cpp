@@ -372,8 +372,8 @@ std::string ProjectionExec::describe() const {
     return s + "]";
 }
 
-static BatchPtr project_batch(const Exec& ex, const Batch& in, const std::vector<std::pair<ExprPtr, std::string>>& exprs,
-                              const SchemaPtr& schema) {
+BatchPtr project_batch(const Exec& ex, const Batch& in, const std::vector<std::pair<ExprPtr, std::string>>& exprs,
+                       const SchemaPtr& schema) {
     auto out = std::make_shared<Batch>();
     out->schema = schema;
     out->ctx = in.ctx;

@@ -200,6 +200,9 @@ private:
     std::vector<BatchPtr> run(int partition, const Exec& ex) const;
     std::vector<BatchPtr> run_packed(int partition, const Exec& ex) const;   // keys packed into 16 bytes (every fast path)
     std::vector<BatchPtr> run_wide(int partition, const Exec& ex) const;     // keys of any width (ops_agg_wide.cpp)
+    // Final over the Merge of ONE partition of a Partial aggregate with the same keys: every group arrives exactly once, the
+    // merge is the identity and the operator is a projection of the state columns (AVG = sum / count)
+    bool run_single_partial(const Exec& ex, std::vector<BatchPtr>& out) const;
     int mode_;
     std::vector<std::pair<ExprPtr, std::string>> group_;
     std::vector<AggregateDesc> aggr_;
@@ -279,6 +282,8 @@ void check_scan_status(const Exec& ex, const ScanStatus* dev_status, ScanStatus*
 void check_scan_flags(const ScanStatus& host_status);   // the same checks on a status already read back
 // value of `e` over `in` as a column (a plain Column reference shares the input buffers)
 Column evaluate_column(const Exec& ex, const Batch& in, const ExprPtr& e);
+// ProjectionExec over one batch: plain columns share their buffers, everything else is one VM launch
+BatchPtr project_batch(const Exec& ex, const Batch& in, const std::vector<std::pair<ExprPtr, std::string>>& exprs, const SchemaPtr& schema);
 // gather of one column incl. its validity bitmap
 Column take_batch_column(const Exec& ex, const Column& c, const uint32_t* idx, int64_t n);
 // columns gathered by one index vector; may_null: the indices may hold 0xFFFFFFFF (outer joins) -> validity always built

@@ -38,19 +38,21 @@ struct AggLds {
     uint32_t winner;
     uint32_t overflow;
     uint32_t pad;
-    uint64_t red[4][AGG_GMAX * AGG_NACC];
+    uint64_t red[4][AGG_GMAX * VM_MAX_ACC];
 };
 
 // The scan parameters (program, column pointers) are read through a pointer to a per-launch copy
 // in device memory: the addresses are wave-uniform, so they are fetched with scalar loads.  (As a
 // by-value kernel argument the 2 KB struct was copied to scratch once the next tile's loads were
 // issued from inside the loop.)
-template <int R, bool NULLS, int GMAX, bool PREFETCH>
-__global__ void __launch_bounds__(BLOCK, (GMAX >= 8 ? 2 : 3))   // >= 2-3 workgroups per CU: caps VGPRs at 256 / 168
+// NACC_: accumulator registers per group.  8 for everything that scans; 16 only for tiny inputs (the Final aggregate over a few
+// partial-state rows per rank: Q1 carries 11 accumulators), where one launch instead of the hash path's dozen is what counts
+template <int R, bool NULLS, int GMAX, bool PREFETCH, int NACC_ = AGG_NACC>
+__global__ void __launch_bounds__(BLOCK, (NACC_ > AGG_NACC ? 1 : (GMAX >= 8 ? 2 : 3)))   // >= 2-3 workgroups per CU: caps VGPRs at 256 / 168
 scan_agg_lowcard_kernel(const ScanParams* __restrict__ Pp, const AggLowCardArgs<GMAX> A) {
     const ScanParams& P = *Pp;
     constexpr int TILE = BLOCK * R;
-    constexpr int NACC = AGG_NACC;
+    constexpr int NACC = NACC_;
     extern __shared__ __align__(16) uint8_t lds_raw[];
     const TileLds L = carve_tile_lds<R, NULLS>(lds_raw, P.prog);
     BHIP_LDS AggLds* S = (BHIP_LDS AggLds*)((lds_u8*)lds_raw + tile_lds_bytes<R>(P.prog.n_vslots, P.prog.n_bslots, NULLS));
@@ -379,14 +381,14 @@ merge_reduce_kernel(const GroupRec* partials, const uint32_t* entry_group, int n
 
 int scan_agg_lowcard_max_grid(const LaunchCfg& cfg) { return cfg.device_cus * 8; }
 
-template <int R, bool NULLS, int GMAX, bool PREFETCH>
+template <int R, bool NULLS, int GMAX, bool PREFETCH, int NACC_ = AGG_NACC>
 static hipError_t launch_lowcard_t(const LaunchCfg& cfg, const ScanParams& P, ScanParams* dparams, GroupRec* partials,
                                    uint32_t* partial_ng, int max_grid, ScanStatus* status, int* grid_out) {
     constexpr int TILE = BLOCK * R;
     const size_t lds = host_tile_bytes<R>(P.prog) + sizeof(AggLds);
     if (lds > LDS_PER_CU) return hipErrorInvalidValue;
     const int64_t n_tiles = (P.n_rows + TILE - 1) / TILE;
-    auto k = scan_agg_lowcard_kernel<R, NULLS, GMAX, PREFETCH>;
+    auto k = scan_agg_lowcard_kernel<R, NULLS, GMAX, PREFETCH, NACC_>;
     hipError_t e = set_lds(k, lds);
     if (e != hipSuccess) return e;
     // one grid-stride wave of resident workgroups: every workgroup gets the same number of tiles
@@ -425,6 +427,11 @@ static hipError_t launch_lowcard_n(const LaunchCfg& cfg, const ScanParams& P, Sc
         if (r == 4) return pf ? BHIP_LC(4, 4, true) : BHIP_LC(4, 4, false);
     }
 #endif
+    if (P.n_acc > AGG_NACC) {                      // tiny inputs only (host/ops_agg.cpp): 16 accumulator registers per group
+        if (gmax == 4) return launch_lowcard_t<1, NULLS, 4, false, VM_MAX_ACC>(cfg, P, dparams, partials, partial_ng, max_grid, status, grid_out);
+        if (gmax == 1) return launch_lowcard_t<1, NULLS, 1, false, VM_MAX_ACC>(cfg, P, dparams, partials, partial_ng, max_grid, status, grid_out);
+        return hipErrorInvalidValue;
+    }
     // 8 groups x 8 accumulators take 128 VGPRs: no room for prefetch registers
     if (gmax == 8) return BHIP_LC(2, 8, false);
     if (gmax == 4) return BHIP_LC(AGG_DEFAULT_R, 4, AGG_DEFAULT_PREFETCH);

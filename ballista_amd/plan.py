@@ -471,6 +471,14 @@ class RecordBatchStream:
         L.check(L.lib().bhip_stream_drain(self._h, None, None, C.byref(r), C.byref(n), C.byref(by)))
         return dict(num_rows=r.value, num_batches=n.value, num_bytes=by.value)
 
+    def write_ipc(self, path: str):
+        """bhip_stream_write_ipc = utils::write_stream_to_disk (rust/core/src/utils.rs:49-84): drain into an Arrow IPC file,
+        return PartitionStats.  Consumes the stream."""
+        r, n, by = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        h, self._h = self._h, None
+        L.check(L.lib().bhip_stream_write_ipc(h, path.encode(), C.byref(r), C.byref(n), C.byref(by)))
+        return dict(num_rows=r.value, num_batches=n.value, num_bytes=by.value)
+
     def to_arrow_reader(self):
         """hand the stream to pyarrow through the Arrow C Stream Interface (consumes it)"""
         import pyarrow as pa
@@ -787,6 +795,42 @@ class LocalLimitExec(ExecutionPlan):
         L.check(L.lib().bhip_plan_local_limit(input._h, limit, C.byref(h)))
         super().__init__(h, input.ctx, [input])
         self.input, self.limit = input, limit
+
+
+# ---- Arrow IPC files (the stage boundary on disk) --------------------------------------------------------------
+
+def ipc_write_file(reader, path: str):
+    """bhip_ipc_write_file: a host-side Arrow stream (pyarrow.RecordBatchReader) -> Arrow IPC file, written by the library's own
+    writer; returns PartitionStats as a dict.  No GPU involved."""
+    c_stream = _ArrowArrayStream()
+    reader._export_to_c(C.addressof(c_stream))
+    r, n, by = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    try:
+        L.check(L.lib().bhip_ipc_write_file(C.addressof(c_stream), path.encode(), C.byref(r), C.byref(n), C.byref(by)))
+    finally:
+        if c_stream.release:
+            C.CFUNCTYPE(None, C.c_void_p)(c_stream.release)(C.addressof(c_stream))
+    return dict(num_rows=r.value, num_batches=n.value, num_bytes=by.value)
+
+
+def ipc_open_file(path: str):
+    """bhip_ipc_open_file: an Arrow IPC file read by the library's own reader -> pyarrow.RecordBatchReader (no GPU involved)"""
+    import pyarrow as pa
+    c_stream = _ArrowArrayStream()
+    L.check(L.lib().bhip_ipc_open_file(path.encode(), C.addressof(c_stream)))
+    return pa.RecordBatchReader._import_from_c(C.addressof(c_stream))
+
+
+class IpcFileExec(ExecutionPlan):
+    """bhip_plan_ipc_files: leaf over Arrow IPC files, one output partition per file — the local half of ShuffleReaderExec
+    (rust/core/src/execution_plans/shuffle_reader.rs:77-99)."""
+
+    def __init__(self, paths: Sequence[str], ctx: Context):
+        arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+        h = C.c_void_p()
+        L.check(L.lib().bhip_plan_ipc_files(ctx._h, len(paths), arr, C.byref(h)))
+        super().__init__(h, ctx)
+        self.paths = list(paths)
 
 
 class Communicator:

@@ -341,6 +341,21 @@ typedef bhip_status (*bhip_batch_sink)(void* user, bhip_batch* batch);
 bhip_status bhip_stream_drain(bhip_stream* stream, bhip_batch_sink sink, void* user, uint64_t* num_rows,
                               uint64_t* num_batches, uint64_t* num_bytes);
 
+/* ---- Arrow IPC files: the two sides of a stage boundary ------------------------------------------------------
+ * bhip_stream_write_ipc = utils::write_stream_to_disk (rust/core/src/utils.rs:49-84): drains the stream into an Arrow IPC
+ * FILE at `path` (what the executor serves to the next stage, rust/executor/src/flight_service.rs:104-150) and reports
+ * PartitionStats.  The stream is consumed.
+ * bhip_plan_ipc_files: a leaf over such files, one output partition per file — the local half of ShuffleReaderExec
+ * (rust/core/src/execution_plans/shuffle_reader.rs:77-99).  Files written by arrow-rs / pyarrow are read as well
+ * (metadata V4 or V5, no compression, no dictionaries; other files -> BHIP_ENOTIMPL).
+ * bhip_ipc_write_file / bhip_ipc_open_file are the same on host-side Arrow C streams (no GPU involved). */
+bhip_status bhip_stream_write_ipc(bhip_stream* stream, const char* path, uint64_t* num_rows, uint64_t* num_batches,
+                                  uint64_t* num_bytes);
+bhip_status bhip_plan_ipc_files(bhip_ctx* ctx, int32_t n_files, const char* const* paths, bhip_plan** out);
+bhip_status bhip_ipc_write_file(struct ArrowArrayStream* stream, const char* path, uint64_t* num_rows, uint64_t* num_batches,
+                                uint64_t* num_bytes);
+bhip_status bhip_ipc_open_file(const char* path, struct ArrowArrayStream* out);
+
 /* ---- hash repartition exchange support (RepartitionExec(Hash) across GPUs) -----------------
  * The per-row partition id is  bhip_row_hash(key columns) % n  (DESIGN.md "Row hash").  These
  * two calls split a device batch into n device batches (partition p = rows whose id is p, input
