@@ -55,6 +55,13 @@ namespace {
 
 const char* format_of(int dt) { return format_of_dtype(dt); }
 
+// what the device operators carry today: the eight types of the TPC-H schemas.  The wire formats (protobuf plans, Arrow IPC
+// files) know the other primitive types too; a batch of those is refused here (BHIP_ENOTIMPL: keep the CPU operator)
+int device_dtype_from_format(const char* f) {
+    const int dt = dtype_from_format(f);
+    return (dt >= DT_INT32 && dt <= DT_UTF8) ? dt : 0;
+}
+
 // copy n bits starting at bit `off` of src into a fresh, zero-padded bitmap
 std::vector<uint8_t> realign_bits(const uint8_t* src, int64_t off, int64_t n) {
     std::vector<uint8_t> out((size_t)((n + 63) / 64) * 8 + 8, 0);
@@ -272,7 +279,7 @@ bhip_status bhip_batch_import_arrow(bhip_ctx* ctx, struct ArrowArray* array, str
         for (int i = 0; i < n_cols; ++i) {
             const ArrowSchema* cs = schema->children[i];
             const ArrowArray* ca = array->children[i];
-            const int dt = dtype_from_format(cs->format);
+            const int dt = device_dtype_from_format(cs->format);
             if (!dt) fail(BHIP_ENOTIMPL, std::string("unsupported Arrow type '") + cs->format + "' for column " + (cs->name ? cs->name : ""));
             if (ca->dictionary) fail(BHIP_ENOTIMPL, "dictionary arrays are not supported");
             // the array must have the buffers its declared format implies (a producer whose batches do not match
@@ -415,7 +422,7 @@ bhip_status bhip_plan_arrow_streams(bhip_ctx* ctx, int32_t n_partitions, struct 
         if (!sch.format || strcmp(sch.format, "+s") != 0) err = "expected a struct schema (RecordBatch stream)";
         for (int64_t i = 0; err.empty() && i < sch.n_children; ++i) {
             const ArrowSchema* cs = sch.children[i];
-            const int dt = dtype_from_format(cs->format);
+            const int dt = device_dtype_from_format(cs->format);
             if (!dt) err = std::string("unsupported Arrow type '") + cs->format + "' for column " + (cs->name ? cs->name : "");
             else schema->fields.push_back(bhip::Field{cs->name ? cs->name : "", dt, (cs->flags & ARROW_FLAG_NULLABLE) != 0});
         }

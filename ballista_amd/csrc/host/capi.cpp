@@ -424,7 +424,7 @@ bhip_status bhip_stream_next(bhip_stream* s, bhip_batch** out) {
     s->ex.ctx->set_device();
     BatchPtr b = s->s->next();
     // a batch only leaves the library once everything that produces it has finished
-    HIP_CHECK(hipStreamSynchronize(s->ex.stream));
+    s->ex.ctx->wait_stream(s->ex.stream);
     *out = b ? wrap_batch(b) : nullptr;
     BHIP_API_END
 }
@@ -444,7 +444,7 @@ bhip_status bhip_stream_drain(bhip_stream* s, bhip_batch_sink sink, void* user, 
     s->ex.ctx->set_device();
     uint64_t rows = 0, batches = 0, bytes = 0;
     while (BatchPtr b = s->s->next()) {
-        HIP_CHECK(hipStreamSynchronize(s->ex.stream));
+        s->ex.ctx->wait_stream(s->ex.stream);
         rows += (uint64_t)b->n_rows;
         batches += 1;
         bytes += (uint64_t)b->memory_size();

@@ -1,7 +1,12 @@
 // core.cpp — context (allocator, streams), buffers, batches.
 #include "core.hpp"
 
+#include <immintrin.h>
+
+#include <chrono>
 #include <cstdlib>
+
+#include "../util_kernels.h"
 
 namespace bhip {
 
@@ -68,6 +73,39 @@ Context::Context(int device) : device_(device) {
     cus_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const char* t = getenv("BHIP_KERNEL_TIMING");
     timing_ = t ? atoi(t) : 0;
+    const char* sp = getenv("BHIP_SPIN_WAIT");
+    spin_wait_ = !(sp && atoi(sp) == 0);
+    if (spin_wait_) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, sizeof(HostSlot) * N_SLOTS, hipHostMallocDefault) == hipSuccess) {
+            memset(p, 0, sizeof(HostSlot) * N_SLOTS);
+            slots_ = static_cast<HostSlot*>(p);
+        } else {
+            spin_wait_ = false;
+        }
+    }
+}
+
+void Context::wait_stream(hipStream_t stream, const void* dev_src, void* host_dst, size_t bytes) {
+    if (!spin_wait_ || bytes > 56 || (bytes & 3)) {
+        if (bytes) HIP_CHECK(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        return;
+    }
+    const uint64_t seq = slot_seq_.fetch_add(1) + 1;
+    HostSlot* slot = &slots_[seq % N_SLOTS];
+    HIP_CHECK(launch_publish(stream, dev_src, (int)(bytes / 4), (void*)slot, seq));
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0;; ++spins) {
+        if (__atomic_load_n(&slot->w[0], __ATOMIC_ACQUIRE) == seq) break;
+        _mm_pause();
+        if ((spins & 0x3FF) == 0x3FF && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+            HIP_CHECK(hipStreamSynchronize(stream));                      // long kernels: sleep instead of burning the core
+            if (__atomic_load_n(&slot->w[0], __ATOMIC_ACQUIRE) != seq) fail(BHIP_EHIP, "stream finished without publishing its result");
+            break;
+        }
+    }
+    if (bytes) memcpy(host_dst, (const void*)&slot->w[1], bytes);
 }
 
 Context::~Context() {
@@ -79,6 +117,7 @@ Context::~Context() {
     }
     for (auto& kv : live_) hipFree(kv.second.ptr);
     for (auto s : stream_pool_) hipStreamDestroy(s);
+    if (slots_) hipHostFree(slots_);
     for (auto& p : pending_timed_) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : event_pool_) hipEventDestroy(e);
 }

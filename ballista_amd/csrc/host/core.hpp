@@ -69,6 +69,12 @@ public:
     hipStream_t acquire_stream();
     void release_stream(hipStream_t s);
 
+    // "everything enqueued on `stream` so far has finished", optionally with `bytes` (<= 56, a multiple of 4) of device
+    // memory brought along: a one-thread kernel writes them and then a sequence number into a pinned host slot the caller
+    // spins on.  A runtime wait (hipStreamSynchronize after a device-to-host copy) costs 30-40 us of wake-up latency on this
+    // stack; an operator tree makes dozens of them per query.  Falls back to the runtime wait after ~2 ms of spinning.
+    void wait_stream(hipStream_t stream, const void* dev_src = nullptr, void* host_dst = nullptr, size_t bytes = 0);
+
     // kernel timing hook (bench roofline): accumulated by the aggregate operator
     void add_kernel_time(double ms, uint64_t launches, const char* kernel = nullptr);
     std::string kernel_name();
@@ -90,6 +96,11 @@ private:
     std::map<void*, Block> live_;
     uint64_t in_use_ = 0, peak_ = 0, cached_ = 0;
     std::vector<hipStream_t> stream_pool_;
+    static constexpr size_t N_SLOTS = 1024;
+    struct HostSlot { volatile uint64_t w[8]; };      // one cache line of pinned host memory: w[0] = sequence, w[1..7] = payload
+    HostSlot* slots_ = nullptr;
+    std::atomic<uint64_t> slot_seq_{0};
+    bool spin_wait_ = true;
     double k_ms_ = 0;
     uint64_t k_launches_ = 0;
     std::string k_name_;
@@ -235,14 +246,19 @@ Column take_column(const Exec& ex, const Column& c, const uint32_t* indices, int
 BatchPtr concat_batches(const Exec& ex, const SchemaPtr& schema, const std::vector<BatchPtr>& parts);
 BatchPtr slice_head(const Exec& ex, const Batch& in, int64_t n);
 
-// read a small device value after synchronising the task's stream
+// read a small device value once the task's stream has caught up (Context::wait_stream)
 template <class T>
 T read_device(const Exec& ex, const T* dev) {
     T host;
+    if (sizeof(T) <= 56 && sizeof(T) % 4 == 0) {
+        ex.ctx->wait_stream(ex.stream, dev, &host, sizeof(T));
+        return host;
+    }
     HIP_CHECK(hipMemcpyAsync(&host, dev, sizeof(T), hipMemcpyDeviceToHost, ex.stream));
     HIP_CHECK(hipStreamSynchronize(ex.stream));
     return host;
 }
+inline void stream_wait(const Exec& ex) { ex.ctx->wait_stream(ex.stream); }
 
 }  // namespace bhip
 

@@ -472,7 +472,7 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
         }
         table = tmp.get<GroupRec>(1);
         HIP_CHECK(hipMemcpyAsync(table, &id, sizeof(id), hipMemcpyHostToDevice, ex.stream));
-        HIP_CHECK(hipStreamSynchronize(ex.stream));
+        stream_wait(ex);
         n_groups = 1;
     }
 
@@ -538,10 +538,10 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
     if (!utf8_cols.empty()) {
         std::vector<uint64_t> host(group_.size());
         HIP_CHECK(hipMemcpyAsync(host.data(), totals, group_.size() * 8, hipMemcpyDeviceToHost, ex.stream));
-        HIP_CHECK(hipStreamSynchronize(ex.stream));
+        stream_wait(ex);
         for (size_t gi : utf8_cols) out->cols[gi].data_bytes = (int64_t)host[gi];
     } else {
-        HIP_CHECK(hipStreamSynchronize(ex.stream));
+        stream_wait(ex);
     }
     return {out};
 }

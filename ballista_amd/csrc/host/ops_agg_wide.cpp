@@ -120,7 +120,7 @@ std::vector<BatchPtr> HashAggregateExec::run_wide(int partition, const Exec& ex)
         K.n = (int32_t)keys.size();
         for (size_t i = 0; i < keys.size(); ++i) K.col[i] = keys[i].ref();
         TIMED_LAUNCH(ex, "wide_key_assign", launch_wide_key_assign(cfg, K, hashes, table, cap - 1, (uint32_t)n, rep->as<uint32_t>()));
-        HIP_CHECK(hipStreamSynchronize(ex.stream));                  // the scratch is released here
+        stream_wait(ex);                  // the scratch is released here
     }
 
     // ---- the ordinary aggregate, keyed by the representative row ---------------------------------------------
@@ -163,7 +163,7 @@ std::vector<BatchPtr> HashAggregateExec::run_wide(int partition, const Exec& ex)
         for (size_t i = 1; i < r->cols.size(); ++i) out->cols.push_back(r->cols[i]);
         outv.push_back(out);
     }
-    HIP_CHECK(hipStreamSynchronize(ex.stream));
+    stream_wait(ex);
     return outv;
 }
 

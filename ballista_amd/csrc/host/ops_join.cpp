@@ -183,7 +183,7 @@ std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) co
         HIP_CHECK(hipMemcpyAsync(stats, seed, sizeof(seed), hipMemcpyHostToDevice, ex.stream));
         TIMED_LAUNCH_N(ex, "join_key_stats", n, launch_join_key_stats(ex.cfg(), kc.data->ptr(), nkw, ksel, (uint32_t)n, stats));
         HIP_CHECK(hipMemcpyAsync(host_stats, stats, sizeof(host_stats), hipMemcpyDeviceToHost, ex.stream));
-        HIP_CHECK(hipStreamSynchronize(ex.stream));
+        stream_wait(ex);
         const uint64_t bias = nkw == 4 ? 0x80000000ull : (1ull << 63);
         const bool any_key = host_stats[0] <= host_stats[1];
         const uint64_t range = any_key ? host_stats[1] - host_stats[0] : 0;
@@ -216,7 +216,7 @@ std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) co
                 }
             }
             if (!dup) {
-                HIP_CHECK(hipStreamSynchronize(ex.stream));                 // other tasks (other streams) read the map: complete before it is published
+                stream_wait(ex);                 // other tasks (other streams) read the map: complete before it is published
                 bs->ntable.rbits = bs->rbits->as<uint64_t>();
                 bs->ntable.rprefix = bs->rprefix->as<uint32_t>();
                 bs->ntable.rperm = bs->rperm ? bs->rperm->as<uint32_t>() : nullptr;
@@ -471,7 +471,7 @@ StreamPtr HashJoinExec::execute_needed(int partition, const Exec& ex, const std:
                 ridx = orig;
             }
             emit(outsrc, rmap, lidx, ridx, (int64_t)n_out);
-            HIP_CHECK(hipStreamSynchronize(ex.stream));   // index scratch is released at the end of the iteration
+            stream_wait(ex);   // index scratch is released at the end of the iteration
         };
 
         // ---- narrow build side: one pass over the probe rows: ranges -> key-set bit -> rank map / table (kernels_join.hip) -----
@@ -504,7 +504,7 @@ StreamPtr HashJoinExec::execute_needed(int partition, const Exec& ex, const std:
                 ridx = orig;
             }
             emit(outsrc, rmap, lidx, ridx, (int64_t)n_out);
-            HIP_CHECK(hipStreamSynchronize(ex.stream));
+            stream_wait(ex);
         };
         ProbeFilter no_filter;
         memset(&no_filter, 0, sizeof(no_filter));
@@ -569,7 +569,7 @@ StreamPtr HashJoinExec::execute_needed(int partition, const Exec& ex, const std:
                 uint32_t* lidx = tmp.get<uint32_t>((size_t)n_un);
                 TIMED_LAUNCH(ex, "compact_flags", launch_compact_flags(cfg, flags, offsets, (uint32_t)n_left, lidx));
                 emit(nullptr, nullptr, lidx, nullptr, (int64_t)n_un);
-                HIP_CHECK(hipStreamSynchronize(ex.stream));
+                stream_wait(ex);
             }
         }
         return out;

@@ -107,7 +107,7 @@ StreamPtr SortExec::execute(int partition, const Exec& ex) const {
             }
         }
         BatchPtr out = take_batch(ex, *in, perm->as<uint32_t>(), n, nullptr, /*permutation=*/true);
-        HIP_CHECK(hipStreamSynchronize(ex.stream));
+        stream_wait(ex);
         return {out};
     }));
 }
@@ -183,13 +183,13 @@ std::vector<BatchPtr> hash_partition_batch(const Exec& ex, const BatchPtr& in, c
         uint32_t* first_dev = tmp.get<uint32_t>((size_t)n_parts + 1);
         TIMED_LAUNCH(ex, "partition_bounds", launch_partition_bounds(cfg, keys->as<uint64_t>(), n, (uint32_t)n_parts, first_dev));
         HIP_CHECK(hipMemcpyAsync(first.data(), first_dev, ((size_t)n_parts + 1) * 4, hipMemcpyDeviceToHost, ex.stream));
-        HIP_CHECK(hipStreamSynchronize(ex.stream));
+        stream_wait(ex);
     }
     for (int p = 0; p < n_parts; ++p) {
         const int64_t cnt = (int64_t)first[p + 1] - (int64_t)first[p];
         out[p] = take_batch(ex, *in, perm->as<uint32_t>() + first[p], cnt);
     }
-    HIP_CHECK(hipStreamSynchronize(ex.stream));   // `perm` is released when this returns
+    stream_wait(ex);   // `perm` is released when this returns
     return out;
 }
 
@@ -244,7 +244,7 @@ StreamPtr RepartitionExec::execute(int partition, const Exec& ex) const {
                     ++batch_no;
                 }
             }
-            HIP_CHECK(hipStreamSynchronize(ex.stream));
+            stream_wait(ex);
             self->cache_->done = true;
         }
         return self->cache_->parts[(size_t)partition];

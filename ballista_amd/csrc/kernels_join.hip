@@ -185,12 +185,14 @@ struct WaveScratch {
     uint32_t b[FP_CHUNK];        // rank map: popcount of the lower bits; then: the result (build row)
 };
 
-template <int KW>
+// NF: filter columns compiled in (0, 1 or JOIN_FILTER_MAX): registers for the ones a plan does not have would only cost occupancy
+template <int KW, int NF>
 __global__ void __launch_bounds__(BLOCK)
 join_filter_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void* __restrict__ rkeys_v, const uint64_t* __restrict__ rsel,
                          uint32_t n_right, int right_outer, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts,
                          uint32_t* __restrict__ staging, uint32_t* matched) {
     using K = typename KeyT<KW>::type;
+    constexpr int NFR = NF > 0 ? NF : 1;
     __shared__ WaveScratch scratch[BLOCK / 64];
     WaveScratch& S = scratch[threadIdx.x >> 6];
     const K* __restrict__ rkeys = static_cast<const K*>(rkeys_v);
@@ -201,47 +203,52 @@ join_filter_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const voi
     const uint32_t wave_id = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (BLOCK / 64);
     const bool ranked = T.rbits != nullptr;
+
+    // the streamed inputs of one pass; the NEXT pass's are loaded before this pass walks its dependent reads
+    struct Regs { K key[FP_ROWS]; int32_t f[NFR][FP_ROWS]; };
+    auto load = [&](uint64_t base, Regs& r) {
+#pragma unroll
+        for (int k = 0; k < FP_ROWS; ++k) {
+            const uint64_t row = base + 64ull * k + lane;
+            const bool in = row < n_right;
+            r.key[k] = in ? rkeys[row] : K(0);
+#pragma unroll
+            for (int j = 0; j < NF; ++j) r.f[j][k] = (j < F.n && in) ? F.col[j][row] : 0;
+        }
+    };
+    Regs cur, nxt;
+    if (wave_id < n_tiles) load((uint64_t)wave_id * SEL_TILE, cur);
     for (uint32_t t = wave_id; t < n_tiles; t += n_waves) {
         const uint64_t tile_base = (uint64_t)t * SEL_TILE;
         uint32_t tile_cnt = 0;
 #pragma unroll 1
         for (int c = 0; c < SEL_TILE / FP_CHUNK; ++c) {
             const uint64_t base = tile_base + (uint64_t)c * FP_CHUNK;
-            if (base >= n_right) {                                     // past the end: only the bitmap words that exist are cleared
-#pragma unroll
-                for (int k = 0; k < FP_ROWS; ++k)
-                    if (lane == 0 && (base >> 6) + k < n_words) bitmap[(base >> 6) + k] = 0ull;
-                continue;
+            {
+                const bool last = c == SEL_TILE / FP_CHUNK - 1;
+                const uint64_t nbase = last ? (uint64_t)(t + n_waves) * SEL_TILE : base + FP_CHUNK;
+                if (!last || t + n_waves < n_tiles) load(nbase, nxt);
             }
-            K key[FP_ROWS];
-            int32_t f[JOIN_FILTER_MAX][FP_ROWS];
             bool in[FP_ROWS], pass[FP_ROWS], live[FP_ROWS];
             uint32_t m[FP_ROWS];
 #pragma unroll
             for (int k = 0; k < FP_ROWS; ++k) {
                 const uint64_t row = base + 64ull * k + lane;
                 in[k] = row < n_right;
-                key[k] = in[k] ? rkeys[row] : K(0);
-#pragma unroll
-                for (int j = 0; j < JOIN_FILTER_MAX; ++j)
-                    f[j][k] = (j < F.n && in[k]) ? F.col[j][row] : 0;
-            }
-#pragma unroll
-            for (int k = 0; k < FP_ROWS; ++k) {
                 bool p = in[k];
 #pragma unroll
-                for (int j = 0; j < JOIN_FILTER_MAX; ++j)
-                    if (j < F.n) p = p && f[j][k] >= F.lo[j] && f[j][k] <= F.hi[j];
+                for (int j = 0; j < NF; ++j)
+                    if (j < F.n) p = p && cur.f[j][k] >= F.lo[j] && cur.f[j][k] <= F.hi[j];
                 pass[k] = p;
                 m[k] = 0xFFFFFFFFu;
-                live[k] = p && jbit_at(rsel, base + 64ull * k + lane);          // NULL keys never match
+                live[k] = p && jbit_at(rsel, row);                      // NULL keys never match
             }
             // ---- the exact key set: one bit per value of the window (rank map: rbits, CAS table: present) ----------------
             uint64_t d[FP_ROWS], word[FP_ROWS];
             if (ranked || T.present) {
 #pragma unroll
                 for (int k = 0; k < FP_ROWS; ++k) {
-                    d[k] = key_offset<KW>(key[k], T.kmin64);
+                    d[k] = key_offset<KW>(cur.key[k], T.kmin64);
                     live[k] = live[k] && d[k] <= T.krange;
                     if (ranked) word[k] = live[k] ? T.rbits[d[k] >> 6] : 0ull;
                     else word[k] = live[k] ? (uint64_t)T.present[d[k] >> 5] << (d[k] & 32) : 0ull;      // the 32-bit word at its place in the 64-bit one
@@ -261,7 +268,7 @@ join_filter_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const voi
                     idx[k] = before[k] + (uint32_t)__popcll(lw[k] & lane_lt);
                     if (live[k]) {
                         if (ranked) { S.a[idx[k]] = d[k] >> 6; S.b[idx[k]] = (uint32_t)__popcll(word[k] & ((1ull << (d[k] & 63)) - 1ull)); }
-                        else S.a[idx[k]] = (uint64_t)key[k];
+                        else S.a[idx[k]] = (uint64_t)cur.key[k];
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -295,6 +302,7 @@ join_filter_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const voi
                 if (emit && staging) staging[tile_base + tile_cnt + (uint32_t)__popcll(wd & lane_lt)] = m[k];
                 tile_cnt += (uint32_t)__popcll(wd);
             }
+            cur = nxt;
         }
         if (lane == 0) tile_counts[t] = tile_cnt;
     }
@@ -372,12 +380,19 @@ hipError_t launch_join_filter_probe(const LaunchCfg& cfg, const NarrowJoinTable&
     const int64_t need = (n_tiles + BLOCK / 64 - 1) / (BLOCK / 64);
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;
-    if (key_width == 4)
-        hipLaunchKernelGGL(join_filter_probe_kernel<4>, dim3((unsigned)grid), dim3(BLOCK), 0, cfg.stream, T, F, rkeys, rsel, n_right,
-                           right_outer ? 1 : 0, bitmap, tile_counts, staging, matched);
-    else
-        hipLaunchKernelGGL(join_filter_probe_kernel<8>, dim3((unsigned)grid), dim3(BLOCK), 0, cfg.stream, T, F, rkeys, rsel, n_right,
-                           right_outer ? 1 : 0, bitmap, tile_counts, staging, matched);
+#define BHIP_PROBE(KW_, NF_)                                                                                                          \
+    hipLaunchKernelGGL((join_filter_probe_kernel<KW_, NF_>), dim3((unsigned)grid), dim3(BLOCK), 0, cfg.stream, T, F, rkeys, rsel, n_right,    \
+                       right_outer ? 1 : 0, bitmap, tile_counts, staging, matched)
+    if (key_width == 4) {
+        if (F.n == 0) BHIP_PROBE(4, 0);
+        else if (F.n == 1) BHIP_PROBE(4, 1);
+        else BHIP_PROBE(4, JOIN_FILTER_MAX);
+    } else {
+        if (F.n == 0) BHIP_PROBE(8, 0);
+        else if (F.n == 1) BHIP_PROBE(8, 1);
+        else BHIP_PROBE(8, JOIN_FILTER_MAX);
+    }
+#undef BHIP_PROBE
     return hipGetLastError();
 }
 

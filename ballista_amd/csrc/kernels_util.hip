@@ -600,6 +600,20 @@ pack_buffers_kernel(PackDesc d, uint8_t* out) {
     uint8_t* dst = out + d.dst[b];
     for (uint32_t i = threadIdx.x; i < d.bytes[b]; i += BLOCK) dst[i] = src[i];
 }
+// host notification without a runtime wait: copy up to 56 bytes to a pinned host slot, then publish a sequence number
+// (system-scope release) the host spins on — what stands behind read_device() / stream_wait() in host/core.hpp
+__global__ void publish_kernel(const uint32_t* __restrict__ src, int n_words, volatile uint32_t* payload, volatile uint64_t* seq_word, uint64_t seq) {
+    for (int i = 0; i < n_words; ++i) payload[i] = src[i];
+    __threadfence_system();
+    *seq_word = seq;
+}
+hipError_t launch_publish(hipStream_t stream, const void* src, int n_words, void* slot, uint64_t seq) {
+    auto w = static_cast<volatile uint64_t*>(slot);
+    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(1), 0, stream, static_cast<const uint32_t*>(src), n_words,
+                       reinterpret_cast<volatile uint32_t*>(w + 1), w, seq);
+    return hipGetLastError();
+}
+
 hipError_t launch_pack_buffers(const LaunchCfg& cfg, const PackDesc& d, uint8_t* out) {
     if (d.n == 0) return hipSuccess;
     hipLaunchKernelGGL(pack_buffers_kernel, dim3(d.n), dim3(BLOCK), 0, cfg.stream, d, out);

@@ -75,6 +75,8 @@ struct PackDesc {
     uint32_t bytes[PACK_MAX];
     uint32_t dst[PACK_MAX];
 };
+// one-thread kernel: n_words 4-byte words from src to the slot's payload (byte 8 on), then its first 8 bytes = seq with system-scope release (pinned host slot)
+hipError_t launch_publish(hipStream_t stream, const void* src, int n_words, void* slot, uint64_t seq);
 hipError_t launch_pack_buffers(const LaunchCfg& cfg, const PackDesc& d, uint8_t* out);
 
 constexpr int EMIT_BATCH_MAX = 16;

@@ -97,3 +97,79 @@ def test_q6_whole_equals_sum_of_halves(big_ctx):
     cnt = ba.HashAggregateExec(ba.plan.PARTIAL, [], [E.Count(E.lit(1, E.UINT8), "n")],
                                ba.FilterExec(tpch.q6_predicate(tpch.LINEITEM_SCHEMA), ba.MemoryExec([[whole]], ctx))).collect()
     assert cnt[0].to_pydict()["n[count]"][0] == sel
+
+
+def _q3_tables(ctx):
+    dims = tpch.dimension_tables(ctx, SF)
+    n = tpch.table_rows(SF)
+    orders = ba.plan.tpch_orders(ctx, SF, tpch.SEED, 0, n["orders"])
+    return dims["customer"], orders, n
+
+
+def test_q3_sf100_join_counts_and_halves(big_ctx):
+    """Q3 at SF100 (two hash joins, 1.13 M groups, sort), properties no oracle run is needed for:
+      * the rows the order-key join emits == the lineitem rows whose key is among the surviving orders, counted on an
+        independent path (Inner join against the bare key list + COUNT, no aggregate-over-join pruning, CAS table forced off/on is
+        not involved: a different operator shape);
+      * whole table == Final merge of partials over two lineitem halves: same groups, revenue within 1e-9;
+      * ORDER BY revenue DESC, o_orderdate; every group key is a surviving order; group count == distinct matched orders."""
+    ctx = big_ctx
+    cust, orders, n = _q3_tables(ctx)
+    m = lambda b: ba.MemoryExec([[b]], ctx)
+    li = ba.plan.tpch_lineitem(ctx, SF, tpch.SEED, 0, N)
+    res = tpch.q3_plan(m(cust), m(orders), m(li)).collect()
+    n_groups = sum(b.num_rows for b in res)
+    assert 1_000_000 < n_groups < 1_300_000
+    # sortedness on the device result: revenue descending (ties by date ascending)
+    rev = np.concatenate([np.asarray(b.column([c[0] for c in b.schema()].index("revenue"))[1]) for b in res])
+    dat = np.concatenate([np.asarray(b.column([c[0] for c in b.schema()].index("o_orderdate"))[1]) for b in res])
+    assert np.all((rev[:-1] > rev[1:]) | ((rev[:-1] == rev[1:]) & (dat[:-1] <= dat[1:])))
+    keys = np.concatenate([np.asarray(b.column([c[0] for c in b.schema()].index("l_orderkey"))[1]) for b in res])
+    assert len(np.unique(keys)) == n_groups                                   # one group per order key
+
+    # independent count of the join's output rows and of its distinct keys
+    j1 = tpch.q3_build_side(m(cust), m(orders))
+    key_only = ba.ProjectionExec([(col("o_orderkey"), "o_orderkey")], j1)
+    probe = ba.ProjectionExec([(col("l_orderkey"), "l_orderkey")], ba.FilterExec(E.coerce(col("l_shipdate") > E.date32("1995-03-15"), tpch.LINEITEM_SCHEMA), m(li)))
+    joined = ba.HashJoinExec(key_only, probe, [("o_orderkey", "l_orderkey")], ba.plan.INNER)
+    cnt = ba.HashAggregateExec(ba.plan.PARTIAL, [], [E.Count(E.lit(1, E.UINT8), "n")], joined).collect()[0].to_pydict()["n[count]"][0]
+    per_key = ba.HashAggregateExec(ba.plan.PARTIAL, [(col("l_orderkey"), "k")], [E.Count(E.lit(1, E.UINT8), "n")], joined).collect()
+    assert sum(b.num_rows for b in per_key) == n_groups
+    assert sum(int(np.sum(np.asarray(b.column(1)[1]))) for b in per_key) == cnt
+    assert 25_000_000 < cnt < 40_000_000                                      # ~10 % of the 324 M lineitems that pass the date filter
+    # every result key is one of the surviving orders: an Inner join of the result with the build keys keeps every row
+    back = ba.HashJoinExec(key_only, ba.ProjectionExec([(col("l_orderkey"), "l_orderkey")], ba.MemoryExec([res], ctx)), [("o_orderkey", "l_orderkey")], ba.plan.INNER)
+    assert sum(b.num_rows for b in back.collect()) == n_groups
+
+    # whole == merge of halves
+    half = N // 2 + 777
+    a = ba.plan.tpch_lineitem(ctx, SF, tpch.SEED, 0, half)
+    b = ba.plan.tpch_lineitem(ctx, SF, tpch.SEED, half, N - half)
+    del li
+    split = tpch.q3_final(tpch.q3_partial(tpch.q3_build_side(m(cust), m(orders)), tpch.q3_probe_side(ba.MemoryExec([[a], [b]], ctx)))).collect()
+    assert sum(x.num_rows for x in split) == n_groups
+    rev2 = np.concatenate([np.asarray(x.column([c[0] for c in x.schema()].index("revenue"))[1]) for x in split])
+    keys2 = np.concatenate([np.asarray(x.column([c[0] for c in x.schema()].index("l_orderkey"))[1]) for x in split])
+    o1, o2 = np.argsort(keys, kind="stable"), np.argsort(keys2, kind="stable")
+    assert np.array_equal(keys[o1], keys2[o2])
+    assert np.allclose(rev[o1], rev2[o2], rtol=1e-9, atol=0)
+
+
+def test_q3_is_bit_reproducible_run_to_run(big_ctx):
+    """two executions of the same plan over the same tables give bit-identical revenue sums and the same row order
+    (fixed-order reductions; the join emits in probe order, the aggregate sums each group in row order)"""
+    ctx = big_ctx
+    sf = 1.0
+    n = tpch.table_rows(sf)
+    dims = tpch.dimension_tables(ctx, sf)
+    m = lambda b: ba.MemoryExec([[b]], ctx)
+    orders = ba.plan.tpch_orders(ctx, sf, tpch.SEED, 0, n["orders"])
+    li = ba.plan.tpch_lineitem(ctx, sf, tpch.SEED, 0, n["lineitem"])
+    runs = []
+    for _ in range(3):
+        res = tpch.fresh(tpch.q3_plan(m(dims["customer"]), m(orders), m(li))).collect()
+        rev = np.concatenate([np.asarray(b.column(1)[1]) for b in res])
+        key = np.concatenate([np.asarray(b.column(0)[1]) for b in res])
+        runs.append((rev.view(np.uint64).copy(), key.copy()))
+    for r, k in runs[1:]:
+        assert np.array_equal(k, runs[0][1]) and np.array_equal(r, runs[0][0])
