@@ -10,6 +10,6 @@ from . import expr, plan, tpch  # noqa: F401
 from ._lib import (BallistaError, ExecutionError, HipError, NotImplementedOnGpu, PlanError, LIB_PATH)  # noqa: F401
 from .plan import (Context, RecordBatch, RecordBatchStream, ExecutionPlan, Partitioning, MemoryExec, FilterExec,  # noqa: F401
                    ProjectionExec, HashAggregateExec, HashJoinExec, SortExec, RepartitionExec, CoalesceBatchesExec,
-                   MergeExec, GlobalLimitExec, LocalLimitExec, ArrowStreamExec)
+                   MergeExec, GlobalLimitExec, LocalLimitExec, ArrowStreamExec, ParquetExec, IpcFileExec)
 
 __version__ = "0.1.0"

@@ -107,6 +107,7 @@ SYMBOLS = {
     "bhip_plan_memory": (C.c_int32, [_P, C.c_int32, C.POINTER(C.c_int32), _PP, _PP]),
     "bhip_plan_arrow_stream": (C.c_int32, [_P, _P, _PP]),
     "bhip_plan_arrow_streams": (C.c_int32, [_P, C.c_int32, _PP, _PP]),
+    "bhip_plan_parquet": (C.c_int32, [_P, C.c_int32, C.POINTER(C.c_char_p), C.c_int32, C.POINTER(C.c_uint32), C.c_int32, _PP]),
     "bhip_plan_empty": (C.c_int32, [_P, C.c_int32, C.POINTER(ColumnDesc), C.c_int32, _PP]),
     "bhip_plan_filter": (C.c_int32, [_P, C.POINTER(Expr), _PP]),
     "bhip_plan_projection": (C.c_int32, [_P, C.c_int32, C.POINTER(Expr), C.POINTER(C.c_char_p), _PP]),

@@ -83,7 +83,8 @@ bhip_status bhip_ctx_kernel_stats(bhip_ctx* ctx, int32_t reset, char* buf, size_
     std::string text;
     for (auto& kv : ctx->p->kernel_stats(reset != 0)) {
         char line[256];
-        snprintf(line, sizeof line, "%s\t%.6f\t%llu\n", kv.first.c_str(), kv.second.ms, (unsigned long long)kv.second.launches);
+        snprintf(line, sizeof line, "%s\t%.6f\t%llu\t%llu\n", kv.first.c_str(), kv.second.ms, (unsigned long long)kv.second.launches,
+                 (unsigned long long)kv.second.bytes);
         text += line;
     }
     if (text.size() + 1 > cap) fail(BHIP_EINVAL, "bhip_ctx_kernel_stats: buffer too small");
@@ -321,6 +322,18 @@ bhip_status bhip_plan_local_limit(bhip_plan* input, int64_t limit, bhip_plan** o
     BHIP_API_BEGIN
     need(out, "out");
     *out = wrap_plan(std::make_shared<LimitExec>(plan_of(input, "input"), limit, false));
+    BHIP_API_END
+}
+
+bhip_status bhip_plan_parquet(bhip_ctx* ctx, int32_t n_files, const char* const* paths, int32_t n_projection, const uint32_t* projection,
+                              int32_t num_partitions, bhip_plan** out) {
+    BHIP_API_BEGIN
+    need(ctx, "ctx"); need(paths, "paths"); need(out, "out");
+    std::vector<std::string> files;
+    for (int i = 0; i < n_files; ++i) { need(paths[i], "path"); files.push_back(paths[i]); }
+    std::vector<uint32_t> proj;
+    if (n_projection > 0) { need(projection, "projection"); proj.assign(projection, projection + n_projection); }
+    *out = wrap_plan(make_parquet_exec(ctx->p, files, proj, n_projection >= 0 && projection != nullptr, num_partitions));
     BHIP_API_END
 }
 

@@ -246,9 +246,9 @@ hipEvent_t Context::timing_event() {
     return e;
 }
 
-void Context::push_timed(hipEvent_t a, hipEvent_t b, const char* name) {
+void Context::push_timed(hipEvent_t a, hipEvent_t b, const char* name, uint64_t bytes) {
     std::lock_guard<std::mutex> g(mu_);
-    pending_timed_.push_back({a, b, name});
+    pending_timed_.push_back({a, b, name, bytes});
 }
 
 std::map<std::string, Context::KernelStat> Context::kernel_stats(bool reset) {
@@ -260,6 +260,7 @@ std::map<std::string, Context::KernelStat> Context::kernel_stats(bool reset) {
             auto& st = k_stats_[p.name];
             st.ms += t;
             st.launches += 1;
+            st.bytes += p.bytes;
         }
         event_pool_.push_back(p.a);
         event_pool_.push_back(p.b);

@@ -82,8 +82,8 @@ public:
     bool timing_enabled() const { return timing_ > 0; }
     int timing_level() const { return timing_; }
     // per-kernel-name totals (BHIP_KERNEL_TIMING=1): event pairs queued by KernelTimer are resolved when read
-    struct KernelStat { double ms = 0; uint64_t launches = 0; };
-    void push_timed(hipEvent_t a, hipEvent_t b, const char* name);
+    struct KernelStat { double ms = 0; uint64_t launches = 0; uint64_t bytes = 0; };    // bytes: algorithmic bytes of the timed launches
+    void push_timed(hipEvent_t a, hipEvent_t b, const char* name, uint64_t bytes = 0);
     hipEvent_t timing_event();
     std::map<std::string, KernelStat> kernel_stats(bool reset);
 
@@ -104,7 +104,7 @@ private:
     double k_ms_ = 0;
     uint64_t k_launches_ = 0;
     std::string k_name_;
-    struct PendingTimed { hipEvent_t a, b; const char* name; };
+    struct PendingTimed { hipEvent_t a, b; const char* name; uint64_t bytes; };
     std::vector<PendingTimed> pending_timed_;
     std::vector<hipEvent_t> event_pool_;
     std::map<std::string, KernelStat> k_stats_;
@@ -126,7 +126,8 @@ struct KernelTimer {
     hipEvent_t a = nullptr, b = nullptr;
     // rows: what the launch covers.  BHIP_KERNEL_TIMING=1 times launches over >= 2^18 rows only (an event pair per tiny
     // launch would stretch the small-launch tail it is there to measure); =2 times every launch
-    KernelTimer(const Exec& e, const char* n, int64_t rows = -1) : ex(e), name(n) {
+    uint64_t bytes = 0;
+    KernelTimer(const Exec& e, const char* n, int64_t rows = -1, uint64_t algorithmic_bytes = 0) : ex(e), name(n), bytes(algorithmic_bytes) {
         const int level = ex.ctx->timing_level();
         if (level <= 0 || (level == 1 && rows < (1 << 18))) return;
         a = ex.ctx->timing_event();
@@ -136,7 +137,7 @@ struct KernelTimer {
     void stop() {
         if (!a) return;
         hipEventRecord(b, ex.stream);
-        ex.ctx->push_timed(a, b, name);
+        ex.ctx->push_timed(a, b, name, bytes);
         a = b = nullptr;
     }
     ~KernelTimer() { stop(); }
@@ -144,6 +145,8 @@ struct KernelTimer {
 
 #define TIMED_LAUNCH(ex, name, call) do { ::bhip::KernelTimer _kt((ex), (name)); HIP_CHECK(call); } while (0)
 #define TIMED_LAUNCH_N(ex, name, rows, call) do { ::bhip::KernelTimer _kt((ex), (name), (int64_t)(rows)); HIP_CHECK(call); } while (0)
+// ... with the launch's algorithmic bytes, for the roofline line of bench.py
+#define TIMED_LAUNCH_B(ex, name, rows, bytes, call) do { ::bhip::KernelTimer _kt((ex), (name), (int64_t)(rows), (uint64_t)(bytes)); HIP_CHECK(call); } while (0)
 
 // ---- device buffers -----------------------------------------------------------------------------
 constexpr size_t BUFFER_SLACK = 16;

@@ -16,9 +16,47 @@ struct HashAggTable {
     uint64_t* nvalid;         // [capacity][n_acc]   (only with NULLs)
     uint64_t* rows;           // [capacity]
     int32_t n_acc;
-    int32_t pad;
+    int32_t n_fsum;           // SUM(Float64) accumulators summed in a fixed order (kernels_dagg.hip); 0: all accumulators are atomics
+    // fixed-order Float64 sums: the scan records every row's slot and addends instead of adding atomically
+    uint32_t* rowslot;        // [total rows] slot of the row's group, 0xFFFFFFFF = the row reaches no group
+    double* fvals;            // [n_fsum][total rows]
+    uint64_t total_rows;
+    uint8_t fsum_of_acc[VM_MAX_ACC];   // accumulator -> index into fvals, 0xFF = an atomic accumulator
 };
 struct MergeAccKinds { uint8_t kind[VM_MAX_ACC]; };
+
+// ---- Float64 sums in a fixed order (kernels_dagg.hip) ------------------------------------------------------------------------
+// Atomic adds make a SUM(Float64) depend on the scheduling of the waves; here every group's addends are combined in ROW ORDER:
+//   segments  one wave per 1024-row tile: runs of consecutive rows with the same slot are summed by a segmented scan (a fixed
+//             tree), a run that continues into the next 64-row chunk carries its sum along; every run end leaves a record
+//             (slot, first row, sums) in the tile's staging area and bumps the slot's run count (an integer atomic);
+//   apply     a slot with ONE run takes its sums with a plain store; the runs of the others go to a spill list;
+//   spill     sorted by (slot, first row) and combined left to right, one thread per slot.
+// Input clustered by group (lineitem by order key: Q3) spills only the runs that straddle a tile; unclustered input spills
+// everything and pays a sort — still the same sums, run to run and whatever the grid.
+struct DetSum {
+    const uint32_t* rowslot;
+    const double* fvals;
+    uint64_t total_rows;
+    int32_t n_fsum;
+    int32_t n_acc;
+    uint8_t acc_of_fsum[VM_MAX_ACC];
+    // staging, [n_tiles * 1024] each
+    uint32_t* seg_slot;
+    uint32_t* seg_first;
+    double* seg_sum;          // [n_fsum][n_tiles * 1024]
+    uint32_t* tile_nseg;      // [n_tiles]
+    uint32_t* runs;           // [capacity] runs per slot
+    uint64_t* acc;            // the table's accumulators [capacity][n_acc]
+    // spill
+    uint64_t* spill_key;      // (slot << 32) | first row
+    uint32_t* spill_seg;      // index of the run in the staging area
+    uint32_t* spill_count;
+};
+hipError_t launch_det_segments(const LaunchCfg& cfg, const DetSum& D);
+hipError_t launch_det_apply(const LaunchCfg& cfg, const DetSum& D);
+// sorted_key / sorted_seg: the spill list after a stable sort by key
+hipError_t launch_det_spill_combine(const LaunchCfg& cfg, const DetSum& D, const uint64_t* sorted_key, const uint32_t* sorted_seg, uint32_t n_spill);
 
 hipError_t launch_scan_agg_hash(const LaunchCfg& cfg, const ScanParams& P, const HashAggTable& T, uint32_t row_base,
                                 ScanStatus* status);

@@ -191,6 +191,21 @@ GroupRec* hash_aggregate(const Exec& ex, Temp& tmp, const ScanParams& P0, const 
     for (int i = 0; i < VM_MAX_ACC; ++i) kinds.kind[i] = i < P0.n_acc ? P0.acc[i].kind : (uint8_t)ACC_COUNT_ROWS;
     if (P0.n_acc > 0) TIMED_LAUNCH(ex, "hash_agg_init", launch_hash_agg_init(cfg, T, kinds));
     HIP_CHECK(hipMemsetAsync(status, 0, sizeof(ScanStatus), ex.stream));
+    // SUM(Float64) accumulators are summed in row order after the scan (kernels_dagg.hip); BHIP_AGG_ATOMIC=1: atomic adds
+    // (order of addition left to the scheduler: the same sums to ~1e-16 relative, not bit for bit)
+    static const bool atomic_sums = [] { const char* v = getenv("BHIP_AGG_ATOMIC"); return v && atoi(v) != 0; }();
+    memset(T.fsum_of_acc, 0xFF, sizeof(T.fsum_of_acc));
+    DetSum D;
+    memset(&D, 0, sizeof(D));
+    if (!atomic_sums && total_rows > 0) {
+        for (int a = 0; a < P0.n_acc; ++a)
+            if (P0.acc[a].kind == ACC_SUM_F64) { D.acc_of_fsum[T.n_fsum] = (uint8_t)a; T.fsum_of_acc[a] = (uint8_t)T.n_fsum++; }
+        if (T.n_fsum) {
+            T.total_rows = (uint64_t)total_rows;
+            T.rowslot = tmp.get<uint32_t>((size_t)total_rows);
+            T.fvals = tmp.get<double>((size_t)total_rows * T.n_fsum);
+        }
+    }
     uint32_t row_base = 0;
     for (auto& b : inputs) {
         ScanParams P = P0;
@@ -198,6 +213,35 @@ GroupRec* hash_aggregate(const Exec& ex, Temp& tmp, const ScanParams& P0, const 
         TIMED_LAUNCH_N(ex, "scan_keys", b->n_rows, launch_scan_keys(cfg, P, keys + 2ull * row_base, nullptr, nullptr, status));
         TIMED_LAUNCH_N(ex, "scan_agg_hash", b->n_rows, launch_scan_agg_hash(cfg, P, T, row_base, status));
         row_base += (uint32_t)b->n_rows;
+    }
+    if (T.n_fsum) {
+        const size_t n_tiles = ((size_t)total_rows + 1023) / 1024, stage_n = n_tiles * 1024;
+        D.rowslot = T.rowslot;
+        D.fvals = T.fvals;
+        D.total_rows = T.total_rows;
+        D.n_fsum = T.n_fsum;
+        D.n_acc = T.n_acc;
+        D.seg_slot = tmp.get<uint32_t>(stage_n);
+        D.seg_first = tmp.get<uint32_t>(stage_n);
+        D.seg_sum = tmp.get<double>(stage_n * T.n_fsum);
+        D.tile_nseg = tmp.get<uint32_t>(n_tiles);
+        D.runs = tmp.get<uint32_t>(cap);
+        D.acc = T.acc;
+        D.spill_key = tmp.get<uint64_t>(stage_n);
+        D.spill_seg = tmp.get<uint32_t>(stage_n);
+        D.spill_count = tmp.get<uint32_t>(2);
+        HIP_CHECK(hipMemsetAsync(D.runs, 0, cap * 4, ex.stream));
+        HIP_CHECK(hipMemsetAsync(D.spill_count, 0, 8, ex.stream));
+        TIMED_LAUNCH_N(ex, "det_segments", total_rows, launch_det_segments(cfg, D));
+        TIMED_LAUNCH_N(ex, "det_apply", total_rows, launch_det_apply(cfg, D));
+        const uint32_t n_spill = read_device(ex, D.spill_count);
+        if (n_spill) {
+            // runs of groups that have several: ordered by (slot, first row), then added up left to right
+            BufferPtr kb = std::make_shared<Buffer>(ex.ctx, D.spill_key, (size_t)n_spill * 8), pb2 = std::make_shared<Buffer>(ex.ctx, D.spill_seg, (size_t)n_spill * 4);
+            radix_sort_pairs(ex, kb, pb2, (int64_t)n_spill);
+            TIMED_LAUNCH_N(ex, "det_spill_combine", n_spill, launch_det_spill_combine(cfg, D, kb->as<uint64_t>(), pb2->as<uint32_t>(), n_spill));
+            stream_wait(ex);                 // kb / pb2 may be buffers of the sort: released here
+        }
     }
     // used slots -> dense records (slot order: deterministic for a given input)
     uint32_t* flags = tmp.get<uint32_t>(cap);

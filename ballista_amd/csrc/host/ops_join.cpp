@@ -487,7 +487,8 @@ StreamPtr HashJoinExec::execute_needed(int partition, const Exec& ex, const std:
             uint64_t* total = tmp.get<uint64_t>(1);
             void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes(n_tiles));
             uint32_t* staging = need_left ? tmp.get<uint32_t>((size_t)n_tiles * SEL_TILE) : nullptr;
-            TIMED_LAUNCH_N(ex, "join_filter_probe", n,
+            // algorithmic bytes: the predicate columns and the key column once, one selection bit per row
+            TIMED_LAUNCH_B(ex, "join_filter_probe", n, (uint64_t)n * (uint64_t)(bs->narrow_width + 4 * F.n) + (uint64_t)n / 8,
                            launch_join_filter_probe(cfg, bs->ntable, F, kc.data->ptr(), bs->narrow_width,
                                                     kc.validity ? kc.validity->as<uint64_t>() : nullptr, (uint32_t)n, right_outer, bitmap,
                                                     tile_counts, staging, left_outer ? matched->as<uint32_t>() : nullptr));

@@ -269,6 +269,9 @@ private:
     std::shared_ptr<SplitCache> cache_;
 };
 
+// ParquetExec (parquet.cpp): one partition per chunk of files, one batch per row group
+PlanPtr make_parquet_exec(const ContextPtr& ctx, const std::vector<std::string>& files, const std::vector<uint32_t>& projection, bool has_projection,
+                          int num_partitions);
 // the wire plan (proto.cpp): protobuf PhysicalPlanNode -> operator tree; ctx may be null (inspection only)
 PlanPtr plan_from_proto(const ContextPtr& ctx, const void* bytes, size_t len, bhip_leaf_resolver resolver, void* user);
 ExprPtr expr_from_proto(const void* bytes, size_t len);

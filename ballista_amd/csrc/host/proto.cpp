@@ -681,8 +681,13 @@ struct Decoder {
             if (!files.empty() || L.path.compare(0, 6, "mem://") != 0)
                 return std::make_shared<TblScanExec>(ctx, L.path, files, L.file_schema, L.projection, L.has_projection);
         }
-        if (L.kind == BHIP_LEAF_PARQUET_SCAN)
-            fail(BHIP_ENOTIMPL, "ParquetExec: the file schema is not part of the wire plan; resolve this leaf (bhip_leaf_resolver)");
+        if (L.kind == BHIP_LEAF_PARQUET_SCAN) {
+            // the file schema is not part of the wire plan: it is read from the files' footers, so this leaf needs the files —
+            // and a device context to put their rows on
+            if (!ctx) fail(BHIP_ENOTIMPL, "ParquetExec: without a device context the leaf cannot be built (its schema lives in the files); "
+                                          "resolve it (bhip_leaf_resolver) or pass a context");
+            return make_parquet_exec(ctx, L.filenames, L.projection, L.has_projection, (int)L.num_partitions);
+        }
         static const char* ops[] = {"", "CsvExec", "ParquetExec", "ShuffleReaderExec", "UnresolvedShuffleExec"};
         int parts = 1;
         if (L.kind == BHIP_LEAF_SHUFFLE_READER) parts = 1;

@@ -61,12 +61,16 @@ scan_agg_hash_kernel(const ScanParams P, const HashAggTable T, uint32_t row_base
             const int idx = r * BLOCK + tid;
             const int64_t row = base + idx;
             bool live = row < P.n_rows;
-            if (live && P.pred_slot >= 0) live = L.bvals[P.pred_slot * TILE + idx] & 1;
-            if (!live) continue;
             const uint32_t grow = row_base + (uint32_t)row;
+            if (live && P.pred_slot >= 0) live = L.bvals[P.pred_slot * TILE + idx] & 1;
+            if (!live) {
+                if (T.n_fsum && row < P.n_rows) T.rowslot[grow] = 0xFFFFFFFFu;
+                continue;
+            }
             const Key128 key{T.keys128[2ull * grow], T.keys128[2ull * grow + 1]};
             const uint32_t slot = table_upsert(T.owner, T.mask, T.keys128, key, grow);
             atomicAdd(reinterpret_cast<unsigned long long*>(&T.rows[slot]), 1ull);
+            if (T.n_fsum) T.rowslot[grow] = slot;
             for (int a = 0; a < P.n_acc; ++a) {
                 const AccSpec sp = P.acc[a];
                 uint64_t v = 1;
@@ -77,6 +81,11 @@ scan_agg_hash_kernel(const ScanParams P, const HashAggTable T, uint32_t row_base
                     if (NULLS) k = L.vvalid[sp.slot * TILE + idx];
                 }
                 if (sp.kind == ACC_COUNT_VALID || sp.kind == ACC_COUNT_VALID_B) { v = k ? 1 : 0; k = true; }
+                if (T.n_fsum && T.fsum_of_acc[a] != 0xFF) {       // summed later, in row order: record the addend (NULL adds +0.0)
+                    T.fvals[(size_t)T.fsum_of_acc[a] * T.total_rows + grow] = k ? u2d(v) : 0.0;
+                    if (NULLS && k) atomicAdd(reinterpret_cast<unsigned long long*>(&T.nvalid[(size_t)slot * T.n_acc + a]), 1ull);
+                    continue;
+                }
                 if (!k) continue;
                 atomic_acc(&T.acc[(size_t)slot * T.n_acc + a], v, sp.kind);
                 if (NULLS) atomicAdd(reinterpret_cast<unsigned long long*>(&T.nvalid[(size_t)slot * T.n_acc + a]), 1ull);

@@ -600,6 +600,61 @@ pack_buffers_kernel(PackDesc d, uint8_t* out) {
     uint8_t* dst = out + d.dst[b];
     for (uint32_t i = threadIdx.x; i < d.bytes[b]; i += BLOCK) dst[i] = src[i];
 }
+// ---- Parquet value decode -------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK)
+pq_expand_runs_kernel(const PqRun* __restrict__ runs, uint32_t n_runs, const uint8_t* __restrict__ page, int bw, uint32_t n_values,
+                      uint32_t limit, uint32_t* __restrict__ out) {
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n_values; i += gridDim.x * BLOCK) {
+        uint32_t lo = 0, hi = n_runs;                   // last run with out_start <= i
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (runs[mid].out_start <= i) lo = mid; else hi = mid;
+        }
+        const PqRun r = runs[lo];
+        uint32_t v;
+        if (!r.packed) v = r.value;
+        else {
+            const uint64_t bit = (uint64_t)(i - r.out_start) * (uint64_t)bw;
+            const uint8_t* p = page + r.value + (bit >> 3);
+            uint64_t w = 0;                              // up to 32 + 7 bits
+            for (int b = 0; b < 5; ++b) w |= (uint64_t)p[b] << (8 * b);
+            v = (uint32_t)((w >> (bit & 7)) & ((bw >= 32) ? 0xFFFFFFFFull : ((1ull << bw) - 1ull)));
+        }
+        out[i] = v < limit ? v : 0xFFFFFFFFu;
+    }
+}
+hipError_t launch_pq_expand_runs(const LaunchCfg& cfg, const PqRun* runs, uint32_t n_runs, const uint8_t* page, int bit_width, uint32_t n_values,
+                                 uint32_t limit, uint32_t* out) {
+    if (n_values == 0 || n_runs == 0) return hipSuccess;
+    hipLaunchKernelGGL(pq_expand_runs_kernel, dim3(grid_for(cfg, n_values)), dim3(BLOCK), 0, cfg.stream, runs, n_runs, page, bit_width, n_values,
+                       limit, out);
+    return hipGetLastError();
+}
+
+template <class T>
+__global__ void __launch_bounds__(BLOCK)
+pq_scatter_valid_kernel(const uint64_t* __restrict__ validity, const uint32_t* __restrict__ prefix, const T* __restrict__ src, int64_t n,
+                        T* __restrict__ dst, T null_value) {
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+        const uint64_t w = validity[i >> 6];
+        const int b = (int)(i & 63);
+        dst[i] = ((w >> b) & 1ull) ? src[prefix[i >> 6] + (uint32_t)__popcll(w & ((1ull << b) - 1ull))] : null_value;
+    }
+}
+hipError_t launch_pq_scatter_valid(const LaunchCfg& cfg, const uint64_t* validity, const uint32_t* word_prefix, const void* src, int width,
+                                   int64_t n, void* dst, int null_index) {
+    if (n == 0) return hipSuccess;
+    if (width == 4)
+        hipLaunchKernelGGL(pq_scatter_valid_kernel<uint32_t>, dim3(grid_for(cfg, n)), dim3(BLOCK), 0, cfg.stream, validity, word_prefix,
+                           static_cast<const uint32_t*>(src), n, static_cast<uint32_t*>(dst), null_index ? 0xFFFFFFFFu : 0u);
+    else if (width == 8)
+        hipLaunchKernelGGL(pq_scatter_valid_kernel<uint64_t>, dim3(grid_for(cfg, n)), dim3(BLOCK), 0, cfg.stream, validity, word_prefix,
+                           static_cast<const uint64_t*>(src), n, static_cast<uint64_t*>(dst), (uint64_t)0);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 // host notification without a runtime wait: copy up to 56 bytes to a pinned host slot, then publish a sequence number
 // (system-scope release) the host spins on — what stands behind read_device() / stream_wait() in host/core.hpp
 __global__ void publish_kernel(const uint32_t* __restrict__ src, int n_words, volatile uint32_t* payload, volatile uint64_t* seq_word, uint64_t seq) {

@@ -75,6 +75,22 @@ struct PackDesc {
     uint32_t bytes[PACK_MAX];
     uint32_t dst[PACK_MAX];
 };
+// ---- Parquet value decode (host/parquet.cpp) ---------------------------------------------------------------------------------
+// one run of the RLE / bit-packed hybrid (the host parses the run headers, the device expands the runs)
+struct PqRun {
+    uint32_t out_start;     // index of the run's first value in the page
+    uint32_t count;
+    uint32_t packed;        // 1: bit-packed, `value` = byte offset of the run's bits in the page; 0: RLE, `value` = the repeated value
+    uint32_t value;
+};
+// out[i] = i-th value of the page (one thread per value: binary search of its run, bit extraction); values >= limit
+// (a dictionary index outside the dictionary: a corrupt page) are clamped to 0xFFFFFFFF
+hipError_t launch_pq_expand_runs(const LaunchCfg& cfg, const PqRun* runs, uint32_t n_runs, const uint8_t* page, int bit_width, uint32_t n_values,
+                                 uint32_t limit, uint32_t* out);
+// dense values -> rows: dst[i] = valid(i) ? src[rank of i among the valid rows] : (null_index ? 0xFFFFFFFF : 0); width 4 or 8
+hipError_t launch_pq_scatter_valid(const LaunchCfg& cfg, const uint64_t* validity, const uint32_t* word_prefix, const void* src, int width,
+                                   int64_t n, void* dst, int null_index);
+
 // one-thread kernel: n_words 4-byte words from src to the slot's payload (byte 8 on), then its first 8 bytes = seq with system-scope release (pinned host slot)
 hipError_t launch_publish(hipStream_t stream, const void* src, int n_words, void* slot, uint64_t seq);
 hipError_t launch_pack_buffers(const LaunchCfg& cfg, const PackDesc& d, uint8_t* out);

@@ -75,13 +75,13 @@ class Context:
         return L.lib().bhip_ctx_kernel_name(self._h).decode()
 
     def kernel_stats(self, reset=False):
-        """{kernel name: (total ms, launches)} of every kernel timed since the last reset (BHIP_KERNEL_TIMING=1)"""
+        """{kernel name: (total ms, launches, algorithmic bytes)} of every kernel timed since the last reset (BHIP_KERNEL_TIMING=1)"""
         buf = C.create_string_buffer(1 << 16)
         L.check(L.lib().bhip_ctx_kernel_stats(self._h, 1 if reset else 0, buf, len(buf)))
         out = {}
         for line in buf.value.decode().splitlines():
-            name, ms, n = line.split("\t")
-            out[name] = (float(ms), int(n))
+            name, ms, n, nbytes = line.split("\t")
+            out[name] = (float(ms), int(n), int(nbytes))
         return out
 
     def __del__(self):
@@ -663,6 +663,20 @@ class ArrowStreamExec(ExecutionPlan):
                 if cs.release:                         # not taken over (an error): release our export
                     C.CFUNCTYPE(None, C.c_void_p)(cs.release)(C.addressof(cs))
         super().__init__(h, ctx)
+
+
+class ParquetExec(ExecutionPlan):
+    """ParquetExec::try_from_files(filenames, projection, None, batch_size, num_partitions)  (from_proto.rs:111-121): the files dealt
+    out to `num_partitions` partitions, one batch per row group; projection = column indices (None: all)."""
+
+    def __init__(self, filenames: Sequence[str], ctx: Context, projection: Optional[Sequence[int]] = None, num_partitions: int = 1):
+        arr = (C.c_char_p * len(filenames))(*[f.encode() for f in filenames])
+        proj = (C.c_uint32 * max(1, len(projection or [])))(*(projection or []))
+        h = C.c_void_p()
+        L.check(L.lib().bhip_plan_parquet(ctx._h, len(filenames), arr, len(projection) if projection is not None else -1,
+                                          proj if projection is not None else None, num_partitions, C.byref(h)))
+        super().__init__(h, ctx)
+        self.filenames, self.projection = list(filenames), projection
 
 
 class FilterExec(ExecutionPlan):

@@ -237,10 +237,11 @@ def main():
     if rank == 0:
         rows_job = n["lineitem"]
         rows_launch = W.rows_local("lineitem")                      # rows one launch of the dominant kernel covers
-        dom = max(kstats.items(), key=lambda kv: kv[1][0]) if kstats else ("", (0.0, 0))
-        dom_name, (dom_ms, dom_n) = dom
+        dom = max(kstats.items(), key=lambda kv: kv[1][0]) if kstats else ("", (0.0, 0, 0))
+        dom_name, (dom_ms, dom_n, dom_bytes) = dom
         kernel_ms = dom_ms / max(dom_n, 1)
-        algo_launch = W.algorithmic_bytes_of_kernel(dom_name, key_bytes)
+        # algorithmic bytes of ONE launch: stated by the call site (join kernels) or rows x bytes/row of the fused scan
+        algo_launch = dom_bytes / max(dom_n, 1) if dom_bytes else W.algorithmic_bytes_of_kernel(dom_name, key_bytes)
         achieved = algo_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         algo_job = W.algorithmic_bytes(key_bytes)
         out = {

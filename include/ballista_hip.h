@@ -239,6 +239,13 @@ bhip_status bhip_plan_arrow_stream(bhip_ctx* ctx, struct ArrowArrayStream* strea
 /* the same with one stream per output partition of the CPU child (all moved into the plan): partition p of the leaf is
  * streams[p]; a join above drains every partition of its build side, as the reference's collect-left join does */
 bhip_status bhip_plan_arrow_streams(bhip_ctx* ctx, int32_t n_partitions, struct ArrowArrayStream* const* streams, bhip_plan** out);
+/* ParquetExec::try_from_files(filenames, projection, None, batch_size, num_partitions)  :111-121 — the files are dealt out to
+ * `num_partitions` output partitions in chunks; one batch per row group.  projection NULL: every column.  Pages are located
+ * and decompressed (Snappy) on the host, values are decoded on the device (dictionary runs, NULL re-insertion, gathers).
+ * Flat schemas of INT32 / INT64 / DOUBLE / BOOLEAN / BYTE_ARRAY (+ DATE), PLAIN and RLE_DICTIONARY, data pages V1 / V2,
+ * UNCOMPRESSED / SNAPPY; anything else is BHIP_ENOTIMPL. */
+bhip_status bhip_plan_parquet(bhip_ctx* ctx, int32_t n_files, const char* const* paths, int32_t n_projection, const uint32_t* projection,
+                              int32_t num_partitions, bhip_plan** out);
 bhip_status bhip_plan_empty(bhip_ctx* ctx, int32_t n_cols, const bhip_column_desc* schema, int32_t produce_one_row,
                             bhip_plan** out);
 bhip_status bhip_plan_filter(bhip_plan* input, const bhip_expr* predicate, bhip_plan** out);          /* :81-92  */
@@ -403,7 +410,7 @@ bhip_status bhip_tpch_orders(bhip_ctx* ctx, double sf, uint64_t seed, uint64_t r
 /* time (ms, HIP events on the stream the kernels ran on) and launch count of the dominant scan
  * kernel accumulated on this context since the last reset */
 bhip_status bhip_ctx_kernel_time(bhip_ctx* ctx, int32_t reset, double* ms, uint64_t* launches);
-/* every kernel timed since the last reset (BHIP_KERNEL_TIMING=1), one line per kernel: "name\tms\tlaunches\n"
+/* every kernel timed since the last reset (BHIP_KERNEL_TIMING=1), one line per kernel: "name\tms\tlaunches\talgorithmic bytes\n" (bytes: 0 where the call site does not state them)
  * (NUL terminated; BHIP_EINVAL when `cap` is too small).  Waits for the timed launches to finish. */
 bhip_status bhip_ctx_kernel_stats(bhip_ctx* ctx, int32_t reset, char* buf, size_t cap);
 /* name of the kernel those launches ran ("" before the first timed launch); valid until the next call */
