@@ -141,6 +141,14 @@ hipError_t launch_join_filter_probe(const LaunchCfg& cfg, const NarrowJoinTable&
                                     uint32_t* staging, uint32_t* matched);
 hipError_t launch_join_compact_staged(const LaunchCfg& cfg, const uint32_t* staging, const uint64_t* tile_off, uint64_t total,
                                       int64_t n_tiles, uint32_t* out);
+// ---- radix-partitioned join with LDS-resident tables (kernels_radix_join.hip): the measured alternative, BHIP_JOIN_RADIX=1 ----
+// sort keys (partition id << 32) | key + row ids; partition bounds of a sorted side; the per-partition LDS build + probe.
+// flags[0] != 0: a build partition outgrew the LDS table; flags[1] != 0: duplicate build keys.
+hipError_t launch_radix_join_keys(const LaunchCfg& cfg, const uint32_t* keys, uint32_t n, int log2p, uint64_t* out_keys, uint32_t* out_rows);
+hipError_t launch_radix_join_bounds(const LaunchCfg& cfg, const uint64_t* sorted, uint32_t n, uint32_t n_parts, uint32_t* first);
+hipError_t launch_radix_join_lds(const LaunchCfg& cfg, const uint64_t* bkeys, const uint32_t* brows, const uint32_t* bfirst, const uint64_t* pkeys,
+                                 const uint32_t* prows, const uint32_t* pfirst, uint32_t n_parts, uint32_t* partner, uint64_t* bitmap,
+                                 uint32_t* tile_counts, uint32_t* flags);
 hipError_t launch_join_unmatched_flags(const LaunchCfg& cfg, const uint32_t* matched, uint32_t n_left, uint32_t* flags);
 hipError_t launch_compact_flags(const LaunchCfg& cfg, const uint32_t* flags, const uint64_t* offsets, uint32_t n, uint32_t* out);
 

@@ -12,6 +12,7 @@
 #include "hash_kernels.h"
 #include "plan.hpp"
 #include "sop.hpp"
+#include "../sort_kernels.h"
 
 namespace bhip {
 
@@ -25,7 +26,14 @@ struct JoinBuildSide {
     int narrow_width = 0;           // its key bytes (4: Int32 / Date32, 8: Int64 / UInt64)
     BufferPtr slots, present, rbits, rprefix, rperm;
     NarrowJoinTable ntable;
+    // BHIP_JOIN_RADIX=1: the build side in partition order for the LDS join (kernels_radix_join.hip), the A/B partner
+    BufferPtr rj_keys, rj_rows, rj_first;
+    int rj_log2p = -1;
 };
+
+namespace {
+void radix_partition_side(const Exec& ex, const uint32_t* keys, int64_t n, int log2p, BufferPtr& skeys, BufferPtr& srows, BufferPtr& first);
+}
 
 static const char* join_name(int t) { return t == BHIP_JOIN_INNER ? "Inner" : (t == BHIP_JOIN_LEFT ? "Left" : "Right"); }
 
@@ -222,6 +230,14 @@ std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) co
                 bs->ntable.rperm = bs->rperm ? bs->rperm->as<uint32_t>() : nullptr;
                 bs->ntable.krange = (uint32_t)range;
                 bs->narrow = bs->unique = true;
+                static const bool radix_ab = [] { const char* v = getenv("BHIP_JOIN_RADIX"); return v && atoi(v) != 0; }();
+                if (radix_ab && nkw == 4 && !ksel && n < (1ll << 31)) {
+                    int lg = 0;
+                    while ((n >> lg) > 1024 && lg < 16) ++lg;
+                    bs->rj_log2p = lg;
+                    radix_partition_side(ex, kc.data->as<uint32_t>(), n, lg, bs->rj_keys, bs->rj_rows, bs->rj_first);
+                    stream_wait(ex);
+                }
                 cache_->built = bs;
                 return bs;
             }
@@ -294,6 +310,29 @@ static void int_bounds(double lo, double hi, int32_t* lo_i, int32_t* hi_i) {
 }
 
 namespace {
+
+// one side of the radix join in partition order: sort keys (partition id << 32 | key), row ids, partition bounds
+void radix_partition_side(const Exec& ex, const uint32_t* keys, int64_t n, int log2p, BufferPtr& skeys, BufferPtr& srows, BufferPtr& first) {
+    const LaunchCfg cfg = ex.cfg();
+    skeys = make_buffer(ex, (size_t)n * 8 + 8);
+    srows = make_buffer(ex, (size_t)n * 4 + 8);
+    TIMED_LAUNCH_N(ex, "radix_join_keys", n, launch_radix_join_keys(cfg, keys, (uint32_t)n, log2p, skeys->as<uint64_t>(), srows->as<uint32_t>()));
+    if (log2p > 0 && n > 1) {
+        Temp tmp(ex);
+        BufferPtr k2 = make_buffer(ex, (size_t)n * 8 + 8), r2 = make_buffer(ex, (size_t)n * 4 + 8);
+        void* pass_tmp = tmp.get<uint8_t>(radix_sort_temp_bytes(n));
+        for (int byte = 4; byte < 4 + (log2p + 7) / 8; ++byte) {
+            KernelTimer kt(ex, "radix_join_partition_pass", n, (uint64_t)n * 32);
+            HIP_CHECK(radix_pass(cfg, skeys->as<uint64_t>(), srows->as<uint32_t>(), n, byte, k2->as<uint64_t>(), r2->as<uint32_t>(), pass_tmp));
+            kt.stop();
+            std::swap(skeys, k2);
+            std::swap(srows, r2);
+        }
+        stream_wait(ex);
+    }
+    first = make_buffer(ex, ((size_t)(1u << log2p) + 2) * 4);
+    TIMED_LAUNCH(ex, "radix_join_bounds", launch_radix_join_bounds(cfg, skeys->as<uint64_t>(), (uint32_t)n, 1u << log2p, first->as<uint32_t>()));
+}
 
 // where the probe rows come from: right_ = [ProjectionExec(plain columns)] over [CoalesceBatchesExec]* over [FilterExec] over src.
 // The probe then runs on src's UNFILTERED batches and only the rows that join are ever gathered (late materialisation).
@@ -510,6 +549,46 @@ StreamPtr HashJoinExec::execute_needed(int partition, const Exec& ex, const std:
         ProbeFilter no_filter;
         memset(&no_filter, 0, sizeof(no_filter));
 
+        // ---- A/B partner: radix-partitioned probe side against LDS-resident tables (kernels_radix_join.hip).  false: fall back ----
+        auto process_radix = [&](int64_t n, const Column& kc, const Batch* outsrc, const std::vector<int>* rmap, const uint32_t* remap) -> bool {
+            if (n == 0) return true;
+            if (kc.validity || n >= (1ll << 31)) return false;
+            BufferPtr pk, pr, pf;
+            radix_partition_side(ex, kc.data->as<uint32_t>(), n, bs->rj_log2p, pk, pr, pf);
+            const int64_t n_tiles = (n + SEL_TILE - 1) / SEL_TILE;
+            Temp tmp(ex);
+            uint32_t* partner = tmp.get<uint32_t>((size_t)n + 1);
+            uint64_t* bitmap = tmp.get<uint64_t>((size_t)(n + 63) / 64 + 1);
+            uint32_t* tile_counts = tmp.get<uint32_t>((size_t)n_tiles + 1);
+            uint64_t* tile_off = tmp.get<uint64_t>((size_t)n_tiles + 1);
+            uint64_t* total = tmp.get<uint64_t>(1);
+            uint32_t* flags = tmp.get<uint32_t>(2);
+            void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes(n_tiles));
+            HIP_CHECK(hipMemsetAsync(bitmap, 0, ((size_t)(n + 63) / 64 + 1) * 8, ex.stream));
+            HIP_CHECK(hipMemsetAsync(tile_counts, 0, ((size_t)n_tiles + 1) * 4, ex.stream));
+            HIP_CHECK(hipMemsetAsync(flags, 0, 8, ex.stream));
+            TIMED_LAUNCH_N(ex, "radix_join_lds", n,
+                           launch_radix_join_lds(cfg, bs->rj_keys->as<uint64_t>(), bs->rj_rows->as<uint32_t>(), bs->rj_first->as<uint32_t>(), pk->as<uint64_t>(),
+                                                 pr->as<uint32_t>(), pf->as<uint32_t>(), 1u << bs->rj_log2p, partner, bitmap, tile_counts, flags));
+            HIP_CHECK(exclusive_scan_u32_u64(ex.stream, tile_counts, n_tiles, tile_off, false, total, scan_tmp));
+            if (read_device(ex, flags) != 0) return false;               // a build partition outgrew the LDS table
+            const uint64_t n_out = read_device(ex, total);
+            if (n_out == 0) return true;
+            uint32_t* ridx = tmp.get<uint32_t>((size_t)n_out);
+            uint32_t* lidx = tmp.get<uint32_t>((size_t)n_out);
+            TIMED_LAUNCH_N(ex, "select_indices", n, launch_select_indices(cfg, bitmap, tile_off, n, ridx));
+            TIMED_LAUNCH_N(ex, "take_fixed", n_out, launch_take_fixed(cfg, partner, 4, ridx, (int64_t)n_out, lidx));
+            if (remap) {
+                uint32_t* orig = tmp.get<uint32_t>((size_t)n_out);
+                TIMED_LAUNCH_N(ex, "take_fixed", n_out, launch_take_fixed(cfg, remap, 4, ridx, (int64_t)n_out, orig));
+                ridx = orig;
+            }
+            emit(outsrc, rmap, lidx, ridx, (int64_t)n_out);
+            stream_wait(ex);
+            return true;
+        };
+        const bool radix_mode = bs->narrow && bs->rj_log2p >= 0 && !right_outer && !left_outer;
+
         const ProbeChain chain = probe_chain(self->right_);
         static const bool fused_disabled = [] { const char* v = getenv("BHIP_NO_FUSED_PROBE"); return v && atoi(v) != 0; }();
         if (chain.ok) {
@@ -527,6 +606,20 @@ StreamPtr HashJoinExec::execute_needed(int partition, const Exec& ex, const std:
             while (BatchPtr b = ss->next()) {
                 if (b->n_rows == 0) continue;
                 ProbeFilter F;
+                if (radix_mode) {
+                    // the filtered key column first (FilterExec as it stands), then the partitioned join
+                    const uint32_t* remap = nullptr;
+                    BufferPtr sel;
+                    Column keys = b->cols[key_src[0]];
+                    int64_t n_probe = b->n_rows;
+                    if (chain.pred) {
+                        n_probe = filter_indices(ex, *b, chain.pred, sel);
+                        if (n_probe == 0) continue;
+                        remap = sel->as<uint32_t>();
+                        keys = take_batch_column(ex, b->cols[key_src[0]], remap, n_probe);
+                    }
+                    if (process_radix(n_probe, keys, b.get(), &rmap, remap)) continue;
+                }
                 if (bs->narrow && !fused_disabled && int_ranges_of(chain.pred, *b, F)) {
                     process_fused(b->n_rows, F, b->cols[key_src[0]], b.get(), &rmap, nullptr);
                     continue;

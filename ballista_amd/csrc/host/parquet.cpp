@@ -536,7 +536,18 @@ Column decode_chunk(const Exec& ex, std::ifstream& in, const PqColumn& pc, const
             else g.validity = nullptr;
             c = g;
             c.length = n;
-        } else if (h.encoding == ENC_PLAIN) {
+        } else if (h.encoding == ENC_PLAIN || (h.encoding == ENC_RLE && pc.phys == PQ_BOOLEAN)) {
+            std::vector<uint8_t> rle_bits;
+            if (h.encoding == ENC_RLE) {
+                // BOOLEAN of data page V2: [4-byte length] + RLE / bit-packed hybrid of width 1 -> the dense bit vector PLAIN would carry
+                if (vals_len < 4) fail(BHIP_EEXEC, "Parquet: truncated RLE BOOLEAN page");
+                uint32_t bl;
+                memcpy(&bl, vals, 4);
+                if ((size_t)bl + 4 > vals_len) fail(BHIP_EEXEC, "Parquet: RLE BOOLEAN data runs past the page");
+                decode_def_levels(vals + 4, vals + 4 + bl, n_valid, rle_bits);
+                vals = rle_bits.data();
+                vals_len = rle_bits.size();
+            }
             if (pc.phys == PQ_BYTE_ARRAY) {
                 // length-prefixed strings: a sequential walk (host), NULL rows repeat the running offset
                 std::vector<int32_t> off((size_t)n + 1, 0);
