@@ -10,6 +10,7 @@
 // structs (`bhip_ipc_write_file` / `bhip_ipc_open_file`), so it is testable without a GPU against pyarrow in both directions;
 // the device entry points are the existing export / import around it.  Metadata version V5, no compression, no dictionaries
 // (what arrow-rs 4.0's FileWriter produces for the types of this path).  Flatbuffers schema: arrow/format/{Schema,Message,File}.fbs.
+#include <cerrno>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -408,7 +409,7 @@ void ipc_write_file(ArrowArrayStream* stream, const std::string& path, uint64_t*
     try { schema = schema_of_c(csch); } catch (...) { if (csch.release) csch.release(&csch); throw; }
     if (csch.release) csch.release(&csch);
     FILE* f = fopen(path.c_str(), "wb");
-    if (!f) fail(BHIP_EEXEC, "Ballista Error: cannot create " + path);
+    if (!f) fail(BHIP_EEXEC, "Failed to create partition file at " + path + ": " + strerror(errno));       // utils.rs:53-58
     struct Closer { FILE* f; ~Closer() { if (f) fclose(f); } } closer{f};
     int64_t pos = 0;
     pos += write_all(f, "ARROW1\0\0", 8);

@@ -1,7 +1,7 @@
 """Stage outputs on disk: the step right after `plan.execute(partition)` in an executor task and the step right
 before it in the next stage (§8(f) rank 1).
 
-Host-side mirror, in Python over pyarrow, of
+Host-side mirror of
   * `utils::write_stream_to_disk`                       rust/core/src/utils.rs:49-84
   * the ExecutePartition arm of `do_get`                rust/executor/src/flight_service.rs:95-150
     (work_dir/<job>/<stage>/<partition>/data.arrow, reply = 1-row batch {path, partition_stats})
@@ -9,8 +9,8 @@ Host-side mirror, in Python over pyarrow, of
   * the FetchPartition arm / ShuffleReaderExec          rust/executor/src/flight_service.rs:193-228,
                                                         rust/core/src/execution_plans/shuffle_reader.rs:77-103
 so that a GPU stage writes exactly the file an unmodified CPU executor (or the next GPU stage) reads: an
-Arrow IPC *file* with the stream's schema and one message per batch.  Nothing here computes on rows; the
-operators run in the HIP library, batches cross through the Arrow C Data Interface."""
+Arrow IPC *file* with the stream's schema and one message per batch.  The files are written and read by the library
+itself (csrc/host/ipc.cpp); this module only names the paths and frames the `{path, partition_stats}` reply (pyarrow)."""
 from __future__ import annotations
 
 import os
@@ -49,35 +49,12 @@ class PartitionStats:
 
 def write_stream_to_disk(stream, path: str) -> PartitionStats:
     """Drain a RecordBatchStream into an Arrow IPC file; count rows, batches and array bytes (utils.rs:49-84).
+    The file is written by the LIBRARY's own IPC writer (bhip_stream_write_ipc / bhip_ipc_write_file, csrc/host/ipc.cpp).
 
-    `stream`: iterable of ballista_amd.RecordBatch (what ExecutionPlan.execute returns) with `.schema_arrow()`,
-    or an iterable of pyarrow.RecordBatch plus an explicit schema via `stream.schema`."""
-    import pyarrow as pa
-    try:
-        f = open(path, "wb")
-    except OSError as e:
-        raise P.L.ExecutionError(P.L.EEXEC, f"Failed to create partition file at {path}: {e!r}")
-    num_rows = num_batches = num_bytes = 0
-    writer = None
-    with f:
-        if hasattr(stream, "to_arrow_reader"):
-            # a bhip_stream: hand it to pyarrow through the Arrow C Stream Interface (schema + batches)
-            stream = stream.to_arrow_reader()
-        schema = getattr(stream, "schema", None)
-        if schema is not None and not callable(schema):
-            writer = pa.ipc.new_file(f, schema)
-        for batch in stream:
-            pb = batch.to_pyarrow() if hasattr(batch, "to_pyarrow") else batch
-            if writer is None:
-                writer = pa.ipc.new_file(f, pb.schema)
-            num_batches += 1
-            num_rows += pb.num_rows
-            num_bytes += sum(col.nbytes for col in pb.columns)
-            writer.write_batch(pb)
-        if writer is None:
-            raise P.L.ExecutionError(P.L.EEXEC, "cannot write an IPC file without a schema (empty stream of unknown schema)")
-        writer.close()
-    return PartitionStats(num_rows, num_batches, num_bytes)
+    `stream`: a ballista_amd.RecordBatchStream (what ExecutionPlan.execute returns) or a pyarrow.RecordBatchReader."""
+    if hasattr(stream, "write_ipc"):
+        return PartitionStats(**stream.write_ipc(path))
+    return PartitionStats(**P.ipc_write_file(stream, path))
 
 
 def execute_partition(plan: P.ExecutionPlan, job_id: str, stage_id: int, partition: int, work_dir: str):
@@ -100,14 +77,7 @@ def fetch_partition(path: str) -> List:
         return pa.ipc.open_file(src).read_all().to_batches()
 
 
-def shuffle_reader(ctx: P.Context, paths: List[str], schema=None) -> P.MemoryExec:
-    """ShuffleReaderExec (shuffle_reader.rs:55-103): one output partition per input partition file, batches
-    imported to the device through the Arrow C Data Interface."""
-    import pyarrow as pa
-    parts = []
-    for p in paths:
-        batches = fetch_partition(p)
-        if not batches and schema is not None:
-            batches = [pa.RecordBatch.from_pylist([], schema=schema)]
-        parts.append([P.RecordBatch.from_pyarrow(ctx, b) for b in batches])
-    return P.MemoryExec(parts, ctx)
+def shuffle_reader(ctx: P.Context, paths: List[str], schema=None) -> P.ExecutionPlan:
+    """ShuffleReaderExec (shuffle_reader.rs:55-103): one output partition per input partition file, read by the library's own
+    IPC reader (bhip_plan_ipc_files) and imported to the device through the Arrow C Data Interface."""
+    return P.IpcFileExec(paths, ctx)

@@ -167,8 +167,8 @@ def pmc_traffic(kernel, rows, query):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic*.json, written by
     tools/profile_bench.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 runs of this command).  FETCH_SIZE is
     doubled (gfx950 counts wide streaming reads at half, MI355X_MICROARCH.md §HBM).  None when no pass exists for
-    this kernel and launch size — counters cannot be read from inside."""
-    for name in ("pmc_traffic.json", f"pmc_traffic_{query}.json"):
+    this kernel, query and table size — counters cannot be read from inside."""
+    for name in (f"pmc_traffic_{query}.json", "pmc_traffic.json"):
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", name)))
         except (OSError, ValueError):

@@ -1,33 +1,39 @@
 #!/bin/bash
-# rocprofv3 evidence for the bench: per-kernel time (--stats) and HBM traffic (PMC, separate passes).
-# Run on the GPU box from the repo root; summaries land in gpurun_out/prof_*.
+# rocprofv3 evidence for the bench: per-kernel time (--stats) and HBM traffic (PMC, separate passes, counters only with --kernel-trace).
+# Run on the GPU box from the repo root:  QUERY=q1|q6|q3|q5 bash tools/profile_bench.sh ; summaries land in gpurun_out/prof_<query>*.
+# Copy what should be judged into profiles/ (tracked).
 R=$PWD; export TMPDIR=/tmp; cd /tmp
-ARGS="--steps ${STEPS:-5} --warmup 2 --no-cpu-baseline ${EXTRA_ARGS}"
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -- python3 $R/bench.py $ARGS > $R/gpurun_out/prof_stats.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_fetch -- python3 $R/bench.py $ARGS > $R/gpurun_out/prof_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_write -- python3 $R/bench.py $ARGS > $R/gpurun_out/prof_write.log 2>&1
+Q=${QUERY:-q1}
+ARGS="--query $Q --steps ${STEPS:-5} --warmup 2 --no-cpu-baseline ${EXTRA_ARGS}"
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${Q}_stats -- python3 $R/bench.py $ARGS > $R/gpurun_out/prof_${Q}_stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_${Q}_fetch -- python3 $R/bench.py $ARGS > $R/gpurun_out/prof_${Q}_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_${Q}_write -- python3 $R/bench.py $ARGS > $R/gpurun_out/prof_${Q}_write.log 2>&1
 cd $R
-python3 - <<'PY'
-import csv, glob, collections
+QUERY=$Q python3 - <<'PY'
+import csv, glob, collections, json, os, shutil
+q = os.environ["QUERY"]
 def agg(tag, ctr):
     f = glob.glob(f"gpurun_out/{tag}/*/*counter_collection.csv")[0]
-    rows = list(csv.DictReader(open(f)))
     a = collections.defaultdict(float); d = collections.defaultdict(set)
-    for r in rows:
+    for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == ctr:
             a[r["Kernel_Name"]] += float(r["Counter_Value"]); d[r["Kernel_Name"]].add(r["Dispatch_Id"])
     return {k: (v / len(d[k]), len(d[k])) for k, v in a.items()}
-fs, ws = agg("prof_fetch", "FETCH_SIZE"), agg("prof_write", "WRITE_SIZE")
-print("kernel | dispatches | FETCH_SIZE KB/launch (x2 on gfx950 for wide streams) | WRITE_SIZE KB/launch")
-for k, (v, n) in sorted(fs.items(), key=lambda kv: -kv[1][0])[:6]:
-    print(f"{k[:70]} | {n} | {v:.0f} | {ws.get(k, (0, 0))[0]:.0f}")
-import json
-top = max(fs.items(), key=lambda kv: kv[1][0])
-json.dump({"kernel": top[0], "dispatches": top[1][1], "fetch_size_kb_per_launch": top[1][0],
-           "write_size_kb_per_launch": ws.get(top[0], (0, 0))[0],
-           "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; KB = 1024 B; gfx950: FETCH_SIZE x2 for wide streaming reads",
-           "query": __import__("os").environ.get("QUERY", "q1"), "rows_per_launch": int(__import__("os").environ.get("ROWS", "600037902"))}, open("gpurun_out/pmc_traffic.json", "w"), indent=1)
-st = glob.glob("gpurun_out/prof_stats/*/*kernel_stats.csv")
-if st:
-    print(open(st[0]).read()[:3000])
+fs, ws = agg(f"prof_{q}_fetch", "FETCH_SIZE"), agg(f"prof_{q}_write", "WRITE_SIZE")
+st = glob.glob(f"gpurun_out/prof_{q}_stats/*/*kernel_stats.csv")[0]
+shutil.copy(st, f"gpurun_out/{q}_kernel_stats.csv")
+stats = [r for r in csv.DictReader(open(st)) if "gen_" not in r["Name"]]
+stats.sort(key=lambda r: -float(r["TotalDurationNs"]))
+lines = ["kernel | calls | avg ms | FETCH_SIZE KB/launch (x2 on gfx950 for wide streams) | WRITE_SIZE KB/launch"]
+for r in stats[:12]:
+    k = r["Name"]
+    lines.append(f"{k[:90]} | {r['Calls']} | {float(r['AverageNs']) / 1e6:.4f} | {fs.get(k, (0, 0))[0]:.0f} | {ws.get(k, (0, 0))[0]:.0f}")
+open(f"gpurun_out/{q}_pmc_traffic.txt", "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
+top = stats[0]["Name"]
+json.dump({"kernel": top, "dispatches": fs.get(top, (0, 0))[1], "avg_ms": float(stats[0]["AverageNs"]) / 1e6,
+           "fetch_size_kb_per_launch": fs.get(top, (0, 0))[0], "write_size_kb_per_launch": ws.get(top, (0, 0))[0],
+           "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; KB = 1024 B; gfx950: FETCH_SIZE x2 for wide streaming reads; "
+                   "average over the kernel's launches of the run (a join query launches it once per probe side)",
+           "query": q, "rows_per_launch": int(os.environ.get("ROWS", "600037902"))}, open(f"gpurun_out/pmc_traffic_{q}.json", "w"), indent=1)
 PY
