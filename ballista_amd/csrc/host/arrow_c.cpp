@@ -303,8 +303,11 @@ bhip_status bhip_batch_import_arrow(bhip_ctx* ctx, struct ArrowArray* array, str
                 // rebase to 0 so only the referenced bytes are shipped
                 off_storage.emplace_back((size_t)n_rows + 1);
                 auto& o = off_storage.back();
-                const int32_t first = n_rows >= 0 && ca->buffers[1] ? offsets[0] : 0;
-                for (int64_t r = 0; r <= n_rows; ++r) o[(size_t)r] = offsets[r] - first;
+                // the C Data spec lets a length-0 array come without an offsets buffer; any other array must have one
+                if (!ca->buffers[1] && n_rows > 0)
+                    fail(BHIP_EINVAL, std::string("Arrow array of column ") + (cs->name ? cs->name : "") + " has no offsets buffer");
+                const int32_t first = ca->buffers[1] ? offsets[0] : 0;
+                for (int64_t r = 0; r <= n_rows; ++r) o[(size_t)r] = ca->buffers[1] ? offsets[r] - first : 0;
                 d.offsets = o.data();
                 d.data = static_cast<const uint8_t*>(ca->buffers[2]) + first;
                 d.data_bytes = o[(size_t)n_rows];

@@ -437,7 +437,7 @@ bhip_status bhip_stream_next(bhip_stream* s, bhip_batch** out) {
     s->ex.ctx->set_device();
     BatchPtr b = s->s->next();
     // a batch only leaves the library once everything that produces it has finished
-    s->ex.ctx->wait_stream(s->ex.stream);
+    if (b) s->ex.ctx->wait_stream(s->ex.stream);
     *out = b ? wrap_batch(b) : nullptr;
     BHIP_API_END
 }

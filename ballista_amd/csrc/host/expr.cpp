@@ -411,6 +411,13 @@ Operand ProgramBuilder::load_column(int schema_idx) {
     return o;
 }
 
+bool ProgramBuilder::can_raise() const {
+    if (!keys_.empty()) return true;
+    for (auto& vi : instrs_)
+        if (vi.ins.op == OP_DIV_I64) return true;
+    return false;
+}
+
 Operand ProgramBuilder::emit(uint8_t op, const Operand* a, const Operand* b, bool dst_b, int vclass, int dtype,
                              uint16_t aux, int c_breg, uint8_t flags) {
     if ((int)instrs_.size() >= VM_MAX_INSTR) fail(BHIP_ENOTIMPL, "expression needs more than 96 VM instructions");

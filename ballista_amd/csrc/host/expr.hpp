@@ -97,6 +97,9 @@ public:
 
     const std::vector<int>& columns() const { return col_map_; }   // VM column index -> input schema index
     bool creates_nulls() const { return creates_nulls_; }
+    // the program can set an error flag in its ScanStatus (integer division; a Utf8 key part longer than its packed width):
+    // only then does a caller have to read the status back before it hands the result on
+    bool can_raise() const;
     int key_bytes() const { return key_bytes_; }
     struct KeyInfo { int pos, width, nullable, dtype; };
     const std::vector<KeyInfo>& key_info() const { return key_info_; }

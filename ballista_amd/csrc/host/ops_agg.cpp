@@ -169,7 +169,8 @@ GroupRec* hash_aggregate(const Exec& ex, Temp& tmp, const ScanParams& P0, const 
     const LaunchCfg cfg = ex.cfg();
     int64_t total_rows = 0;
     for (auto& b : inputs) total_rows += b->n_rows;
-    if (total_rows > 0xFFFFFFF0ll) fail(BHIP_ENOTIMPL, "hash aggregate over more than 2^32 input rows per partition");
+    // slots are 32-bit indices into a table of >= 2 x rows entries
+    if (total_rows > 0x7FFFFFF0ll) fail(BHIP_ENOTIMPL, "hash aggregate over more than 2^31 input rows per partition");
     // capacity: power of two >= 2 x rows (every row could be its own group)
     uint64_t cap = 1024;
     while (cap < 2ull * (uint64_t)total_rows) cap <<= 1;
@@ -260,8 +261,9 @@ GroupRec* hash_aggregate(const Exec& ex, Temp& tmp, const ScanParams& P0, const 
 
 }  // namespace
 
-std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& ex) const {
+std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& ex, const HashAggregateExec* as_final) const {
     const Schema& in_schema = *input_->schema();
+    const SchemaPtr out_schema = as_final ? as_final->schema_ : schema_;
     // ---- expressions over the (fused) source ---------------------------------------------------
     std::vector<ExprPtr> group, args;
     for (auto& g : group_) group.push_back(g.first);
@@ -311,6 +313,11 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
                         farg = c;
                     }
                     const int acc = add_acc(ACC_SUM_F64, farg);
+                    if (as_final) {
+                        // [count], [sum] of the one partition -> sum / count, NULL without a non-NULL input: what the Final makes of them
+                        emit(EMIT_AVG, acc, 0, DT_FLOAT64);
+                        break;
+                    }
                     emit(EMIT_COUNT, acc, 0, DT_UINT64);
                     emit(EMIT_VALUE, acc, 0, DT_FLOAT64);
                 } break;
@@ -408,10 +415,83 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
 
     Temp tmp(ex);
     const LaunchCfg cfg = ex.cfg();
-    ScanStatus* status = tmp.get<ScanStatus>(1);
+    // status of the scan + merge and the byte totals of the Utf8 key columns, side by side: ONE read brings both back
+    TailInfo* info = tmp.get<TailInfo>(1);
+    ScanStatus* status = &info->st;
+    uint64_t* totals = group_.size() <= (size_t)TAIL_TOTALS ? info->totals : tmp.get<uint64_t>(group_.size() + 1);
     GroupRec* table = nullptr;
     int64_t n_groups = 0;
     TimedLaunches timer(ex);
+
+    // ---- group table -> output batch ------------------------------------------------------------
+    // `n_alloc` rows are allocated; dev_n != nullptr: the kernels read the count themselves (<= n_alloc), the host learns it later.
+    // Utf8 key columns: the value bytes have the packed key's bound (width - 1 per group), so the bytes are written before their
+    // total is known; the totals come back in one read after everything is queued.
+    std::vector<size_t> utf8_cols;
+    auto emit_table = [&](const GroupRec* tab, int64_t n_alloc, const ScanStatus* dev_n) {
+        auto out = std::make_shared<Batch>();
+        out->schema = out_schema;
+        out->ctx = ex.ctx;
+        out->n_rows = n_alloc;
+        const auto& kinfo = sop_layout ? sop.key_info : pb.key_info();
+        utf8_cols.clear();
+        for (size_t gi = 0; gi < group_.size(); ++gi) {
+            Column c;
+            c.dtype = out_schema->fields[gi].dtype;
+            c.length = n_alloc;
+            EmitKeySpec ks{kinfo[gi].pos, kinfo[gi].width, kinfo[gi].nullable, c.dtype};
+            if (kinfo[gi].nullable) c.validity = make_buffer(ex, bitmap_bytes(n_alloc) + 8);
+            uint64_t* vptr = c.validity ? c.validity->as<uint64_t>() : nullptr;
+            if (c.dtype == DT_UTF8) {
+                c.offsets = make_buffer(ex, (size_t)(n_alloc + 1) * 4);
+                c.data = make_buffer(ex, (size_t)n_alloc * (size_t)kinfo[gi].width + 8);
+                if (n_alloc > 0 && n_alloc <= EMIT_UTF8_SMALL_MAX) {
+                    TIMED_LAUNCH(ex, "emit_group_utf8_small", launch_emit_group_utf8_small(cfg, tab, n_alloc, ks, vptr, c.offsets->as<int32_t>(),
+                                                           c.data->as<uint8_t>(), totals + gi, dev_n));
+                } else {
+                    uint32_t* lengths = tmp.get<uint32_t>((size_t)n_alloc + 1);
+                    void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes(n_alloc));
+                    if (n_alloc) TIMED_LAUNCH(ex, "emit_group_key", launch_emit_group_key(cfg, tab, n_alloc, ks, nullptr, vptr, lengths));
+                    HIP_CHECK(exclusive_scan_u32_i32(ex.stream, lengths, n_alloc, c.offsets->as<int32_t>(), true, totals + gi, scan_tmp));
+                    if (n_alloc) TIMED_LAUNCH(ex, "emit_group_utf8", launch_emit_group_utf8(cfg, tab, n_alloc, ks, c.offsets->as<int32_t>(), c.data->as<uint8_t>()));
+                }
+                utf8_cols.push_back(gi);
+            } else {
+                const size_t bytes = c.dtype == DT_BOOLEAN ? bitmap_bytes(n_alloc) : (size_t)n_alloc * dtype_width(c.dtype);
+                c.data = make_buffer(ex, bytes + 8);
+                if (n_alloc) TIMED_LAUNCH(ex, "emit_group_key", launch_emit_group_key(cfg, tab, n_alloc, ks, c.data->ptr(), vptr, nullptr, dev_n));
+            }
+            out->cols.push_back(std::move(c));
+        }
+        // value columns: one launch per EMIT_BATCH_MAX columns
+        EmitValueBatch vb;
+        vb.n = 0;
+        for (size_t k = 0; k < emits.size(); ++k) {
+            EmitValueSpec sp = emits[k];
+            sp.count_is_rows = nullable ? 0 : 1;
+            const Field& fld = out_schema->fields[group_.size() + k];
+            Column c;
+            c.dtype = fld.dtype;
+            c.length = n_alloc;
+            c.data = make_buffer(ex, (size_t)n_alloc * dtype_width(c.dtype) + 8);
+            if (fld.nullable) c.validity = make_buffer(ex, bitmap_bytes(n_alloc) + 8);
+            vb.spec[vb.n] = sp;
+            vb.data[vb.n] = c.data->ptr();
+            vb.validity[vb.n] = c.validity ? c.validity->as<uint64_t>() : nullptr;
+            if (++vb.n == EMIT_BATCH_MAX || k + 1 == emits.size()) {
+                TIMED_LAUNCH(ex, "emit_group_values", launch_emit_group_values(cfg, tab, n_alloc, vb, dev_n));
+                vb.n = 0;
+            }
+            out->cols.push_back(std::move(c));
+        }
+        return out;
+    };
+    // the row count (and the Utf8 byte totals) once the host knows them
+    auto finish_table = [&](const std::shared_ptr<Batch>& out, int64_t n, const uint64_t* host_totals) {
+        out->n_rows = n;
+        for (auto& c : out->cols) c.length = n;
+        for (size_t gi : utf8_cols) out->cols[gi].data_bytes = (int64_t)host_totals[gi];
+    };
 
     int gmax = group_.empty() ? 1 : 4;
     const int hint = path_hint_.load();
@@ -436,11 +516,16 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
         head->n_rows = std::min<int64_t>(head->n_rows, 32768);
         sample.push_back(head);
     }
+    std::shared_ptr<Batch> early;
+    TailInfo tail;
+    memset(&tail, 0, sizeof(tail));
+    static const bool no_early_emit = [] { const char* v = getenv("BHIP_NO_EARLY_EMIT"); return v && atoi(v) != 0; }();
     while (!inputs.empty()) {
         const bool sampling = !sample.empty();
         const std::vector<BatchPtr>& cur = sampling ? sample : inputs;
         if (gmax == -1) {
             // ---- hash path: one device-wide table, atomics ----------------------------------------
+            early.reset();
             sop_layout = false;              // the hash path packs keys with the VM's layout
             table = hash_aggregate(ex, tmp, P0, pb, inputs, nullable, &n_groups, status, timer);
             break;
@@ -481,7 +566,12 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
         AccSpec specs[VM_MAX_ACC];
         for (int i = 0; i < n_acc; ++i) specs[i] = P0.acc[i];
         TIMED_LAUNCH(ex, "merge_partials", launch_merge_partials(cfg, partials, partial_ng, n_part, gmax, specs, n_acc, table, cap, entry_group, status));
-        ScanStatus st = read_device(ex, status);
+        // the table has at most `cap` groups: its columns are emitted for that bound straight away, behind the merge and with the
+        // count read on the device, so the host waits ONCE per aggregate (the result is dropped if the ladder has to go on)
+        early.reset();
+        if (!sampling && !no_early_emit && group_.size() <= (size_t)TAIL_TOTALS) early = emit_table(table, cap, status);
+        tail = read_device(ex, info);
+        const ScanStatus st = tail.st;
         timer.collect();
         if (lean_now && (st.flags & SCAN_ERR_KEY_TOO_LONG)) {
             use_lean = false;                // a string key longer than 3 bytes: the 7-byte variant next
@@ -504,6 +594,7 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
     }
 
     if (n_groups == 0 && group_.empty()) {
+        early.reset();
         // no GROUP BY: exactly one output row even for empty input (SUM = NULL, COUNT = 0)
         GroupRec id;
         memset(&id, 0, sizeof(id));
@@ -522,70 +613,17 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
         n_groups = 1;
     }
 
-    // ---- group table -> output batch ------------------------------------------------------------
-    auto out = std::make_shared<Batch>();
-    out->schema = schema_;
-    out->ctx = ex.ctx;
-    out->n_rows = n_groups;
-    const auto& kinfo = sop_layout ? sop.key_info : pb.key_info();
-    // Utf8 key columns: the value bytes have the packed key's bound (width - 1 per group), so the bytes are
-    // written before their total is known (width bytes per group bounds them); the totals come back in ONE read after everything is queued
-    uint64_t* totals = tmp.get<uint64_t>(group_.size() + 1);
-    std::vector<size_t> utf8_cols;
-    for (size_t gi = 0; gi < group_.size(); ++gi) {
-        Column c;
-        c.dtype = schema_->fields[gi].dtype;
-        c.length = n_groups;
-        EmitKeySpec ks{kinfo[gi].pos, kinfo[gi].width, kinfo[gi].nullable, c.dtype};
-        if (kinfo[gi].nullable) c.validity = make_buffer(ex, bitmap_bytes(n_groups) + 8);
-        uint64_t* vptr = c.validity ? c.validity->as<uint64_t>() : nullptr;
-        if (c.dtype == DT_UTF8) {
-            c.offsets = make_buffer(ex, (size_t)(n_groups + 1) * 4);
-            c.data = make_buffer(ex, (size_t)n_groups * (size_t)kinfo[gi].width + 8);
-            if (n_groups > 0 && n_groups <= EMIT_UTF8_SMALL_MAX) {
-                TIMED_LAUNCH(ex, "emit_group_utf8_small", launch_emit_group_utf8_small(cfg, table, n_groups, ks, vptr, c.offsets->as<int32_t>(), c.data->as<uint8_t>(),
-                                                       totals + gi));
-            } else {
-                uint32_t* lengths = tmp.get<uint32_t>((size_t)n_groups + 1);
-                void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes(n_groups));
-                if (n_groups) TIMED_LAUNCH(ex, "emit_group_key", launch_emit_group_key(cfg, table, n_groups, ks, nullptr, vptr, lengths));
-                HIP_CHECK(exclusive_scan_u32_i32(ex.stream, lengths, n_groups, c.offsets->as<int32_t>(), true, totals + gi, scan_tmp));
-                if (n_groups) TIMED_LAUNCH(ex, "emit_group_utf8", launch_emit_group_utf8(cfg, table, n_groups, ks, c.offsets->as<int32_t>(), c.data->as<uint8_t>()));
-            }
-            utf8_cols.push_back(gi);
-        } else {
-            const size_t bytes = c.dtype == DT_BOOLEAN ? bitmap_bytes(n_groups) : (size_t)n_groups * dtype_width(c.dtype);
-            c.data = make_buffer(ex, bytes + 8);
-            if (n_groups) TIMED_LAUNCH(ex, "emit_group_key", launch_emit_group_key(cfg, table, n_groups, ks, c.data->ptr(), vptr, nullptr));
-        }
-        out->cols.push_back(std::move(c));
+    if (early) {
+        // the emit was queued behind the merge; the single read above brought the count and the Utf8 totals
+        finish_table(early, n_groups, tail.totals);
+        return {early};
     }
-    // value columns: one launch per EMIT_BATCH_MAX columns
-    EmitValueBatch vb;
-    vb.n = 0;
-    for (size_t k = 0; k < emits.size(); ++k) {
-        EmitValueSpec sp = emits[k];
-        sp.count_is_rows = nullable ? 0 : 1;
-        const Field& fld = schema_->fields[group_.size() + k];
-        Column c;
-        c.dtype = fld.dtype;
-        c.length = n_groups;
-        c.data = make_buffer(ex, (size_t)n_groups * dtype_width(c.dtype) + 8);
-        if (fld.nullable) c.validity = make_buffer(ex, bitmap_bytes(n_groups) + 8);
-        vb.spec[vb.n] = sp;
-        vb.data[vb.n] = c.data->ptr();
-        vb.validity[vb.n] = c.validity ? c.validity->as<uint64_t>() : nullptr;
-        if (++vb.n == EMIT_BATCH_MAX || k + 1 == emits.size()) {
-            TIMED_LAUNCH(ex, "emit_group_values", launch_emit_group_values(cfg, table, n_groups, vb));
-            vb.n = 0;
-        }
-        out->cols.push_back(std::move(c));
-    }
+    auto out = emit_table(table, n_groups, nullptr);
     if (!utf8_cols.empty()) {
-        std::vector<uint64_t> host(group_.size());
+        std::vector<uint64_t> host(group_.size() + 1);
         HIP_CHECK(hipMemcpyAsync(host.data(), totals, group_.size() * 8, hipMemcpyDeviceToHost, ex.stream));
         stream_wait(ex);
-        for (size_t gi : utf8_cols) out->cols[gi].data_bytes = (int64_t)host[gi];
+        finish_table(out, n_groups, host.data());
     } else {
         stream_wait(ex);
     }

@@ -41,6 +41,17 @@ bool HashAggregateExec::run_single_partial(const Exec& ex, std::vector<BatchPtr>
         if (group_[i].first->kind != BHIP_EXPR_COLUMN || group_[i].first->name != ps.fields[i].name) return false;
     for (size_t i = 0; i < aggr_.size(); ++i)
         if (aggr_[i].fn != pa->aggr_[i].fn) return false;
+    // the Partial emits its group table as this operator's columns (AVG = sum / count in the emit kernel): no state batch at all
+    if (group_.empty() || !pa->wide_keys_.load()) {
+        try {
+            out = pa->run_packed(0, ex, this);
+            return true;
+        } catch (const Error& e) {
+            if (group_.empty() || !key_width_error(e)) throw;
+            pa->wide_keys_.store(true);
+        }
+    }
+    // wide keys: the Partial's state batch, then AVG = [sum] / [count] as a projection
     std::vector<std::pair<ExprPtr, std::string>> exprs;
     for (size_t i = 0; i < group_.size(); ++i) exprs.push_back({make_column(ps.fields[i].name), group_[i].second});
     size_t pos = group_.size();

@@ -422,7 +422,8 @@ BatchPtr project_batch(const Exec& ex, const Batch& in, const std::vector<std::p
     Temp tmp(ex);
     ScanStatus* st = new_status(tmp);
     TIMED_LAUNCH(ex, "scan_project", launch_scan_project(ex.cfg(), P, po, st));
-    check_scan_status(ex, st);
+    // only an integer division can fail; every other projection is handed on without a host round trip (stream order)
+    if (pb.can_raise()) check_scan_status(ex, st);
     return out;
 }
 

@@ -167,6 +167,8 @@ std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) co
         bs->batch = concat_batches(ex, left_->schema(), parts);
     }
     const int64_t n = bs->batch->n_rows;
+    // build rows are addressed by 32-bit slots / ranks in every table form
+    if (n > 0x7FFFFFF0ll) fail(BHIP_ENOTIMPL, "hash join build side of more than 2^31 rows per partition");
     std::vector<std::string> lcols;
     for (auto& p : on_) lcols.push_back(p.first);
     uint64_t cap = 1024;

@@ -74,6 +74,53 @@ StreamPtr SortExec::execute(int partition, const Exec& ex) const {
         BatchPtr in = concat_batches(ex, self->schema(), parts);
         const int64_t n = in->n_rows;
         const LaunchCfg cfg = ex.cfg();
+        static const bool no_rowsort = [] { const char* v = getenv("BHIP_NO_ROWSORT"); return v && atoi(v) != 0; }();
+        if (!no_rowsort && n <= ROWSORT_MAX_ROWS && self->exprs_.size() <= (size_t)ROWSORT_MAX_KEYS && in->cols.size() <= (size_t)ROWSORT_MAX_COLS) {
+            // a handful of rows (the result of a low-cardinality aggregate): ranks by row comparison + the gather of every column, one launch
+            RowSortArgs A;
+            memset(&A, 0, sizeof(A));
+            A.n_rows = (int32_t)n;
+            A.n_keys = (int32_t)self->exprs_.size();
+            A.n_cols = (int32_t)in->cols.size();
+            std::vector<Column> key_cols;                     // keeps computed key columns alive until the launch is queued
+            for (size_t k = 0; k < self->exprs_.size(); ++k) {
+                const SortDesc& sd = self->exprs_[k];
+                key_cols.push_back(evaluate_column(ex, *in, sd.expr));
+                A.key[k] = key_cols.back().ref();
+                A.desc[k] = sd.descending ? 1 : 0;
+                A.nulls_first[k] = sd.nulls_first ? 1 : 0;
+            }
+            auto out = std::make_shared<Batch>();
+            out->schema = in->schema;
+            out->ctx = in->ctx;
+            out->n_rows = n;
+            for (size_t ci = 0; ci < in->cols.size(); ++ci) {
+                const Column& c = in->cols[ci];
+                Column o;
+                o.dtype = c.dtype;
+                o.length = n;
+                A.col[ci] = c.ref();
+                if (c.dtype == DT_UTF8) {
+                    o.offsets = make_buffer(ex, (size_t)(n + 1) * 4);
+                    o.data = make_buffer(ex, (size_t)c.data_bytes + 8);
+                    o.data_bytes = c.data_bytes;               // a permutation keeps the value bytes
+                    A.out_offsets[ci] = o.offsets->as<int32_t>();
+                } else if (c.dtype == DT_BOOLEAN) {
+                    o.data = make_buffer(ex, bitmap_bytes(n) + 8);
+                } else {
+                    A.width[ci] = (uint8_t)dtype_width(c.dtype);
+                    o.data = make_buffer(ex, (size_t)n * dtype_width(c.dtype) + 8);
+                }
+                A.out_data[ci] = o.data->ptr();
+                if (c.validity) {
+                    o.validity = make_buffer(ex, bitmap_bytes(n) + 8);
+                    A.out_validity[ci] = o.validity->as<uint64_t>();
+                }
+                out->cols.push_back(std::move(o));
+            }
+            TIMED_LAUNCH(ex, "rowsort", launch_rowsort(cfg, A));
+            return {out};                                       // stream order: the consumer's work (or its wait) comes after the launch
+        }
         BufferPtr perm = make_buffer(ex, (size_t)n * 4 + 8);
         BufferPtr keys = make_buffer(ex, (size_t)n * 8 + 8);
         TIMED_LAUNCH(ex, "iota_u32", launch_iota_u32(cfg, perm->as<uint32_t>(), n, 0));

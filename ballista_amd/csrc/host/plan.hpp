@@ -198,7 +198,9 @@ public:
     std::string describe() const override;
 private:
     std::vector<BatchPtr> run(int partition, const Exec& ex) const;
-    std::vector<BatchPtr> run_packed(int partition, const Exec& ex) const;   // keys packed into 16 bytes (every fast path)
+    // keys packed into 16 bytes (every fast path).  as_final != nullptr (a Partial whose only consumer is that Final aggregate over
+    // this single partition, run_single_partial): the group table is emitted straight into the Final's output columns
+    std::vector<BatchPtr> run_packed(int partition, const Exec& ex, const HashAggregateExec* as_final = nullptr) const;
     std::vector<BatchPtr> run_wide(int partition, const Exec& ex) const;     // keys of any width (ops_agg_wide.cpp)
     // Final over the Merge of ONE partition of a Partial aggregate with the same keys: every group arrives exactly once, the
     // merge is the identity and the operator is a projection of the state columns (AVG = sum / count)

@@ -24,6 +24,13 @@ struct ScanStatus {
     uint64_t count;             // generic counter (selected rows, ...)
 };
 
+// what the host reads back after a small aggregate, in one piece (<= 56 bytes: one pinned host slot, host/core.cpp)
+constexpr int TAIL_TOTALS = 5;
+struct TailInfo {
+    ScanStatus st;
+    uint64_t totals[TAIL_TOTALS];   // value bytes of the Utf8 key columns
+};
+
 struct LaunchCfg {
     int device_cus;             // multiprocessor count
     hipStream_t stream;

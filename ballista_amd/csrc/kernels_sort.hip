@@ -263,27 +263,146 @@ hipError_t radix_pass(const LaunchCfg& cfg, const uint64_t* keys, const uint32_t
 }
 
 // ---- key normalisation ---------------------------------------------------------------------------
+// order-preserving u64 image of a fixed-width value: unsigned order of the images == the type's order
+// (floats: total order by sign-magnitude flip, -NaN < -inf < ... < -0 < +0 < ... < +inf < +NaN)
+__device__ inline uint64_t fixed_key_image(const ColumnRef& c, uint32_t row) {
+    constexpr uint64_t SIGN = 0x8000000000000000ull;
+    switch (c.dtype) {
+        case DT_INT8: return (uint64_t)(int64_t) reinterpret_cast<const int8_t*>(c.data)[row] ^ SIGN;
+        case DT_INT16: return (uint64_t)(int64_t) reinterpret_cast<const int16_t*>(c.data)[row] ^ SIGN;
+        case DT_INT32:
+        case DT_DATE32: return (uint64_t)(int64_t) reinterpret_cast<const int32_t*>(c.data)[row] ^ SIGN;
+        case DT_INT64:
+        case DT_DATE64:
+        case DT_TIMESTAMP_S:
+        case DT_TIMESTAMP_MS:
+        case DT_TIMESTAMP_US:
+        case DT_TIMESTAMP_NS: return reinterpret_cast<const uint64_t*>(c.data)[row] ^ SIGN;
+        case DT_UINT8: return reinterpret_cast<const uint8_t*>(c.data)[row];
+        case DT_UINT16: return reinterpret_cast<const uint16_t*>(c.data)[row];
+        case DT_UINT32: return reinterpret_cast<const uint32_t*>(c.data)[row];
+        case DT_UINT64: return reinterpret_cast<const uint64_t*>(c.data)[row];
+        case DT_BOOLEAN: return (reinterpret_cast<const uint8_t*>(c.data)[row >> 3] >> (row & 7)) & 1u;
+        case DT_FLOAT32: {
+            const uint32_t b = reinterpret_cast<const uint32_t*>(c.data)[row];
+            return (b >> 31) ? (uint32_t)~b : (b | 0x80000000u);
+        }
+        default: {   // Float64
+            const uint64_t b = reinterpret_cast<const uint64_t*>(c.data)[row];
+            return (b >> 63) ? ~b : (b | SIGN);
+        }
+    }
+}
+__device__ inline bool row_valid(const uint64_t* validity, uint32_t row) {
+    return validity == nullptr || ((validity[row >> 6] >> (row & 63)) & 1ull);
+}
+
 // out[i] = order-preserving u64 image of column value at row perm[i]
 __global__ void __launch_bounds__(SORT_BLOCK)
 sort_key_fixed_kernel(ColumnRef c, const uint32_t* perm, int64_t n, int descending, uint64_t* out) {
     for (int64_t i = (int64_t)blockIdx.x * SORT_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * SORT_BLOCK) {
         const uint32_t row = perm[i];
-        uint64_t k;
-        switch (c.dtype) {
-            case DT_INT32:
-            case DT_DATE32: k = (uint64_t)(int64_t) reinterpret_cast<const int32_t*>(c.data)[row] ^ 0x8000000000000000ull; break;
-            case DT_INT64: k = reinterpret_cast<const uint64_t*>(c.data)[row] ^ 0x8000000000000000ull; break;
-            case DT_UINT8: k = reinterpret_cast<const uint8_t*>(c.data)[row]; break;
-            case DT_UINT64: k = reinterpret_cast<const uint64_t*>(c.data)[row]; break;
-            case DT_BOOLEAN: k = (reinterpret_cast<const uint8_t*>(c.data)[row >> 3] >> (row & 7)) & 1u; break;
-            default: {   // Float64: total order by sign-magnitude flip
-                const uint64_t b = reinterpret_cast<const uint64_t*>(c.data)[row];
-                k = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
-            } break;
-        }
-        if (c.validity != nullptr && !((c.validity[row >> 6] >> (row & 63)) & 1ull)) k = 0;   // ties among NULLs
+        uint64_t k = fixed_key_image(c, row);
+        if (!row_valid(c.validity, row)) k = 0;   // ties among NULLs
         out[i] = descending ? ~k : k;
     }
+}
+
+// ---- a whole SortExec over at most ROWSORT_MAX_ROWS rows in ONE launch of one workgroup -------------------------------
+// (the result of a low-cardinality aggregate: TPC-H Q1 sorts 4 rows, Q5 5 — the general path is ~20 launches for them).
+// Thread i owns input row i: its output position is the number of rows that sort before it under the lexicographic
+// (key, descending, nulls_first) order, ties by input position — the same stable order the LSD passes produce.  Then thread r
+// writes output row r of every column (fixed width, Boolean and validity bits by ballot, Utf8 through a block prefix sum).
+__device__ inline int rowsort_cmp_key(const ColumnRef& c, uint32_t a, uint32_t b) {   // ascending, both rows valid
+    if (c.dtype == DT_UTF8) {
+        const int32_t oa = c.offsets[a], ob = c.offsets[b];
+        const int la = c.offsets[a + 1] - oa, lb = c.offsets[b + 1] - ob;
+        const uint8_t* sa = reinterpret_cast<const uint8_t*>(c.data) + oa;
+        const uint8_t* sb = reinterpret_cast<const uint8_t*>(c.data) + ob;
+        const int m = la < lb ? la : lb;
+        for (int p = 0; p < m; ++p)
+            if (sa[p] != sb[p]) return sa[p] < sb[p] ? -1 : 1;
+        // one is a prefix of the other: zero-padded chunks first, then the length (sort_key_utf8_kernel)
+        for (int p = m; p < la; ++p) if (sa[p] != 0) return 1;
+        for (int p = m; p < lb; ++p) if (sb[p] != 0) return -1;
+        return la < lb ? -1 : la > lb ? 1 : 0;
+    }
+    const uint64_t ka = fixed_key_image(c, a), kb = fixed_key_image(c, b);
+    return ka < kb ? -1 : ka > kb ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(ROWSORT_MAX_ROWS)
+rowsort_kernel(RowSortArgs A) {
+    __shared__ uint32_t s_src[ROWSORT_MAX_ROWS];
+    __shared__ uint32_t s_wave[ROWSORT_MAX_ROWS / 64];
+    const int n = A.n_rows, i = threadIdx.x, lane = i & 63, wave = i >> 6;
+    if (i < n) {
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            int c = 0;
+            for (int k = 0; k < A.n_keys && c == 0; ++k) {
+                const ColumnRef& kc = A.key[k];
+                const bool vj = row_valid(kc.validity, (uint32_t)j), vi = row_valid(kc.validity, (uint32_t)i);
+                if (vj && vi) {
+                    c = rowsort_cmp_key(kc, (uint32_t)j, (uint32_t)i);
+                    if (A.desc[k]) c = -c;
+                } else if (vj != vi) {
+                    c = (!vj) == (A.nulls_first[k] != 0) ? -1 : 1;      // the NULL row goes first iff nulls_first
+                }
+            }
+            rank += (c < 0 || (c == 0 && j < i)) ? 1 : 0;
+        }
+        s_src[rank] = (uint32_t)i;
+    }
+    __syncthreads();
+    const bool in = i < n;
+    const uint32_t src = in ? s_src[i] : 0u;
+    const int n_words = (n + 63) >> 6;
+    for (int ci = 0; ci < A.n_cols; ++ci) {
+        const ColumnRef& c = A.col[ci];
+        const bool valid = in && row_valid(c.validity, src);
+        if (A.out_validity[ci] != nullptr) {
+            const uint64_t w = __ballot(valid);
+            if (lane == 0 && wave < n_words) A.out_validity[ci][wave] = w;
+        }
+        if (c.dtype == DT_UTF8) {
+            const int32_t o0 = in ? c.offsets[src] : 0;
+            const uint32_t len = in ? (uint32_t)(c.offsets[src + 1] - o0) : 0u;
+            uint32_t x = len;                      // inclusive scan inside the wave, then the wave totals
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+            if (lane == 63) s_wave[wave] = x;
+            __syncthreads();
+            uint32_t before = 0, total = 0;
+            for (int w = 0; w < ROWSORT_MAX_ROWS / 64; ++w) { if (w < wave) before += s_wave[w]; total += s_wave[w]; }
+            __syncthreads();
+            const uint32_t d0 = before + x - len;
+            if (in) {
+                A.out_offsets[ci][i] = (int32_t)d0;
+                const uint8_t* s = reinterpret_cast<const uint8_t*>(c.data) + o0;
+                uint8_t* d = reinterpret_cast<uint8_t*>(A.out_data[ci]) + d0;
+                for (uint32_t b = 0; b < len; ++b) d[b] = s[b];
+            }
+            if (i == 0) A.out_offsets[ci][n] = (int32_t)total;
+        } else if (c.dtype == DT_BOOLEAN) {
+            const bool bit = in && ((reinterpret_cast<const uint8_t*>(c.data)[src >> 3] >> (src & 7)) & 1u);
+            const uint64_t w = __ballot(bit);
+            if (lane == 0 && wave < n_words) reinterpret_cast<uint64_t*>(A.out_data[ci])[wave] = w;
+        } else if (in) {
+            switch (A.width[ci]) {
+                case 1: reinterpret_cast<uint8_t*>(A.out_data[ci])[i] = reinterpret_cast<const uint8_t*>(c.data)[src]; break;
+                case 2: reinterpret_cast<uint16_t*>(A.out_data[ci])[i] = reinterpret_cast<const uint16_t*>(c.data)[src]; break;
+                case 4: reinterpret_cast<uint32_t*>(A.out_data[ci])[i] = reinterpret_cast<const uint32_t*>(c.data)[src]; break;
+                default: reinterpret_cast<uint64_t*>(A.out_data[ci])[i] = reinterpret_cast<const uint64_t*>(c.data)[src]; break;
+            }
+        }
+    }
+}
+
+hipError_t launch_rowsort(const LaunchCfg& cfg, const RowSortArgs& A) {
+    if (A.n_rows < 1 || A.n_rows > ROWSORT_MAX_ROWS || A.n_keys > ROWSORT_MAX_KEYS || A.n_cols > ROWSORT_MAX_COLS) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rowsort_kernel, dim3(1), dim3(ROWSORT_MAX_ROWS), 0, cfg.stream, A);
+    return hipGetLastError();
 }
 
 // Utf8: chunk `chunk` = bytes [8*chunk, 8*chunk+8) big-endian, zero padded; chunk == -1: the length

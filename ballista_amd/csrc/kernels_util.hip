@@ -433,7 +433,8 @@ __device__ inline uint64_t key_get(const GroupRec& g, int pos, int width) {
 // one group column; `pos` = byte position of the part inside the packed key
 __global__ void __launch_bounds__(BLOCK)
 emit_group_key_kernel(const GroupRec* table, int64_t n_groups, EmitKeySpec spec, void* data, uint64_t* validity,
-                      uint32_t* utf8_lengths) {
+                      uint32_t* utf8_lengths, const ScanStatus* dev_n) {
+    if (dev_n) n_groups = dev_n->n_groups;                  // the host has not read the count yet (small tables, ops_agg.cpp)
     const int64_t n_round = (n_groups + 63) & ~(int64_t)63;
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n_round; i += (int64_t)gridDim.x * BLOCK) {
         bool valid = false;
@@ -473,7 +474,8 @@ emit_group_key_kernel(const GroupRec* table, int64_t n_groups, EmitKeySpec spec,
 // bytes, the validity words and the byte total (a thread owns SCAN_ITEMS consecutive groups, so four lanes make a word)
 __global__ void __launch_bounds__(SCAN_BLOCK)
 emit_group_utf8_small_kernel(const GroupRec* table, int64_t n_groups, EmitKeySpec spec, uint64_t* validity, int32_t* offsets,
-                             uint8_t* bytes, uint64_t* total_out) {
+                             uint8_t* bytes, uint64_t* total_out, const ScanStatus* dev_n) {
+    if (dev_n) n_groups = dev_n->n_groups;
     static_assert(SCAN_ITEMS == 16, "four lanes x 16 groups = one validity word");
     __shared__ uint64_t s_wave[4];
     uint32_t len[SCAN_ITEMS];
@@ -529,7 +531,8 @@ emit_group_utf8_kernel(const GroupRec* table, int64_t n_groups, EmitKeySpec spec
 
 // all value columns of an aggregate's output in ONE launch: blockIdx.y selects the column
 __global__ void __launch_bounds__(BLOCK)
-emit_group_values_kernel(const GroupRec* table, int64_t n_groups, EmitValueBatch batch) {
+emit_group_values_kernel(const GroupRec* table, int64_t n_groups, EmitValueBatch batch, const ScanStatus* dev_n) {
+    if (dev_n) n_groups = dev_n->n_groups;
     const EmitValueSpec spec = batch.spec[blockIdx.y];
     void* data = batch.data[blockIdx.y];
     uint64_t* validity = batch.validity[blockIdx.y];
@@ -676,17 +679,17 @@ hipError_t launch_pack_buffers(const LaunchCfg& cfg, const PackDesc& d, uint8_t*
 }
 
 hipError_t launch_emit_group_key(const LaunchCfg& cfg, const GroupRec* table, int64_t n_groups, const EmitKeySpec& spec,
-                                 void* data, uint64_t* validity, uint32_t* utf8_lengths) {
+                                 void* data, uint64_t* validity, uint32_t* utf8_lengths, const ScanStatus* dev_n) {
     if (n_groups == 0) return hipSuccess;
     hipLaunchKernelGGL(emit_group_key_kernel, dim3(grid_for(cfg, n_groups)), dim3(BLOCK), 0, cfg.stream, table, n_groups,
-                       spec, data, validity, utf8_lengths);
+                       spec, data, validity, utf8_lengths, dev_n);
     return hipGetLastError();
 }
 hipError_t launch_emit_group_utf8_small(const LaunchCfg& cfg, const GroupRec* table, int64_t n_groups, const EmitKeySpec& spec,
-                                        uint64_t* validity, int32_t* offsets, uint8_t* bytes, uint64_t* total_out) {
+                                        uint64_t* validity, int32_t* offsets, uint8_t* bytes, uint64_t* total_out, const ScanStatus* dev_n) {
     if (n_groups <= 0 || n_groups > EMIT_UTF8_SMALL_MAX) return hipErrorInvalidValue;
     hipLaunchKernelGGL(emit_group_utf8_small_kernel, dim3(1), dim3(SCAN_BLOCK), 0, cfg.stream, table, n_groups, spec, validity,
-                       offsets, bytes, total_out);
+                       offsets, bytes, total_out, dev_n);
     return hipGetLastError();
 }
 hipError_t launch_emit_group_utf8(const LaunchCfg& cfg, const GroupRec* table, int64_t n_groups, const EmitKeySpec& spec,
@@ -701,12 +704,13 @@ hipError_t launch_emit_group_value(const LaunchCfg& cfg, const GroupRec* table, 
     if (n_groups == 0) return hipSuccess;
     EmitValueBatch b;
     b.n = 1; b.spec[0] = spec; b.data[0] = data; b.validity[0] = validity;
-    return launch_emit_group_values(cfg, table, n_groups, b);
+    return launch_emit_group_values(cfg, table, n_groups, b, nullptr);
 }
-hipError_t launch_emit_group_values(const LaunchCfg& cfg, const GroupRec* table, int64_t n_groups, const EmitValueBatch& batch) {
+hipError_t launch_emit_group_values(const LaunchCfg& cfg, const GroupRec* table, int64_t n_groups, const EmitValueBatch& batch,
+                                    const ScanStatus* dev_n) {
     if (n_groups == 0 || batch.n == 0) return hipSuccess;
     hipLaunchKernelGGL(emit_group_values_kernel, dim3(grid_for(cfg, n_groups), batch.n), dim3(BLOCK), 0, cfg.stream, table,
-                       n_groups, batch);
+                       n_groups, batch, dev_n);
     return hipGetLastError();
 }
 

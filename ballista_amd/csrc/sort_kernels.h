@@ -17,6 +17,20 @@ hipError_t radix_key_diff(const LaunchCfg& cfg, const uint64_t* keys, int64_t n,
 hipError_t radix_pass(const LaunchCfg& cfg, const uint64_t* keys, const uint32_t* vals, int64_t n, int byte,
                       uint64_t* keys_out, uint32_t* vals_out, void* temp);
 
+// a whole multi-key sort + gather of every column for n_rows <= ROWSORT_MAX_ROWS, one launch (kernels_sort.hip)
+constexpr int ROWSORT_MAX_ROWS = 256, ROWSORT_MAX_KEYS = 8, ROWSORT_MAX_COLS = 32;
+struct RowSortArgs {
+    int32_t n_rows, n_keys, n_cols;
+    ColumnRef key[ROWSORT_MAX_KEYS];               // most significant first
+    uint8_t desc[ROWSORT_MAX_KEYS], nulls_first[ROWSORT_MAX_KEYS];
+    ColumnRef col[ROWSORT_MAX_COLS];               // the columns to reorder
+    uint8_t width[ROWSORT_MAX_COLS];               // bytes per value of a fixed-width column
+    void* out_data[ROWSORT_MAX_COLS];
+    int32_t* out_offsets[ROWSORT_MAX_COLS];        // Utf8
+    uint64_t* out_validity[ROWSORT_MAX_COLS];      // nullptr: the column has no validity bitmap
+};
+hipError_t launch_rowsort(const LaunchCfg& cfg, const RowSortArgs& A);
+
 hipError_t launch_sort_key_fixed(const LaunchCfg& cfg, const ColumnRef& c, const uint32_t* perm, int64_t n, bool desc, uint64_t* out);
 hipError_t launch_sort_key_utf8(const LaunchCfg& cfg, const ColumnRef& c, const uint32_t* perm, int64_t n, int chunk, bool desc,
                                 uint64_t* out);

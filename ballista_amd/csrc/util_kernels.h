@@ -102,13 +102,17 @@ struct EmitValueBatch {
     void* data[EMIT_BATCH_MAX];
     uint64_t* validity[EMIT_BATCH_MAX];
 };
-hipError_t launch_emit_group_values(const LaunchCfg& cfg, const GroupRec* table, int64_t n_groups, const EmitValueBatch& batch);
+// dev_n != nullptr (all three launchers below): the group count is read on the device from dev_n->n_groups and `n_groups` only
+// bounds it (the size the outputs were allocated for) — the host queues the emit before it has read the count back
+hipError_t launch_emit_group_values(const LaunchCfg& cfg, const GroupRec* table, int64_t n_groups, const EmitValueBatch& batch,
+                                    const ScanStatus* dev_n = nullptr);
 hipError_t launch_emit_group_key(const LaunchCfg& cfg, const GroupRec* table, int64_t n_groups, const EmitKeySpec& spec,
-                                 void* data, uint64_t* validity, uint32_t* utf8_lengths);
+                                 void* data, uint64_t* validity, uint32_t* utf8_lengths, const ScanStatus* dev_n = nullptr);
 // n_groups <= EMIT_UTF8_SMALL_MAX: lengths + prefix sum + offsets (n + 1) + bytes + validity + byte total in one launch
 constexpr int64_t EMIT_UTF8_SMALL_MAX = 4096;
 hipError_t launch_emit_group_utf8_small(const LaunchCfg& cfg, const GroupRec* table, int64_t n_groups, const EmitKeySpec& spec,
-                                        uint64_t* validity, int32_t* offsets, uint8_t* bytes, uint64_t* total_out);
+                                        uint64_t* validity, int32_t* offsets, uint8_t* bytes, uint64_t* total_out,
+                                        const ScanStatus* dev_n = nullptr);
 hipError_t launch_emit_group_utf8(const LaunchCfg& cfg, const GroupRec* table, int64_t n_groups, const EmitKeySpec& spec,
                                   const int32_t* offsets, uint8_t* bytes);
 hipError_t launch_emit_group_value(const LaunchCfg& cfg, const GroupRec* table, int64_t n_groups,

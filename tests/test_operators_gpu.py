@@ -368,6 +368,29 @@ def test_sort(ctx, si):
     run_both(plan, ordered=True)      # both sorts are stable, so even ties line up
 
 
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 200, 256, 257])
+@pytest.mark.parametrize("si", range(len(SORTS)))
+def test_sort_few_rows(ctx, si, n):
+    """at most 256 rows: ranks by row comparison and the gather of all ten columns in ONE launch (rowsort_kernel); 257: the
+    LSD passes.  Same stable order either way: NULL placement per key, DESC, Boolean/Utf8/validity output by ballot + scan"""
+    b = random_batch(n, seed=90 + si)
+    run_both(ba.SortExec(SORTS[si], helpers.memory_exec(ctx, [[b]])), ordered=True)
+
+
+def test_sort_few_rows_edge_values(ctx):
+    """strings that are prefixes of each other with trailing NUL bytes, empty strings, NaN / infinities"""
+    from collections import OrderedDict
+    svals = ["ab", "ab\0", "a", "", "ab\0c", "abc", "a\0", "b", "", "ab"]
+    fvals = np.array([0.0, 2.5, np.nan, np.inf, -np.inf, 1.5, -1.5, 2.5, 0.0, -3.0])     # (one NaN, no -0.0: their tie order is unspecified)
+    b = OrderedDict([("s", OCol("Utf8", svals, np.array([1, 1, 1, 1, 1, 1, 1, 0, 1, 1], bool))), ("f", OCol("Float64", fvals)),
+                     ("i", OCol("Int64", np.arange(10)))])
+    m = helpers.memory_exec(ctx, [[b]])
+    for desc in (False, True):
+        for nf in (False, True):
+            run_both(ba.SortExec([E.PhysicalSortExpr(col("s"), descending=desc, nulls_first=nf)], m), ordered=True)
+            run_both(ba.SortExec([E.PhysicalSortExpr(col("f"), descending=desc, nulls_first=nf), E.PhysicalSortExpr(col("s"))], m), ordered=True)
+
+
 @pytest.mark.parametrize("n", [700, 5000])
 def test_sort_by_long_strings(ctx, n):
     """Utf8 sort keys of any length (here up to 90 bytes, sharing long prefixes, with NULLs and empty strings): one

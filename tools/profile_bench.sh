@@ -30,6 +30,19 @@ for r in stats[:12]:
     lines.append(f"{k[:90]} | {r['Calls']} | {float(r['AverageNs']) / 1e6:.4f} | {fs.get(k, (0, 0))[0]:.0f} | {ws.get(k, (0, 0))[0]:.0f}")
 open(f"gpurun_out/{q}_pmc_traffic.txt", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
+# the launches of the last timed step, in stream order: start offset and duration (us) — where a step's time outside its big kernel goes
+tr = glob.glob(f"gpurun_out/prof_{q}_stats/*/*kernel_trace.csv")
+if tr:
+    rows = sorted(csv.DictReader(open(tr[0])), key=lambda r: int(r["Start_Timestamp"]))
+    big = [i for i, r in enumerate(rows) if r["Kernel_Name"] == stats[0]["Name"]]
+    per_step = max(1, len(big) // max(1, int(os.environ.get("STEPS_TOTAL", "0")) or len(big)))
+    if len(big) >= 2:
+        a = big[-1 - per_step] if len(big) > per_step else big[0]
+        t0 = int(rows[a]["Start_Timestamp"])
+        tl = ["start_us | dur_us | kernel   (from the first dominant-kernel launch of the second-to-last step to the end of the run)"]
+        for r in rows[a:]:
+            tl.append(f"{(int(r['Start_Timestamp']) - t0) / 1e3:10.1f} | {(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:8.1f} | {r['Kernel_Name'][:100]}")
+        open(f"gpurun_out/{q}_step_timeline.txt", "w").write("\n".join(tl) + "\n")
 top = stats[0]["Name"]
 json.dump({"kernel": top, "dispatches": fs.get(top, (0, 0))[1], "avg_ms": float(stats[0]["AverageNs"]) / 1e6,
            "fetch_size_kb_per_launch": fs.get(top, (0, 0))[0], "write_size_kb_per_launch": ws.get(top, (0, 0))[0],
