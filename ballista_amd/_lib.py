@@ -131,6 +131,7 @@ SYMBOLS = {
     "bhip_plan_children": (C.c_int32, [_P, C.c_int32, _PP, C.POINTER(C.c_int32)]),
     "bhip_plan_with_new_children": (C.c_int32, [_P, C.c_int32, _PP, _PP]),
     "bhip_plan_execute": (C.c_int32, [_P, C.c_int32, _PP]),
+    "bhip_plan_collect": (C.c_int32, [_P, C.c_int32, _PP, C.POINTER(C.c_int32)]),
     "bhip_plan_display": (C.c_int32, [_P, C.c_char_p, C.c_size_t]),
     "bhip_stream_next": (C.c_int32, [_P, _PP]),
     "bhip_stream_schema": (C.c_int32, [_P, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.POINTER(C.c_int32),

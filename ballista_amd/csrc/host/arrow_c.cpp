@@ -55,11 +55,12 @@ namespace {
 
 const char* format_of(int dt) { return format_of_dtype(dt); }
 
-// what the device operators carry today: the eight types of the TPC-H schemas.  The wire formats (protobuf plans, Arrow IPC
-// files) know the other primitive types too; a batch of those is refused here (BHIP_ENOTIMPL: keep the CPU operator)
+// what the device operators carry: every primitive type the serde ships (rust/core/proto/ballista.proto:755-790) except
+// LargeUtf8, Binary, Float16, Time32/64, Interval, Duration, Decimal and the nested types — a batch of those is refused here
+// (BHIP_ENOTIMPL: keep the CPU operator); timestamps with a time zone likewise
 int device_dtype_from_format(const char* f) {
     const int dt = dtype_from_format(f);
-    return (dt >= DT_INT32 && dt <= DT_UTF8) ? dt : 0;
+    return (dt >= DT_INT32 && dt <= DT_LAST) ? dt : 0;
 }
 
 // copy n bits starting at bit `off` of src into a fresh, zero-padded bitmap

@@ -423,10 +423,37 @@ bhip_status bhip_plan_execute(bhip_plan* p, int32_t partition, bhip_stream** out
     ContextPtr ctx = p->p->context();
     if (!ctx) fail(BHIP_EEXEC, "Ballista Error: this plan has unresolved leaves and no device context; it can be inspected, not executed");
     ctx->set_device();
+    trace_point("plan_execute: enter");
     auto h = std::unique_ptr<bhip_stream>(new bhip_stream());
     h->ex = Exec{ctx, ctx->acquire_stream()};
     h->s = p->p->execute(partition, h->ex);
     *out = h.release();
+    trace_point("plan_execute: leave");
+    BHIP_API_END
+}
+
+bhip_status bhip_plan_collect(bhip_plan* p, int32_t cap, bhip_batch** out, int32_t* n_out) {
+    BHIP_API_BEGIN
+    need(p, "plan"); need(out, "out"); need(n_out, "n_out");
+    ContextPtr ctx = p->p->context();
+    if (!ctx) fail(BHIP_EEXEC, "Ballista Error: this plan has unresolved leaves and no device context; it can be inspected, not executed");
+    ctx->set_device();
+    trace_point("plan_collect: enter");
+    std::vector<BatchPtr> got;
+    {
+        const Exec ex{ctx, ctx->acquire_stream()};
+        struct Release { const Exec& ex; ~Release() { ex.ctx->release_stream(ex.stream); } } release{ex};
+        const int n_parts = p->p->output_partitioning().count;
+        for (int part = 0; part < n_parts; ++part) {
+            StreamPtr s = p->p->execute(part, ex);
+            while (BatchPtr b = s->next()) got.push_back(b);
+        }
+        ctx->wait_stream(ex.stream);               // batches only leave the library once everything that produces them has finished
+    }
+    if ((int64_t)got.size() > cap) fail(BHIP_EINVAL, "bhip_plan_collect: the plan yields " + std::to_string(got.size()) + " batches, the caller has room for " + std::to_string(cap));
+    for (size_t i = 0; i < got.size(); ++i) out[i] = wrap_batch(got[i]);
+    *n_out = (int32_t)got.size();
+    trace_point("plan_collect: leave");
     BHIP_API_END
 }
 
@@ -435,10 +462,13 @@ bhip_status bhip_stream_next(bhip_stream* s, bhip_batch** out) {
     BHIP_API_BEGIN
     need(s, "stream"); need(out, "out");
     s->ex.ctx->set_device();
+    trace_point("stream_next: enter");
     BatchPtr b = s->s->next();
+    trace_point("stream_next: operators returned");
     // a batch only leaves the library once everything that produces it has finished
     if (b) s->ex.ctx->wait_stream(s->ex.stream);
     *out = b ? wrap_batch(b) : nullptr;
+    trace_point("stream_next: leave");
     BHIP_API_END
 }
 

@@ -86,7 +86,16 @@ Context::Context(int device) : device_(device) {
     }
 }
 
+void trace_point(const char* what) {
+    static const bool on = [] { const char* v = getenv("BHIP_TRACE_HOST"); return v && atoi(v) != 0; }();
+    if (!on) return;
+    static const auto t0 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[bhip-host] %10.1f %s\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), what);
+}
+
 void Context::wait_stream(hipStream_t stream, const void* dev_src, void* host_dst, size_t bytes) {
+    trace_point("wait: enter");
+    struct Leave { ~Leave() { trace_point("wait: leave"); } } leave;
     if (!spin_wait_ || bytes > 56 || (bytes & 3)) {
         if (bytes) HIP_CHECK(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
@@ -138,7 +147,15 @@ void* Context::alloc(size_t bytes, hipStream_t stream) {
             Block b = it->second;
             free_blocks_.erase(it);
             cached_ -= b.bytes;
-            if (b.last_stream != stream && b.ready) HIP_CHECK(hipStreamWaitEvent(stream, b.ready, 0));
+            if (b.last_stream != stream) {
+                // the block's last user was another task's stream: everything queued there so far comes first.  The event is
+                // recorded HERE, not at release — a release then costs no stream operation (a task frees hundreds of scratch
+                // buffers, and each record is a packet the command processor serialises), and reuse on the same stream, the
+                // common case, is ordered by the stream itself
+                if (!b.ready) HIP_CHECK(hipEventCreateWithFlags(&b.ready, hipEventDisableTiming));
+                HIP_CHECK(hipEventRecord(b.ready, b.last_stream));
+                HIP_CHECK(hipStreamWaitEvent(stream, b.ready, 0));
+            }
             b.last_stream = stream;
             live_[b.ptr] = b;
             in_use_ += b.bytes;
@@ -173,10 +190,7 @@ void Context::free(void* ptr, hipStream_t stream) {
     Block b = it->second;
     live_.erase(it);
     in_use_ -= b.bytes;
-    hipSetDevice(device_);
-    if (!b.ready) hipEventCreateWithFlags(&b.ready, hipEventDisableTiming);
     // work that used the block was enqueued on `stream` (the owning task's stream)
-    hipEventRecord(b.ready, stream);
     b.last_stream = stream;
     cached_ += b.bytes;
     free_blocks_.emplace(b.bytes, b);
@@ -352,7 +366,7 @@ BatchPtr batch_from_host(const ContextPtr& ctx, int n_cols, const bhip_column_de
         };
         for (int i = 0; i < n_cols && small; ++i) {
             const bhip_column_desc& d = cols[i];
-            if (d.dtype < DT_INT32 || d.dtype > DT_UTF8) { small = false; break; }
+            if (d.dtype < DT_INT32 || d.dtype > DT_LAST) { small = false; break; }
             const size_t db = d.dtype == DT_UTF8 ? (size_t)d.data_bytes : d.dtype == DT_BOOLEAN ? bitmap_bytes(n_rows) : (size_t)n_rows * dtype_width(d.dtype);
             plan(d.data ? d.data : (const void*)"", db);
             if (d.offsets) plan(d.offsets, (size_t)(n_rows + 1) * 4);
@@ -374,7 +388,7 @@ BatchPtr batch_from_host(const ContextPtr& ctx, int n_cols, const bhip_column_de
     for (int i = 0; i < n_cols; ++i) {
         const bhip_column_desc& d = cols[i];
         if (!d.name) fail(BHIP_EINVAL, "column without a name");
-        if (d.dtype < DT_INT32 || d.dtype > DT_UTF8) fail(BHIP_ENOTIMPL, std::string("unsupported data type for column ") + d.name);
+        if (d.dtype < DT_INT32 || d.dtype > DT_LAST) fail(BHIP_ENOTIMPL, std::string("unsupported data type for column ") + d.name);
         schema->fields.push_back(Field{d.name, d.dtype, d.nullable != 0 || d.validity != nullptr});
         Column c;
         c.dtype = d.dtype;

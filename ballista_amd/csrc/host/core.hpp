@@ -48,7 +48,7 @@ struct Block {               // one allocation of the caching allocator
     void* ptr = nullptr;
     size_t bytes = 0;
     hipStream_t last_stream = nullptr;
-    hipEvent_t ready = nullptr;   // recorded when the block was released
+    hipEvent_t ready = nullptr;   // recorded on last_stream only when ANOTHER stream takes the block over (Context::alloc)
 };
 
 class Context : public std::enable_shared_from_this<Context> {
@@ -248,6 +248,10 @@ BatchPtr take_batch(const Exec& ex, const Batch& in, const uint32_t* indices, in
 Column take_column(const Exec& ex, const Column& c, const uint32_t* indices, int64_t n_out, int64_t known_bytes = -1);
 BatchPtr concat_batches(const Exec& ex, const SchemaPtr& schema, const std::vector<BatchPtr>& parts);
 BatchPtr slice_head(const Exec& ex, const Batch& in, int64_t n);
+
+// BHIP_TRACE_HOST=1: one stderr line per call, "[bhip-host] <us since the first point> <what>" — where the host's time goes between
+// the launches of a task (the device side is rocprofv3's job)
+void trace_point(const char* what);
 
 // read a small device value once the task's stream has caught up (Context::wait_stream)
 template <class T>

@@ -45,8 +45,16 @@ static int math_fn(const std::string& n) {
     return -1;
 }
 
+int str_fn(const std::string& name) {
+    static const char* names[] = {"lower", "upper", "trim", "ltrim", "rtrim"};
+    for (int i = 0; i < 5; ++i)
+        if (name == names[i]) return i;
+    return -1;
+}
+
 void check_scalar_function(const std::string& name, int n_args) {
-    if (math_fn(name) < 0) fail(BHIP_ENOTIMPL, "scalar function '" + name + "' is not supported");
+    if (math_fn(name) < 0 && str_fn(name) < 0 && name != "octet_length")
+        fail(BHIP_ENOTIMPL, "scalar function '" + name + "' is not supported");
     if (n_args != 1) fail(BHIP_EINVAL, "scalar function takes one argument");
 }
 
@@ -92,7 +100,8 @@ ExprPtr parse_expr(const bhip_expr& pe) {
                     if (!n.name) fail(BHIP_EINVAL, "Utf8 literal without a value");
                     e->name = n.name;
                 }
-                if (n.dtype < DT_INT32 || n.dtype > DT_UTF8) fail(BHIP_ENOTIMPL, "literal of unsupported type");
+                if (n.dtype < DT_INT32 || n.dtype > DT_LAST) fail(BHIP_ENOTIMPL, "literal of unsupported type");
+                if (n.dtype == DT_FLOAT32) e->f64 = (double)(float)e->f64;
                 break;
             case BHIP_EXPR_BINARY: {
                 if (!n.name || !known_binary(n.name))
@@ -103,7 +112,7 @@ ExprPtr parse_expr(const bhip_expr& pe) {
             } break;
             case BHIP_EXPR_CAST:
                 e->dtype = n.dtype;
-                if (n.dtype < DT_INT32 || n.dtype > DT_UTF8) fail(BHIP_ENOTIMPL, "cast to unsupported type");
+                if (n.dtype < DT_INT32 || n.dtype > DT_LAST) fail(BHIP_ENOTIMPL, "cast to unsupported type");
                 e->args = {pop()};
                 break;
             case BHIP_EXPR_NOT:
@@ -149,6 +158,7 @@ std::string Expr::to_string() const {
         case BHIP_EXPR_LITERAL:
             if (is_null) o << "NULL:" << dtype_name(dtype);
             else if (dtype == DT_FLOAT64) { char b[40]; snprintf(b, sizeof b, "%.17g", f64); o << b; }
+            else if (dtype == DT_FLOAT32) { char b[40]; snprintf(b, sizeof b, "%.9g", f64); o << "Float32(" << b << ")"; }
             else if (dtype == DT_UTF8) o << "'" << name << "'";
             else if (dtype == DT_BOOLEAN) o << (i64 ? "true" : "false");
             else o << dtype_name(dtype) << "(" << i64 << ")";
@@ -225,20 +235,27 @@ int expr_type(const ExprPtr& e, const Schema& schema) {
             case_layout(*e, fw, np);
             return expr_type(e->args[fw + 1], schema);
         }
-        case BHIP_EXPR_SCALAR_FN: return DT_FLOAT64;
+        case BHIP_EXPR_SCALAR_FN: return str_fn(e->name) >= 0 ? DT_UTF8 : (e->name == "octet_length" ? DT_INT32 : DT_FLOAT64);
         default: fail(BHIP_ENOTIMPL, "unsupported expression kind");
     }
 }
 
 // ---- coercion -------------------------------------------------------------------------------------
+// DataFusion's numerical_coercion (datafusion 4.0.0-SNAPSHOT rev 46161d2, physical_plan/expressions/coercion.rs — the crate is not
+// vendored in the reference; rust/Cargo.lock:497-500 pins it): equal types stay; otherwise the FIRST of
+// Float64, Float32, Int64, Int32, Int16, Int8, UInt64, UInt32, UInt16, UInt8 that either side has.
 static int numeric_rank(int t) {
     switch (t) {
-        case DT_UINT8: return 1;
-        case DT_INT32:
-        case DT_DATE32: return 2;
-        case DT_INT64: return 3;
+        case DT_FLOAT64: return 10;
+        case DT_FLOAT32: return 9;
+        case DT_INT64: return 8;
+        case DT_INT32: return 7;
+        case DT_INT16: return 6;
+        case DT_INT8: return 5;
         case DT_UINT64: return 4;
-        case DT_FLOAT64: return 5;
+        case DT_UINT32: return 3;
+        case DT_UINT16: return 2;
+        case DT_UINT8: return 1;
         default: return 0;
     }
 }
@@ -246,21 +263,33 @@ static int numeric_rank(int t) {
 static int common_type(int a, int b) {
     if (a == b) return a;
     const int ra = numeric_rank(a), rb = numeric_rank(b);
-    if (ra && rb) {
-        if (a == DT_DATE32 || b == DT_DATE32) return DT_DATE32;
-        return ra >= rb ? a : b;
-    }
+    if (ra && rb) return ra >= rb ? a : b;
+    // a temporal column against an integer literal of its storage width (the planner's own casts are explicit)
+    if (dt_is_temporal(a) && rb && !dt_is_float(b)) return a;
+    if (dt_is_temporal(b) && ra && !dt_is_float(a)) return b;
     fail(BHIP_EINVAL, std::string("cannot coerce ") + dtype_name(a) + " and " + dtype_name(b));
 }
 
 static ExprPtr cast_to(const ExprPtr& x, int t, const Schema& schema) {
     if (expr_type(x, schema) == t) return x;
-    if (x->kind == BHIP_EXPR_LITERAL && !x->is_null && numeric_rank(t) && numeric_rank(x->dtype)) {
-        auto l = std::make_shared<Expr>(*x);        // a numeric literal is re-typed, not cast
-        if (t == DT_FLOAT64 && x->dtype != DT_FLOAT64) l->f64 = x->dtype == DT_UINT64 ? (double)(uint64_t)x->i64 : (double)x->i64;
-        if (t != DT_FLOAT64 && x->dtype == DT_FLOAT64) l->i64 = (int64_t)x->f64;
-        l->dtype = t;
-        return l;
+    if (x->kind == BHIP_EXPR_LITERAL && !x->is_null && (numeric_rank(t) || dt_is_temporal(t)) && numeric_rank(x->dtype)) {
+        // a numeric literal is re-typed, not cast — when the value survives (an out-of-range one stays a CAST: NULL at run time)
+        auto l = std::make_shared<Expr>(*x);
+        bool fits = true;
+        if (dt_is_float(t)) {
+            if (!dt_is_float(x->dtype)) l->f64 = x->dtype == DT_UINT64 ? (double)(uint64_t)x->i64 : (double)x->i64;
+            if (t == DT_FLOAT32) l->f64 = (double)(float)l->f64;
+        } else {
+            if (dt_is_float(x->dtype)) {
+                fits = x->f64 == (double)(int64_t)x->f64 && x->f64 >= -9.2e18 && x->f64 <= 9.2e18;
+                if (fits) l->i64 = (int64_t)x->f64;
+            }
+            int64_t lo, hi;
+            dt_int_range(t, lo, hi);
+            if (fits && !(x->dtype == DT_UINT64 && x->i64 < 0 && t != DT_UINT64)) fits = (t == DT_UINT64 && x->dtype == DT_UINT64) || (l->i64 >= lo && l->i64 <= hi);
+            else fits = false;
+        }
+        if (fits) { l->dtype = t; return l; }
     }
     auto c = std::make_shared<Expr>();
     c->kind = BHIP_EXPR_CAST;
@@ -306,7 +335,8 @@ ExprPtr coerce_expr(const ExprPtr& e, const Schema& schema) {
         }
         case BHIP_EXPR_SCALAR_FN: {
             auto c = std::make_shared<Expr>(*e);
-            for (auto& a : c->args) a = cast_to(coerce_expr(a, schema), DT_FLOAT64, schema);
+            const bool math = math_fn(e->name) >= 0;        // Signature::Uniform(1, [Float64, Float32]): the first type the argument coerces to
+            for (auto& a : c->args) a = math ? cast_to(coerce_expr(a, schema), DT_FLOAT64, schema) : coerce_expr(a, schema);
             return c;
         }
         default: {
@@ -328,9 +358,10 @@ bool expr_nullable(const ExprPtr& e, const Schema& schema) {
         case BHIP_EXPR_IS_NULL:
         case BHIP_EXPR_IS_NOT_NULL: return false;
         case BHIP_EXPR_CAST: {
+            // a cast that can fall outside the target's range yields NULLs (float -> integer, integer -> narrower integer)
             const int from = expr_type(e->args[0], schema);
-            if (from == DT_FLOAT64 && e->dtype != DT_FLOAT64) return true;
-            if (dtype_width(e->dtype) && dtype_width(from) && e->dtype != DT_FLOAT64 && from != e->dtype) return true;
+            if (dt_is_float(from) && !dt_is_float(e->dtype)) return true;
+            if (dtype_width(e->dtype) && dtype_width(from) && !dt_is_float(e->dtype) && from != e->dtype) return true;
             return expr_nullable(e->args[0], schema);
         }
         case BHIP_EXPR_CASE:
@@ -395,7 +426,7 @@ Operand ProgramBuilder::load_column(int schema_idx) {
         if ((int)loads_.size() >= VM_MAX_LOADS) fail(BHIP_ENOTIMPL, "expression loads more than 16 columns");
         const bool is_b = f.dtype == DT_BOOLEAN;
         o.index = new_vreg(is_b);
-        o.vclass = is_b ? VC_BOOL : (f.dtype == DT_FLOAT64 ? VC_F64 : VC_I64);
+        o.vclass = is_b ? VC_BOOL : (dt_is_float(f.dtype) ? VC_F64 : VC_I64);
         VmLoad ld;
         memset(&ld, 0, sizeof(ld));
         ld.col = (uint8_t)o.col;
@@ -460,7 +491,7 @@ Operand ProgramBuilder::compile(const ExprPtr& e) {
     return o;
 }
 
-static int class_of(int dtype) { return dtype == DT_FLOAT64 ? VC_F64 : (dtype == DT_BOOLEAN ? VC_BOOL : VC_I64); }
+static int class_of(int dtype) { return dt_is_float(dtype) ? VC_F64 : (dtype == DT_BOOLEAN ? VC_BOOL : VC_I64); }
 
 static int64_t parse_date(const std::string& s) {
     int y, m, d;
@@ -474,6 +505,20 @@ static int64_t parse_date(const std::string& s) {
     return era * 146097 + (int64_t)doe - 719468;
 }
 
+// multiplier between two temporal types with a common epoch (Date32 days, Date64 ms, Timestamp s/ms/us/ns); 0 = no such cast
+static int64_t temporal_units_per_day(int t) {
+    switch (t) {
+        case DT_DATE32: return 1;
+        case DT_TIMESTAMP_S: return 86400ll;
+        case DT_DATE64:
+        case DT_TIMESTAMP_MS: return 86400000ll;
+        case DT_TIMESTAMP_US: return 86400000000ll;
+        case DT_TIMESTAMP_NS: return 86400000000000ll;
+        default: return 0;
+    }
+}
+
+// CAST (arrow's cast kernel, non-"safe=false": a value the target cannot hold becomes NULL)
 Operand ProgramBuilder::compile_cast(const Operand& x, int to) {
     const int from = x.dtype;
     if (from == to) return x;
@@ -485,46 +530,68 @@ Operand ProgramBuilder::compile_cast(const Operand& x, int to) {
         o.is_lit = true;
         o.dtype = to;
         o.vclass = class_of(to);
-        if (to == DT_FLOAT64 && from != DT_FLOAT64) {
-            const double d = from == DT_UINT64 ? (double)bits : (double)(int64_t)bits;
+        if (dt_is_float(to)) {
+            double d;
+            if (dt_is_float(from)) memcpy(&d, &bits, 8);
+            else d = from == DT_UINT64 ? (double)bits : (double)(int64_t)bits;
+            if (to == DT_FLOAT32) d = dt_is_float(from) ? (double)(float)d : (from == DT_UINT64 ? (double)(float)bits : (double)(float)(int64_t)bits);
             o.index = literal_index(f64_bits(d));
             return o;
         }
-        if (to != DT_FLOAT64 && to != DT_BOOLEAN && from != DT_FLOAT64) {
+        if (to != DT_BOOLEAN && !dt_is_float(from) && from != DT_BOOLEAN && !(dt_is_temporal(from) && dt_is_temporal(to))) {
             const int64_t v = (int64_t)bits;
-            bool ok = true;
-            if (to == DT_INT32 || to == DT_DATE32) ok = v >= INT32_MIN && v <= INT32_MAX;
-            else if (to == DT_UINT8) ok = v >= 0 && v <= 255;
-            else if (to == DT_UINT64 || (from == DT_UINT64 && to == DT_INT64)) ok = v >= 0;
+            int64_t lo, hi;
+            dt_int_range(to, lo, hi);
+            const bool ok = from == DT_UINT64 ? (to == DT_UINT64 || (v >= 0 && v <= hi)) : (v >= lo && v <= hi);
             if (ok) { o.index = x.index; return o; }
         }
     }
-    if (to == DT_FLOAT64) {
+    if (dt_is_temporal(from) && dt_is_temporal(to)) {
+        // Date32 <-> Date64 <-> Timestamp(unit): the same instant in the other unit (arrow's cast multiplies / divides)
+        const int64_t uf = temporal_units_per_day(from), ut = temporal_units_per_day(to);
+        if (uf == ut) { Operand o = x; o.dtype = to; return o; }
+        Operand src = materialize(x), k;
+        k.is_lit = true;
+        k.vclass = VC_I64;
+        k.dtype = DT_INT64;
+        if (ut > uf) {
+            k.index = literal_index((uint64_t)(ut / uf));
+            Operand r = emit(OP_MUL_I64, &src, &k, false, VC_I64, to);
+            return to == DT_DATE32 ? emit(OP_WRAP_I64, &r, nullptr, false, VC_I64, to, (uint16_t)to) : r;
+        }
+        k.index = literal_index((uint64_t)(uf / ut));
+        Operand r = emit(OP_DIV_I64, &src, &k, false, VC_I64, to, 0, -1);
+        return to == DT_DATE32 ? emit(OP_WRAP_I64, &r, nullptr, false, VC_I64, to, (uint16_t)to) : r;
+    }
+    if (dt_is_float(to)) {
         if (from == DT_BOOLEAN) {
             Operand i = emit(OP_B_TO_I64, &x, nullptr, false, VC_I64, DT_INT64);
-            return emit(OP_I64_TO_F64, &i, nullptr, false, VC_F64, DT_FLOAT64);
+            return emit(to == DT_FLOAT32 ? OP_I64_TO_F32 : OP_I64_TO_F64, &i, nullptr, false, VC_F64, to);
         }
-        return emit(from == DT_UINT64 ? OP_U64_TO_F64 : OP_I64_TO_F64, &x, nullptr, false, VC_F64, DT_FLOAT64);
+        if (from == DT_FLOAT32) { Operand o = x; o.dtype = to; return o; }                      // Float32 -> Float64: the value is held as a double already
+        if (from == DT_FLOAT64) { Operand src = materialize(x); return emit(OP_ROUND_F32, &src, nullptr, false, VC_F64, to); }
+        Operand src = materialize(x);
+        if (to == DT_FLOAT32) return emit(from == DT_UINT64 ? OP_U64_TO_F32 : OP_I64_TO_F32, &src, nullptr, false, VC_F64, to);
+        return emit(from == DT_UINT64 ? OP_U64_TO_F64 : OP_I64_TO_F64, &src, nullptr, false, VC_F64, to);
     }
-    if (from == DT_FLOAT64) {
-        if (to == DT_BOOLEAN) fail(BHIP_ENOTIMPL, "cast Float64 -> Boolean");
+    if (dt_is_float(from)) {
+        if (to == DT_BOOLEAN) fail(BHIP_ENOTIMPL, std::string("cast ") + dtype_name(from) + " -> Boolean");
         creates_nulls_ = true;
         Operand src = materialize(x);
         return emit(OP_F64_TO_I64, &src, nullptr, false, VC_I64, to, (uint16_t)to);
     }
     if (to == DT_BOOLEAN) { Operand src = materialize(x); return emit(OP_I64_TO_B, &src, nullptr, true, VC_BOOL, DT_BOOLEAN); }
     if (from == DT_BOOLEAN) return emit(OP_B_TO_I64, &x, nullptr, false, VC_I64, to);
-    // int -> int
-    bool narrowing = false;
-    if (to == DT_INT32 || to == DT_DATE32) narrowing = !(from == DT_INT32 || from == DT_DATE32 || from == DT_UINT8);
-    else if (to == DT_UINT8) narrowing = true;
-    else if (to == DT_UINT64) narrowing = from != DT_UINT8;
-    else if (to == DT_INT64) narrowing = from == DT_UINT64;
+    // integer-valued -> integer-valued: a check only where the target's range does not cover the source's
+    int64_t flo, fhi, tlo, thi;
+    dt_int_range(from, flo, fhi);
+    dt_int_range(to, tlo, thi);
+    bool narrowing = flo < tlo || fhi > thi;
+    if (from == DT_UINT64) narrowing = to != DT_UINT64;
     if (!narrowing) { Operand o = x; o.dtype = to; return o; }
     creates_nulls_ = true;
     Operand src = materialize(x);
-    const uint16_t chk = (from == DT_UINT64 && to == DT_INT64) ? (uint16_t)DT_UINT64 : (uint16_t)to;
-    return emit(OP_I64_NARROW, &src, nullptr, false, VC_I64, to, chk);
+    return emit(OP_I64_NARROW, &src, nullptr, false, VC_I64, to, (uint16_t)to, -1, from == DT_UINT64 ? VF_SRC_U64 : 0);
 }
 
 Operand ProgramBuilder::to_bool(const Operand& o) {
@@ -614,21 +681,22 @@ Operand ProgramBuilder::compile_binary(const Expr& e) {
             b = emit(OP_B_TO_I64, &b, nullptr, false, VC_I64, DT_INT64);
         }
         if (a.is_lit && b.is_lit) a = materialize(a);
-        const uint8_t opc = lt == DT_FLOAT64 ? OP_CMP_F64 : (lt == DT_UINT64 ? OP_CMP_U64 : OP_CMP_I64);
+        const uint8_t opc = dt_is_float(lt) ? OP_CMP_F64 : (lt == DT_UINT64 ? OP_CMP_U64 : OP_CMP_I64);
         return emit(opc, &a, &b, true, VC_BOOL, DT_BOOLEAN, (uint16_t)cmp_kind(op));
     }
     // arithmetic
     if (lt == DT_BOOLEAN) fail(BHIP_EINVAL, "Cannot evaluate binary expression " + op + " with types Boolean and Boolean");
     if (a.is_lit && b.is_lit) a = materialize(a);
-    const bool f = lt == DT_FLOAT64;
+    const bool f = dt_is_float(lt);
     uint8_t opc;
     if (op == "Plus") opc = f ? OP_ADD_F64 : OP_ADD_I64;
     else if (op == "Minus") opc = f ? OP_SUB_F64 : OP_SUB_I64;
     else if (op == "Multiply") opc = f ? OP_MUL_F64 : OP_MUL_I64;
     else opc = f ? OP_DIV_F64 : OP_DIV_I64;
-    Operand r = emit(opc, &a, &b, false, f ? VC_F64 : VC_I64, lt, 0, opc == OP_DIV_I64 ? pred_vreg_ : -1);
-    if (!f && (lt == DT_INT32 || lt == DT_UINT8 || lt == DT_DATE32))
-        r = emit(OP_WRAP_I64, &r, nullptr, false, VC_I64, lt, (uint16_t)lt);
+    Operand r = emit(opc, &a, &b, false, f ? VC_F64 : VC_I64, lt, 0, opc == OP_DIV_I64 ? pred_vreg_ : -1,
+                     opc == OP_DIV_I64 && lt == DT_UINT64 ? VF_SRC_U64 : 0);
+    if (lt == DT_FLOAT32) r = emit(OP_ROUND_F32, &r, nullptr, false, VC_F64, lt);          // every Float32 node rounds to float
+    else if (!f && dt_width(lt) < 8) r = emit(OP_WRAP_I64, &r, nullptr, false, VC_I64, lt, (uint16_t)lt);
     return r;
 }
 
@@ -659,7 +727,7 @@ Operand ProgramBuilder::compile_uncached(const ExprPtr& ep) {
                 return emit(OP_MOV_V, &z, nullptr, false, o.vclass, e.dtype, 1);
             }
             o.is_lit = true;
-            o.index = literal_index(e.dtype == DT_FLOAT64 ? f64_bits(e.f64) : (uint64_t)e.i64);
+            o.index = literal_index(dt_is_float(e.dtype) ? f64_bits(e.f64) : (uint64_t)e.i64);
             return o;
         }
         case BHIP_EXPR_BINARY: return compile_binary(e);
@@ -696,8 +764,8 @@ Operand ProgramBuilder::compile_uncached(const ExprPtr& ep) {
             const int t = expr_type(e.args[0], schema_);
             if (t == DT_BOOLEAN || t == DT_UTF8) fail(BHIP_EINVAL, std::string("Cannot negate ") + dtype_name(t));
             Operand a = materialize(compile(e.args[0]));
-            Operand r = emit(t == DT_FLOAT64 ? OP_NEG_F64 : OP_NEG_I64, &a, nullptr, false, a.vclass, t);
-            if (t == DT_INT32 || t == DT_UINT8 || t == DT_DATE32) r = emit(OP_WRAP_I64, &r, nullptr, false, VC_I64, t, (uint16_t)t);
+            Operand r = emit(dt_is_float(t) ? OP_NEG_F64 : OP_NEG_I64, &a, nullptr, false, a.vclass, t);
+            if (!dt_is_float(t) && dt_width(t) < 8) r = emit(OP_WRAP_I64, &r, nullptr, false, VC_I64, t, (uint16_t)t);
             return r;
         }
         case BHIP_EXPR_IN_LIST: {
@@ -746,6 +814,15 @@ Operand ProgramBuilder::compile_uncached(const ExprPtr& ep) {
             return result;
         }
         case BHIP_EXPR_SCALAR_FN: {
+            if (e.name == "octet_length") {
+                if (expr_type(e.args[0], schema_) != DT_UTF8) fail(BHIP_EINVAL, "octet_length requires a Utf8 argument");
+                Operand a = compile(e.args[0]);
+                if (!a.is_utf8_col) fail(BHIP_ENOTIMPL, "octet_length of a Utf8 expression that is not a column");
+                Operand o = emit(OP_STR_LEN, nullptr, nullptr, false, VC_I64, DT_INT32);
+                instrs_.back().ins.c = (uint8_t)a.col;
+                return o;
+            }
+            if (str_fn(e.name) >= 0) fail(BHIP_ENOTIMPL, "expression producing Utf8: " + e.name + "() (evaluated as a column, host/utf8_exprs.cpp)");
             if (expr_type(e.args[0], schema_) != DT_FLOAT64) fail(BHIP_EINVAL, e.name + " requires a Float64 argument");
             Operand a = materialize(compile(e.args[0]));
             return emit(OP_MATH_F64, &a, nullptr, false, VC_F64, DT_FLOAT64, (uint16_t)math_fn(e.name));
@@ -779,7 +856,8 @@ void ProgramBuilder::add_key(const ExprPtr& e, bool force_not_null) {
         o = materialize(o);
         k.src = o.index;
         if (o.vclass == VC_BOOL) { k.kind = KP_BSLOT; k.width = 1; }
-        else { k.kind = t == DT_FLOAT64 ? KP_VSLOT_F64 : KP_VSLOT; k.width = dtype_width(t); }
+        // (a Float32 key part holds the double's bits: 8 bytes, turned back into a float when the group table is emitted)
+        else { k.kind = dt_is_float(t) ? KP_VSLOT_F64 : KP_VSLOT; k.width = t == DT_FLOAT32 ? 8 : dtype_width(t); }
         k.width += nullable ? 1 : 0;
     }
     keys_.push_back(k);

@@ -71,6 +71,9 @@ struct Operand {
     int col = -1;
 };
 
+// index of a string-valued scalar function (lower, upper, trim, ltrim, rtrim; evaluated as columns, utf8_exprs.cpp), -1 otherwise
+int str_fn(const std::string& name);
+
 class ProgramBuilder {
 public:
     explicit ProgramBuilder(const Schema& input);

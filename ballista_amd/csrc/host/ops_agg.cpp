@@ -17,9 +17,10 @@
 
 namespace bhip {
 
+// sum_return_type of DataFusion 4.0 (physical_plan/aggregates.rs): signed -> Int64, unsigned -> UInt64, Float32 -> Float32, Float64 -> Float64
 static int sum_type(int t) {
-    if (t == DT_FLOAT64) return DT_FLOAT64;
-    if (t == DT_UINT8 || t == DT_UINT64) return DT_UINT64;
+    if (dt_is_float(t)) return t;
+    if (dt_is_unsigned(t)) return DT_UINT64;
     return DT_INT64;
 }
 
@@ -71,6 +72,18 @@ HashAggregateExec::HashAggregateExec(int mode, std::vector<std::pair<ExprPtr, st
         }
     }
     schema_ = s;
+    // string nodes in the expressions, MIN / MAX over Utf8: run_strings (ops_agg_wide.cpp)
+    for (auto& g : group_) strings_ = strings_ || has_utf8_node(g.first, in) || (g.first->kind == BHIP_EXPR_LITERAL && g.first->dtype == DT_UTF8);
+    size_t sp = group_.size();
+    for (auto& a : aggr_) {
+        if (mode == BHIP_AGG_PARTIAL) {
+            strings_ = strings_ || has_utf8_node(a.arg, in);
+            if ((a.fn == BHIP_AGG_MIN || a.fn == BHIP_AGG_MAX) && expr_type(a.arg, in) == DT_UTF8) strings_ = true;
+        } else {
+            if ((a.fn == BHIP_AGG_MIN || a.fn == BHIP_AGG_MAX) && in.fields[sp].dtype == DT_UTF8) strings_ = true;
+            sp += a.fn == BHIP_AGG_AVG ? 2 : 1;
+        }
+    }
 }
 
 PlanPtr HashAggregateExec::with_new_children(const std::vector<PlanPtr>& c) const {
@@ -113,11 +126,15 @@ FusedInput fuse_below(const PlanPtr& input, std::vector<ExprPtr> group, std::vec
     f.args = std::move(args);
     for (;;) {
         if (auto* flt = dynamic_cast<const FilterExec*>(f.source.get())) {
+            if (has_utf8_node(flt->predicate(), *flt->input()->schema())) break;      // string nodes: the filter runs on its own (utf8_exprs.cpp)
             f.predicate = f.predicate ? make_binary(flt->predicate(), "And", f.predicate) : flt->predicate();
             f.source = flt->input();
         } else if (auto* co = dynamic_cast<const CoalesceBatchesExec*>(f.source.get())) {
             f.source = co->input();
         } else if (auto* pr = dynamic_cast<const ProjectionExec*>(f.source.get())) {
+            bool strings = false;
+            for (auto& en : pr->exprs()) strings = strings || has_utf8_node(en.first, *pr->input()->schema()) || (en.first->kind == BHIP_EXPR_LITERAL && en.first->dtype == DT_UTF8);
+            if (strings) break;
             std::map<std::string, ExprPtr> subst;
             for (auto& en : pr->exprs()) subst[en.second] = en.first;
             for (auto& g : f.group) g = substitute(g, subst);
@@ -300,7 +317,8 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
             const bool lit_nonnull = arg->kind == BHIP_EXPR_LITERAL && !arg->is_null;
             switch (a.fn) {
                 case BHIP_AGG_SUM: {
-                    const int acc = add_acc(t == DT_FLOAT64 ? ACC_SUM_F64 : ACC_SUM_I64, arg);
+                    // (SUM(Float32) adds doubles and rounds the total to float once: closer to the exact sum than the reference's running float)
+                    const int acc = add_acc(dt_is_float(t) ? ACC_SUM_F64 : ACC_SUM_I64, arg);
                     emit(EMIT_VALUE, acc, 0, sum_type(t));
                 } break;
                 case BHIP_AGG_AVG: {
@@ -345,9 +363,10 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
                     emit(EMIT_RAW, acc, 0, DT_UINT64);
                 } break;
                 default: {
-                    if (t == DT_UTF8 || t == DT_BOOLEAN) fail(BHIP_ENOTIMPL, "MIN/MAX over Utf8 or Boolean");
+                    if (t == DT_UTF8) fail(BHIP_ENOTIMPL, "MIN/MAX over Utf8 on the packed-key path (run_strings handles it)");
+                    if (t == DT_BOOLEAN) fail(BHIP_ENOTIMPL, "MIN/MAX over Boolean");
                     const bool is_min = a.fn == BHIP_AGG_MIN;
-                    const int kind = t == DT_FLOAT64 ? (is_min ? ACC_MIN_F64 : ACC_MAX_F64) : (is_min ? ACC_MIN_I64 : ACC_MAX_I64);
+                    const int kind = dt_is_float(t) ? (is_min ? ACC_MIN_F64 : ACC_MAX_F64) : (is_min ? ACC_MIN_I64 : ACC_MAX_I64);
                     emit(EMIT_VALUE, add_acc(kind, arg), 0, t);
                 } break;
             }
@@ -356,7 +375,7 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
             const int t = expr_type(st0, src_schema);
             switch (a.fn) {
                 case BHIP_AGG_SUM: {
-                    const int acc = add_acc(t == DT_FLOAT64 ? ACC_SUM_F64 : ACC_SUM_I64, st0);
+                    const int acc = add_acc(dt_is_float(t) ? ACC_SUM_F64 : ACC_SUM_I64, st0);
                     emit(EMIT_VALUE, acc, 0, t);
                 } break;
                 case BHIP_AGG_AVG: {
@@ -368,7 +387,7 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
                 case BHIP_AGG_COUNT: emit(EMIT_RAW, add_acc(ACC_SUM_I64, st0), 0, DT_UINT64); break;
                 default: {
                     const bool is_min = a.fn == BHIP_AGG_MIN;
-                    const int kind = t == DT_FLOAT64 ? (is_min ? ACC_MIN_F64 : ACC_MAX_F64) : (is_min ? ACC_MIN_I64 : ACC_MAX_I64);
+                    const int kind = dt_is_float(t) ? (is_min ? ACC_MIN_F64 : ACC_MAX_F64) : (is_min ? ACC_MIN_I64 : ACC_MAX_I64);
                     emit(EMIT_VALUE, add_acc(kind, st0), 0, t);
                 } break;
             }
@@ -398,6 +417,7 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
         while (BatchPtr b = s->next())
             if (b->n_rows > 0) inputs.push_back(b);
     }
+    trace_point("aggregate: inputs ready");
     bool nullable = pb.creates_nulls();
     for (auto& b : inputs)
         for (int ci : pb.columns())
@@ -435,6 +455,47 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
         out->n_rows = n_alloc;
         const auto& kinfo = sop_layout ? sop.key_info : pb.key_info();
         utf8_cols.clear();
+        if (dev_n && n_alloc <= EMIT_ALL_MAX_GROUPS && group_.size() <= (size_t)EMIT_ALL_MAX_KEYS && emits.size() <= (size_t)EMIT_ALL_MAX_VALUES) {
+            // the small table of the register path: every column in ONE launch, count read on the device
+            EmitAllArgs A;
+            memset(&A, 0, sizeof(A));
+            A.table = tab;
+            A.status = dev_n;
+            A.n_keys = (int32_t)group_.size();
+            A.n_values = (int32_t)emits.size();
+            for (size_t gi = 0; gi < group_.size(); ++gi) {
+                Column c;
+                c.dtype = out_schema->fields[gi].dtype;
+                c.length = n_alloc;
+                A.key[gi] = EmitKeySpec{kinfo[gi].pos, kinfo[gi].width, kinfo[gi].nullable, c.dtype};
+                if (kinfo[gi].nullable) { c.validity = make_buffer(ex, bitmap_bytes(n_alloc) + 8); A.key_validity[gi] = c.validity->as<uint64_t>(); }
+                if (c.dtype == DT_UTF8) {
+                    c.offsets = make_buffer(ex, (size_t)(n_alloc + 1) * 4);
+                    c.data = make_buffer(ex, (size_t)n_alloc * (size_t)kinfo[gi].width + 8);
+                    A.key_offsets[gi] = c.offsets->as<int32_t>();
+                    A.key_total[gi] = totals + gi;
+                    utf8_cols.push_back(gi);
+                } else {
+                    c.data = make_buffer(ex, (c.dtype == DT_BOOLEAN ? bitmap_bytes(n_alloc) : (size_t)n_alloc * dtype_width(c.dtype)) + 8);
+                }
+                A.key_data[gi] = c.data->ptr();
+                out->cols.push_back(std::move(c));
+            }
+            for (size_t k = 0; k < emits.size(); ++k) {
+                const Field& fld = out_schema->fields[group_.size() + k];
+                Column c;
+                c.dtype = fld.dtype;
+                c.length = n_alloc;
+                c.data = make_buffer(ex, (size_t)n_alloc * dtype_width(c.dtype) + 8);
+                if (fld.nullable) { c.validity = make_buffer(ex, bitmap_bytes(n_alloc) + 8); A.value_validity[k] = c.validity->as<uint64_t>(); }
+                A.value[k] = emits[k];
+                A.value[k].count_is_rows = nullable ? 0 : 1;
+                A.value_data[k] = c.data->ptr();
+                out->cols.push_back(std::move(c));
+            }
+            TIMED_LAUNCH(ex, "emit_all", launch_emit_all(cfg, A));
+            return out;
+        }
         for (size_t gi = 0; gi < group_.size(); ++gi) {
             Column c;
             c.dtype = out_schema->fields[gi].dtype;
@@ -570,6 +631,7 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
         // count read on the device, so the host waits ONCE per aggregate (the result is dropped if the ladder has to go on)
         early.reset();
         if (!sampling && !no_early_emit && group_.size() <= (size_t)TAIL_TOTALS) early = emit_table(table, cap, status);
+        trace_point("aggregate: scan + merge + emit queued");
         tail = read_device(ex, info);
         const ScanStatus st = tail.st;
         timer.collect();
@@ -613,6 +675,7 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
         n_groups = 1;
     }
 
+    trace_point("aggregate: done");
     if (early) {
         // the emit was queued behind the merge; the single read above brought the count and the Utf8 totals
         finish_table(early, n_groups, tail.totals);

@@ -7,6 +7,7 @@
 //      (hash table of row ids over 64-bit row hashes; equality on the key columns themselves, NULL == NULL);
 //   2. the ordinary aggregate runs with that ONE Int32 column as its key, and the key columns of the result are
 //      gathered from the input at the representative rows.
+#include "../str_kernels.h"
 #include "hash_kernels.h"
 #include "plan.hpp"
 
@@ -33,7 +34,7 @@ bool HashAggregateExec::run_single_partial(const Exec& ex, std::vector<BatchPtr>
         break;
     }
     auto pa = dynamic_cast<const HashAggregateExec*>(p);
-    if (!pa || !below || pa->mode_ != BHIP_AGG_PARTIAL || pa->output_partitioning().count != 1) return false;
+    if (!pa || !below || pa->mode_ != BHIP_AGG_PARTIAL || pa->output_partitioning().count != 1 || pa->strings_) return false;
     if (pa->group_.size() != group_.size() || pa->aggr_.size() != aggr_.size()) return false;
     const Schema& ps = *pa->schema();
     // this operator's keys must be the partial's key columns, in order, and the functions must be the same
@@ -74,6 +75,7 @@ bool HashAggregateExec::run_single_partial(const Exec& ex, std::vector<BatchPtr>
 }
 
 std::vector<BatchPtr> HashAggregateExec::run(int partition, const Exec& ex) const {
+    if (strings_) return run_strings(partition, ex);
     {
         std::vector<BatchPtr> out;
         if (run_single_partial(ex, out)) return out;
@@ -172,6 +174,118 @@ std::vector<BatchPtr> HashAggregateExec::run_wide(int partition, const Exec& ex)
         std::vector<Column> got = take_columns(ex, kp, r->cols[0].data->as<uint32_t>(), r->n_rows, false);
         for (auto& c : got) out->cols.push_back(std::move(c));
         for (size_t i = 1; i < r->cols.size(); ++i) out->cols.push_back(r->cols[i]);
+        outv.push_back(out);
+    }
+    stream_wait(ex);
+    return outv;
+}
+
+// ---- string nodes in the keys / arguments, MIN / MAX over Utf8 -------------------------------------------------------
+// MIN(s) over strings = the string at the smallest position in the sort order of s: the column is sorted once (the SortExec
+// passes), every row gets its rank as an Int64 with the string's validity, the ordinary aggregate takes MIN / MAX of the ranks,
+// and the result's strings are gathered through the sort permutation.
+std::vector<BatchPtr> HashAggregateExec::run_strings(int partition, const Exec& ex) const {
+    const SchemaPtr in_schema = input_->schema();
+    std::vector<BatchPtr> parts;
+    {
+        auto s = input_->execute(partition, ex);
+        while (BatchPtr b = s->next())
+            if (b->n_rows > 0) parts.push_back(b);
+    }
+    BatchPtr in;
+    if (parts.empty()) {
+        auto e = std::make_shared<Batch>();
+        e->schema = in_schema;
+        e->ctx = ex.ctx;
+        for (auto& f : in_schema->fields) {
+            Column c;
+            c.dtype = f.dtype;
+            c.data = make_buffer(ex, 8);
+            if (f.dtype == DT_UTF8) { c.offsets = make_buffer(ex, 8); HIP_CHECK(hipMemsetAsync(c.offsets->ptr(), 0, 8, ex.stream)); }
+            e->cols.push_back(c);
+        }
+        in = e;
+    } else {
+        in = parts.size() == 1 ? parts[0] : concat_batches(ex, in_schema, parts);
+    }
+    parts.clear();
+    const int64_t n = in->n_rows;
+    const LaunchCfg cfg = ex.cfg();
+
+    // the string nodes as columns
+    Utf8Lowering low(*in_schema);
+    std::vector<std::pair<ExprPtr, std::string>> group2;
+    for (auto& g : group_) group2.push_back({low.rewrite(g.first, true), g.second});
+    std::vector<AggregateDesc> aggr2 = aggr_;
+    if (mode_ == BHIP_AGG_PARTIAL)
+        for (auto& a : aggr2) a.arg = low.rewrite(a.arg, true);
+    const BatchPtr aug = low.any() ? low.apply(ex, *in) : in;
+    auto s2 = std::make_shared<Schema>(*aug->schema);
+    auto b2 = std::make_shared<Batch>(*aug);
+
+    // MIN / MAX over Utf8 -> over ranks
+    struct Ranked { size_t agg; Column strings; BufferPtr perm; };
+    std::vector<Ranked> ranked;
+    size_t pos = group_.size();
+    for (size_t i = 0; i < aggr2.size(); ++i) {
+        AggregateDesc& a = aggr2[i];
+        const size_t state_pos = pos;
+        pos += a.fn == BHIP_AGG_AVG ? 2 : 1;
+        if (a.fn != BHIP_AGG_MIN && a.fn != BHIP_AGG_MAX) continue;
+        int ci;
+        if (mode_ == BHIP_AGG_PARTIAL) {
+            if (expr_type(a.arg, *s2) != DT_UTF8) continue;
+            if (a.arg->kind != BHIP_EXPR_COLUMN) fail(BHIP_ENOTIMPL, "MIN/MAX over a Utf8 expression: " + a.arg->to_string());
+            ci = s2->index_of(a.arg->name);
+        } else {
+            ci = (int)state_pos;
+            if (s2->fields[ci].dtype != DT_UTF8) continue;
+        }
+        const Column strings = aug->cols[ci];
+        Ranked r;
+        r.agg = i;
+        r.strings = strings;
+        Column rank;
+        rank.dtype = DT_INT64;
+        rank.length = n;
+        rank.data = make_buffer(ex, (size_t)n * 8 + 8);
+        rank.validity = strings.validity;
+        if (n > 0) {
+            r.perm = sort_permutation(ex, *aug, {SortDesc{make_column(s2->fields[ci].name), false, false}});
+            TIMED_LAUNCH_N(ex, "invert_perm", n, launch_invert_perm(cfg, r.perm->as<uint32_t>(), n, rank.data->as<int64_t>()));
+        }
+        if (mode_ == BHIP_AGG_PARTIAL) {
+            const std::string name = "__rank_" + std::to_string(i);
+            s2->fields.push_back(Field{name, DT_INT64, s2->fields[ci].nullable});
+            b2->cols.push_back(rank);
+            a.arg = make_column(name);
+        } else {
+            s2->fields[ci].dtype = DT_INT64;                  // Final reads its states by position
+            b2->cols[ci] = rank;
+        }
+        ranked.push_back(std::move(r));
+    }
+    b2->schema = s2;
+    auto src = std::make_shared<MemoryExec>(ex.ctx, s2, std::vector<std::vector<BatchPtr>>{{BatchPtr(b2)}});
+    auto inner = std::make_shared<HashAggregateExec>(mode_, group2, aggr2, src);
+    if (inner->strings_) fail(BHIP_ENOTIMPL, "aggregate over string expressions: " + describe());
+    std::vector<BatchPtr> res = inner->run(0, ex);
+
+    std::vector<BatchPtr> outv;
+    for (auto& r : res) {
+        auto out = std::make_shared<Batch>(*r);
+        out->schema = schema_;
+        for (auto& rk : ranked) {
+            size_t col = group_.size();
+            for (size_t i = 0; i < rk.agg; ++i) col += aggr_[i].fn == BHIP_AGG_AVG && mode_ == BHIP_AGG_PARTIAL ? 2 : 1;
+            const Column& ranks = r->cols[col];
+            BufferPtr idx = make_buffer(ex, (size_t)r->n_rows * 4 + 8);
+            TIMED_LAUNCH_N(ex, "rank_to_row", r->n_rows, launch_rank_to_row(cfg, ranks.data->as<int64_t>(), ranks.validity ? ranks.validity->as<uint64_t>() : nullptr,
+                                                                             rk.perm ? rk.perm->as<uint32_t>() : nullptr, r->n_rows, idx->as<uint32_t>()));
+            std::vector<const Column*> one{&rk.strings};
+            out->cols[col] = take_columns(ex, one, idx->as<uint32_t>(), r->n_rows, /*may_null=*/true, false)[0];
+            stream_wait(ex);                                    // idx is released here
+        }
         outv.push_back(out);
     }
     stream_wait(ex);

@@ -252,6 +252,13 @@ BatchPtr slice_head(const Exec& ex, const Batch& in, int64_t n) {
 
 // ---- filter ------------------------------------------------------------------------------------------
 int64_t filter_indices(const Exec& ex, const Batch& in, const ExprPtr& predicate, BufferPtr& indices_out) {
+    if (has_utf8_node(predicate, *in.schema)) {
+        // lower(s) = 'x', CASE ... THEN 'a' ... : the string nodes become columns first
+        Utf8Lowering low(*in.schema);
+        const ExprPtr p2 = low.rewrite(predicate);
+        const BatchPtr aug = low.apply(ex, in);
+        return filter_indices(ex, *aug, p2, indices_out);
+    }
     ProgramBuilder pb(*in.schema);
     pb.set_predicate(predicate);
     ScanParams P;
@@ -321,8 +328,12 @@ FilterExec::FilterExec(ExprPtr predicate, PlanPtr input) : predicate_(std::move(
     if (expr_type(predicate_, *input_->schema()) != DT_BOOLEAN)
         fail(BHIP_EINVAL, "Filter predicate must return boolean values, not " +
                               std::string(dtype_name(expr_type(predicate_, *input_->schema()))));
-    ProgramBuilder pb(*input_->schema());
-    pb.set_predicate(predicate_);   // surfaces BHIP_ENOTIMPL at plan time
+    Utf8Lowering low(*input_->schema());
+    const ExprPtr lowered = low.rewrite(predicate_);
+    low.validate();
+    const SchemaPtr aug = low.schema();
+    ProgramBuilder pb(*aug);
+    pb.set_predicate(lowered);      // surfaces BHIP_ENOTIMPL at plan time
 }
 PlanPtr FilterExec::with_new_children(const std::vector<PlanPtr>& c) const {
     if (c.size() != 1) fail(BHIP_EINVAL, "FilterExec wrong number of children");
@@ -351,15 +362,18 @@ ProjectionExec::ProjectionExec(std::vector<std::pair<ExprPtr, std::string>> expr
     ctx_ = input_->context();
     auto s = std::make_shared<Schema>();
     const Schema& in = *input_->schema();
-    ProgramBuilder pb(in);
+    Utf8Lowering low(in);
+    std::vector<ExprPtr> lowered;
     for (auto& en : exprs_) {
         const int t = expr_type(en.first, in);
         s->fields.push_back(Field{en.second, t, expr_nullable(en.first, in)});
-        if (en.first->kind != BHIP_EXPR_COLUMN) {
-            if (t == DT_UTF8) fail(BHIP_ENOTIMPL, "projection expression producing Utf8");
-            pb.add_output(en.first);
-        }
+        lowered.push_back(low.rewrite(en.first, /*output=*/true));
     }
+    low.validate();
+    const SchemaPtr aug = low.schema();
+    ProgramBuilder pb(*aug);                                  // plan-time check of everything the VM will be asked to do
+    for (auto& e : lowered)
+        if (e->kind != BHIP_EXPR_COLUMN) pb.add_output(e);
     schema_ = s;
 }
 PlanPtr ProjectionExec::with_new_children(const std::vector<PlanPtr>& c) const {
@@ -374,6 +388,17 @@ std::string ProjectionExec::describe() const {
 
 BatchPtr project_batch(const Exec& ex, const Batch& in, const std::vector<std::pair<ExprPtr, std::string>>& exprs,
                        const SchemaPtr& schema) {
+    {
+        bool strings = false;
+        for (auto& en : exprs) strings = strings || has_utf8_node(en.first, *in.schema) || (en.first->kind == BHIP_EXPR_LITERAL && en.first->dtype == DT_UTF8);
+        if (strings) {
+            Utf8Lowering low(*in.schema);
+            std::vector<std::pair<ExprPtr, std::string>> e2;
+            for (auto& en : exprs) e2.push_back({low.rewrite(en.first, /*output=*/true), en.second});
+            const BatchPtr aug = low.apply(ex, in);
+            return project_batch(ex, *aug, e2, schema);
+        }
+    }
     auto out = std::make_shared<Batch>();
     out->schema = schema;
     out->ctx = in.ctx;
@@ -430,7 +455,6 @@ BatchPtr project_batch(const Exec& ex, const Batch& in, const std::vector<std::p
 Column evaluate_column(const Exec& ex, const Batch& in, const ExprPtr& e) {
     auto s = std::make_shared<Schema>();
     s->fields.push_back(Field{"v", expr_type(e, *in.schema), expr_nullable(e, *in.schema)});
-    if (e->kind != BHIP_EXPR_COLUMN && s->fields[0].dtype == DT_UTF8) fail(BHIP_ENOTIMPL, "expression producing Utf8");
     BatchPtr b = project_batch(ex, in, {{e, "v"}}, s);
     return b->cols[0];
 }

@@ -42,10 +42,12 @@ void radix_sort_pairs(const Exec& ex, BufferPtr& keys, BufferPtr& perm, int64_t 
 SortExec::SortExec(std::vector<SortDesc> exprs, PlanPtr input) : exprs_(std::move(exprs)) {
     input_ = std::move(input);
     ctx_ = input_->context();
+    Utf8Lowering low(*input_->schema());
     for (auto& s : exprs_) {
-        const int t = expr_type(s.expr, *input_->schema());
-        if (t == DT_UTF8 && s.expr->kind != BHIP_EXPR_COLUMN) fail(BHIP_ENOTIMPL, "sort key expression producing Utf8");
+        expr_type(s.expr, *input_->schema());
+        low.rewrite(s.expr, true);
     }
+    low.validate();                        // a key like lower(s) is evaluated as a column first (utf8_exprs.cpp)
 }
 PlanPtr SortExec::with_new_children(const std::vector<PlanPtr>& c) const {
     if (c.size() != 1) fail(BHIP_EINVAL, "SortExec wrong number of children");
@@ -71,6 +73,7 @@ StreamPtr SortExec::execute(int partition, const Exec& ex) const {
                 if (b->n_rows > 0) parts.push_back(b);
         }
         if (parts.empty()) return {};
+        trace_point("sort: input ready");
         BatchPtr in = concat_batches(ex, self->schema(), parts);
         const int64_t n = in->n_rows;
         const LaunchCfg cfg = ex.cfg();
@@ -119,13 +122,27 @@ StreamPtr SortExec::execute(int partition, const Exec& ex) const {
                 out->cols.push_back(std::move(o));
             }
             TIMED_LAUNCH(ex, "rowsort", launch_rowsort(cfg, A));
+            trace_point("sort: queued");
             return {out};                                       // stream order: the consumer's work (or its wait) comes after the launch
         }
+        BufferPtr perm = sort_permutation(ex, *in, self->exprs_);
+        BatchPtr out = take_batch(ex, *in, perm->as<uint32_t>(), n, nullptr, /*permutation=*/true);
+        stream_wait(ex);
+        return {out};
+    }));
+}
+
+// the stable order of `in`'s rows under the keys (LSD: last key first, each key an order-preserving u64 image)
+BufferPtr sort_permutation(const Exec& ex, const Batch& batch, const std::vector<SortDesc>& exprs) {
+    const Batch* in = &batch;
+    const int64_t n = batch.n_rows;
+    const LaunchCfg cfg = ex.cfg();
+    {
         BufferPtr perm = make_buffer(ex, (size_t)n * 4 + 8);
         BufferPtr keys = make_buffer(ex, (size_t)n * 8 + 8);
         TIMED_LAUNCH(ex, "iota_u32", launch_iota_u32(cfg, perm->as<uint32_t>(), n, 0));
-        for (size_t k = self->exprs_.size(); k-- > 0;) {
-            const SortDesc& sd = self->exprs_[k];
+        for (size_t k = exprs.size(); k-- > 0;) {
+            const SortDesc& sd = exprs[k];
             const Column col = evaluate_column(ex, *in, sd.expr);
             const ColumnRef cr = col.ref();
             if (col.dtype == DT_UTF8) {
@@ -153,10 +170,8 @@ StreamPtr SortExec::execute(int partition, const Exec& ex) const {
                 radix_sort_pairs(ex, keys, perm, n);
             }
         }
-        BatchPtr out = take_batch(ex, *in, perm->as<uint32_t>(), n, nullptr, /*permutation=*/true);
-        stream_wait(ex);
-        return {out};
-    }));
+        return perm;
+    }
 }
 
 // ---- hash partitioning ----------------------------------------------------------------------------------

@@ -210,11 +210,15 @@ PqFile read_footer(const std::string& path) {
             case PQ_INT32:
                 if (c.logical_date || c.converted == 6) c.dtype = DT_DATE32;
                 else if (c.converted == -1 || c.converted == 17) c.dtype = DT_INT32;       // none / INT_32
-                break;
+                else if (c.converted == 13) c.dtype = DT_UINT32;                           // UINT_32: the same four bytes
+                break;                                                                     // (INT_8/16, UINT_8/16 would need a narrowing pass: declined)
             case PQ_INT64:
                 if (c.converted == -1 || c.converted == 18) c.dtype = DT_INT64;           // none / INT_64
                 else if (c.converted == 14) c.dtype = DT_UINT64;                          // UINT_64
+                else if (c.converted == 9) c.dtype = DT_TIMESTAMP_MS;                     // TIMESTAMP_MILLIS
+                else if (c.converted == 10) c.dtype = DT_TIMESTAMP_US;                    // TIMESTAMP_MICROS
                 break;
+            case PQ_FLOAT: c.dtype = DT_FLOAT32; break;
             case PQ_DOUBLE: c.dtype = DT_FLOAT64; break;
             case PQ_BYTE_ARRAY: c.dtype = DT_UTF8; break;
             default: break;
@@ -420,7 +424,7 @@ Column dictionary_column(const Exec& ex, const PqColumn& pc, const uint8_t* vals
         d.data = upload(ex, bytes.data(), bytes.size());
         d.data_bytes = (int64_t)bytes.size();
     } else {
-        const size_t w = pc.phys == PQ_INT32 ? 4 : 8;
+        const size_t w = (pc.phys == PQ_INT32 || pc.phys == PQ_FLOAT) ? 4 : 8;
         if (pc.phys == PQ_BOOLEAN) fail(BHIP_ENOTIMPL, "Parquet: dictionary-encoded BOOLEAN");
         if (nbytes < w * (size_t)n) fail(BHIP_EEXEC, "Parquet: truncated dictionary page");
         d.data = upload(ex, vals, w * (size_t)n);
@@ -436,7 +440,7 @@ Column decode_chunk(const Exec& ex, std::ifstream& in, const PqColumn& pc, const
     in.seekg(start);
     if (!in.read(reinterpret_cast<char*>(raw.data()), ch.compressed)) fail(BHIP_EEXEC, "Parquet: column chunk of '" + pc.name + "' runs past the end of the file");
     const bool optional = pc.repetition == 1;
-    const size_t width = pc.phys == PQ_INT32 ? 4 : (pc.phys == PQ_INT64 || pc.phys == PQ_DOUBLE) ? 8 : 0;
+    const size_t width = (pc.phys == PQ_INT32 || pc.phys == PQ_FLOAT) ? 4 : (pc.phys == PQ_INT64 || pc.phys == PQ_DOUBLE) ? 8 : 0;
     Column dict;
     bool have_dict = false;
     std::vector<Column> pieces;

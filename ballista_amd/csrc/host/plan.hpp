@@ -205,6 +205,10 @@ private:
     // Final over the Merge of ONE partition of a Partial aggregate with the same keys: every group arrives exactly once, the
     // merge is the identity and the operator is a projection of the state columns (AVG = sum / count)
     bool run_single_partial(const Exec& ex, std::vector<BatchPtr>& out) const;
+    // group / argument expressions with string nodes (lower(s), CASE ... THEN 'a'), MIN / MAX over Utf8: the strings become
+    // columns, MIN / MAX(Utf8) become MIN / MAX over sort ranks, and the ordinary aggregate runs on that (ops_agg_wide.cpp)
+    std::vector<BatchPtr> run_strings(int partition, const Exec& ex) const;
+    bool strings_ = false;
     int mode_;
     std::vector<std::pair<ExprPtr, std::string>> group_;
     std::vector<AggregateDesc> aggr_;
@@ -281,12 +285,33 @@ ExprPtr expr_from_proto(const void* bytes, size_t len);
 // shared helpers (ops_*.cpp)
 // evaluate `predicate` over `in` and return the surviving rows as ascending indices
 int64_t filter_indices(const Exec& ex, const Batch& in, const ExprPtr& predicate, BufferPtr& indices_out);
+
+// expressions that produce Utf8 values (lower / upper / trim / ltrim / rtrim, CASE with string branches, string literals as
+// output columns) are evaluated as extra Utf8 columns of the input batch; the rest of the expression goes to the VM with those
+// nodes replaced by column references (utf8_exprs.cpp)
+bool has_utf8_node(const ExprPtr& e, const Schema& schema);
+class Utf8Lowering {
+public:
+    explicit Utf8Lowering(const Schema& in);
+    ExprPtr rewrite(const ExprPtr& e, bool output = false);       // output: `e` is a whole output column (a bare string literal counts)
+    bool any() const { return !nodes_.empty(); }
+    SchemaPtr schema() const;                                     // the input's fields + one Utf8 field per node
+    void validate() const;                                        // BHIP_ENOTIMPL for a node this layer cannot evaluate (plan time)
+    BatchPtr apply(const Exec& ex, const Batch& in) const;        // the input's columns + the evaluated nodes
+private:
+    const Schema& in_;
+    std::vector<ExprPtr> nodes_;
+    std::vector<std::string> names_;
+};
 // split a batch by hash(exprs) % n, keeping input order inside each part
 std::vector<BatchPtr> hash_partition_batch(const Exec& ex, const BatchPtr& in, const std::vector<ExprPtr>& exprs, int n);
 void check_scan_status(const Exec& ex, const ScanStatus* dev_status, ScanStatus* host_out = nullptr);
 void check_scan_flags(const ScanStatus& host_status);   // the same checks on a status already read back
 // value of `e` over `in` as a column (a plain Column reference shares the input buffers)
 Column evaluate_column(const Exec& ex, const Batch& in, const ExprPtr& e);
+struct SortDesc;
+// SortExec's order as a row permutation (ops_sort.cpp): stable, perm[i] = the input row that goes to position i
+BufferPtr sort_permutation(const Exec& ex, const Batch& in, const std::vector<SortDesc>& exprs);
 // ProjectionExec over one batch: plain columns share their buffers, everything else is one VM launch
 BatchPtr project_batch(const Exec& ex, const Batch& in, const std::vector<std::pair<ExprPtr, std::string>>& exprs, const SchemaPtr& schema);
 // gather of one column incl. its validity bitmap

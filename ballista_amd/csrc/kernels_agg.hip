@@ -353,12 +353,26 @@ merge_reduce_kernel(const GroupRec* partials, const uint32_t* entry_group, int n
         const int kind = is_rows ? (int)ACC_COUNT_ROWS : (int)specs.acc[a].kind;
         uint64_t v = is_rows ? 0 : acc_identity(kind);
         uint64_t nv = 0;
-        for (int e = threadIdx.x; e < n_entries; e += BLOCK) {
-            if (entry_group[e] == (uint32_t)g) {
-                if (is_rows) v += partials[e].rows;
-                else {
-                    v = acc_combine(v, partials[e].acc[a], kind);   // empty partials hold the identity
-                    nv += partials[e].nvalid[a];
+        // eight records per thread at a time: their group indices first, then every value load at once (unconditional, from a
+        // safe address) — two memory latencies per eight records instead of sixteen; the combine order stays the record order
+        constexpr int U = 8;
+        for (int e0 = threadIdx.x; e0 < n_entries; e0 += BLOCK * U) {
+            uint32_t eg[U];
+            uint64_t x[U], xn[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) { const int e = e0 + k * BLOCK; eg[k] = e < n_entries ? entry_group[e] : 0xFFFFFFFFu; }
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const int e = e0 + k * BLOCK;
+                const GroupRec& p = partials[eg[k] == (uint32_t)g ? e : 0];
+                x[k] = is_rows ? p.rows : p.acc[is_rows ? 0 : a];
+                xn[k] = is_rows ? 0 : p.nvalid[is_rows ? 0 : a];
+            }
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                if (eg[k] == (uint32_t)g) {
+                    if (is_rows) v += x[k];
+                    else { v = acc_combine(v, x[k], kind); nv += xn[k]; }   // empty partials hold the identity
                 }
             }
         }

@@ -346,15 +346,8 @@ __device__ inline bool wide_keys_equal(const WideKeyCols& K, uint32_t a, uint32_
                 const uint8_t* d = static_cast<const uint8_t*>(r.data);
                 if (((d[a >> 3] >> (a & 7)) & 1) != ((d[b >> 3] >> (b & 7)) & 1)) return false;
             } break;
-            case DT_UINT8:
-                if (static_cast<const uint8_t*>(r.data)[a] != static_cast<const uint8_t*>(r.data)[b]) return false;
-                break;
-            case DT_INT32:
-            case DT_DATE32:
-                if (static_cast<const uint32_t*>(r.data)[a] != static_cast<const uint32_t*>(r.data)[b]) return false;
-                break;
-            default:                                                  // Int64 / UInt64 / Float64 (by bits)
-                if (static_cast<const uint64_t*>(r.data)[a] != static_cast<const uint64_t*>(r.data)[b]) return false;
+            default:                                                  // fixed width: by bits
+                if (dt_load(r.dtype, r.data, a) != dt_load(r.dtype, r.data, b)) return false;
                 break;
         }
     }

@@ -152,9 +152,7 @@ rank_perm_kernel(const void* __restrict__ keys_v, const uint64_t* __restrict__ s
 }
 
 // ---- probe ---------------------------------------------------------------------------------------------------------------
-constexpr int FP_ROWS = 4;                       // rows per lane and pass: their loads are in flight together
-constexpr int FP_CHUNK = 64 * FP_ROWS;           // rows of one pass of a wave
-static_assert(SEL_TILE % FP_CHUNK == 0, "a tile is a whole number of passes");
+// FP_ROWS rows per lane and pass: their loads are in flight together (template parameter: 4 or 8, launch_join_filter_probe)
 
 template <int KW>
 __device__ inline uint32_t table_lookup(const NarrowJoinTable& T, typename KeyT<KW>::type key) {
@@ -180,19 +178,23 @@ __device__ inline uint32_t table_lookup(const NarrowJoinTable& T, typename KeyT<
 }
 
 // per-wave LDS scratch of the lookup compaction: up to FP_CHUNK packed items
-struct WaveScratch {
+template <int FP_CHUNK>
+struct WaveScratchT {
     uint64_t a[FP_CHUNK];        // rank map: word index; table: the key
     uint32_t b[FP_CHUNK];        // rank map: popcount of the lower bits; then: the result (build row)
 };
 
 // NF: filter columns compiled in (0, 1 or JOIN_FILTER_MAX): registers for the ones a plan does not have would only cost occupancy
-template <int KW, int NF>
+template <int KW, int NF, int FP_ROWS>
 __global__ void __launch_bounds__(BLOCK)
 join_filter_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void* __restrict__ rkeys_v, const uint64_t* __restrict__ rsel,
                          uint32_t n_right, int right_outer, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts,
                          uint32_t* __restrict__ staging, uint32_t* matched) {
     using K = typename KeyT<KW>::type;
     constexpr int NFR = NF > 0 ? NF : 1;
+    constexpr int FP_CHUNK = 64 * FP_ROWS;           // rows of one pass of a wave
+    static_assert(SEL_TILE % FP_CHUNK == 0, "a tile is a whole number of passes");
+    using WaveScratch = WaveScratchT<FP_CHUNK>;
     __shared__ WaveScratch scratch[BLOCK / 64];
     WaveScratch& S = scratch[threadIdx.x >> 6];
     const K* __restrict__ rkeys = static_cast<const K*>(rkeys_v);
@@ -380,9 +382,16 @@ hipError_t launch_join_filter_probe(const LaunchCfg& cfg, const NarrowJoinTable&
     const int64_t need = (n_tiles + BLOCK / 64 - 1) / (BLOCK / 64);
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;
+    static const int rows = [] { const char* v = getenv("BHIP_PROBE_ROWS"); return v && atoi(v) == 8 ? 8 : 4; }();
 #define BHIP_PROBE(KW_, NF_)                                                                                                          \
-    hipLaunchKernelGGL((join_filter_probe_kernel<KW_, NF_>), dim3((unsigned)grid), dim3(BLOCK), 0, cfg.stream, T, F, rkeys, rsel, n_right,    \
-                       right_outer ? 1 : 0, bitmap, tile_counts, staging, matched)
+    do {                                                                                                                              \
+        if (rows == 8)                                                                                                                \
+            hipLaunchKernelGGL((join_filter_probe_kernel<KW_, NF_, 8>), dim3((unsigned)grid), dim3(BLOCK), 0, cfg.stream, T, F, rkeys, rsel,  \
+                               n_right, right_outer ? 1 : 0, bitmap, tile_counts, staging, matched);                                  \
+        else                                                                                                                          \
+            hipLaunchKernelGGL((join_filter_probe_kernel<KW_, NF_, 4>), dim3((unsigned)grid), dim3(BLOCK), 0, cfg.stream, T, F, rkeys, rsel,  \
+                               n_right, right_outer ? 1 : 0, bitmap, tile_counts, staging, matched);                                  \
+    } while (0)
     if (key_width == 4) {
         if (F.n == 0) BHIP_PROBE(4, 0);
         else if (F.n == 1) BHIP_PROBE(4, 1);

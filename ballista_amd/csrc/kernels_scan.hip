@@ -57,14 +57,7 @@ scan_project_kernel(const ScanParams P, const ProjectOut O, ScanStatus* status) 
                 } else {
                     const uint64_t v = L.vals[slot * TILE + idx];
                     if (NULLS) known = L.vvalid[slot * TILE + idx];
-                    if (in) {
-                        switch (dt) {
-                            case DT_INT32:
-                            case DT_DATE32: gptr_w<int32_t>(O.data[j])[row] = (int32_t)v; break;
-                            case DT_UINT8: gptr_w<uint8_t>(O.data[j])[row] = (uint8_t)v; break;
-                            default: gptr_w<uint64_t>(O.data[j])[row] = v; break;
-                        }
-                    }
+                    if (in) dt_store(dt, O.data[j], row, v);
                 }
                 if (O.validity[j] != nullptr) {
                     const uint64_t vw = __ballot(in && known);

@@ -135,6 +135,7 @@ partition_scatter_kernel(const void* keys, int64_t n, uint32_t n_parts, const ui
                 const int w = cols.width[c];
                 if (w == 8) reinterpret_cast<uint64_t*>(cols.dst[c])[pos] = reinterpret_cast<const uint64_t*>(cols.src[c])[j];
                 else if (w == 4) reinterpret_cast<uint32_t*>(cols.dst[c])[pos] = reinterpret_cast<const uint32_t*>(cols.src[c])[j];
+                else if (w == 2) reinterpret_cast<uint16_t*>(cols.dst[c])[pos] = reinterpret_cast<const uint16_t*>(cols.src[c])[j];
                 else reinterpret_cast<uint8_t*>(cols.dst[c])[pos] = reinterpret_cast<const uint8_t*>(cols.src[c])[j];
             }
         }

@@ -280,6 +280,7 @@ take_many_kernel(TakeMany d, const uint32_t* idx, int64_t n) {
         const uint32_t j = idx[i];
         if (width == 8) reinterpret_cast<uint64_t*>(dst)[i] = j == NULL_INDEX ? 0ull : reinterpret_cast<const uint64_t*>(src)[j];
         else if (width == 4) reinterpret_cast<uint32_t*>(dst)[i] = j == NULL_INDEX ? 0u : reinterpret_cast<const uint32_t*>(src)[j];
+        else if (width == 2) reinterpret_cast<uint16_t*>(dst)[i] = j == NULL_INDEX ? (uint16_t)0 : reinterpret_cast<const uint16_t*>(src)[j];
         else reinterpret_cast<uint8_t*>(dst)[i] = j == NULL_INDEX ? (uint8_t)0 : reinterpret_cast<const uint8_t*>(src)[j];
     }
 }
@@ -317,6 +318,8 @@ hipError_t launch_take_fixed(const LaunchCfg& cfg, const void* src, int width, c
     switch (width) {
         case 1: hipLaunchKernelGGL(take_fixed_kernel<uint8_t>, dim3(grid), dim3(BLOCK), 0, cfg.stream,
                                    (const uint8_t*)src, idx, n, (uint8_t*)dst); break;
+        case 2: hipLaunchKernelGGL(take_fixed_kernel<uint16_t>, dim3(grid), dim3(BLOCK), 0, cfg.stream,
+                                   (const uint16_t*)src, idx, n, (uint16_t*)dst); break;
         case 4: hipLaunchKernelGGL(take_fixed_kernel<uint32_t>, dim3(grid), dim3(BLOCK), 0, cfg.stream,
                                    (const uint32_t*)src, idx, n, (uint32_t*)dst); break;
         case 8: hipLaunchKernelGGL(take_fixed_kernel<uint64_t>, dim3(grid), dim3(BLOCK), 0, cfg.stream,
@@ -447,13 +450,7 @@ emit_group_key_kernel(const GroupRec* table, int64_t n_groups, EmitKeySpec spec,
                 if (utf8_lengths) utf8_lengths[i] = valid ? (uint32_t)key_get(g, pos, 1) : 0u;
             } else {
                 uint64_t v = valid ? key_get(g, pos, width) : 0;
-                switch (spec.dtype) {
-                    case DT_INT32:
-                    case DT_DATE32: reinterpret_cast<int32_t*>(data)[i] = (int32_t)(uint32_t)v; break;
-                    case DT_UINT8: reinterpret_cast<uint8_t*>(data)[i] = (uint8_t)v; break;
-                    case DT_BOOLEAN: break;   // written below as a ballot word
-                    default: reinterpret_cast<uint64_t*>(data)[i] = v; break;
-                }
+                if (spec.dtype != DT_BOOLEAN) dt_store(spec.dtype, data, i, v);   // (Boolean: written below as a ballot word; Float32 keys hold the double's bits)
                 if (spec.dtype == DT_BOOLEAN) {
                     const uint64_t word = __ballot(v & 1);
                     if ((threadIdx.x & 63) == 0) reinterpret_cast<uint64_t*>(data)[i >> 6] = word;
@@ -529,6 +526,27 @@ emit_group_utf8_kernel(const GroupRec* table, int64_t n_groups, EmitKeySpec spec
     }
 }
 
+// value of one output column of a group (shared by the per-column and the all-in-one emit kernels)
+__device__ inline uint64_t emit_value_of(const GroupRec& g, const EmitValueSpec& spec, bool& valid) {
+    const uint64_t cnt_a = spec.count_is_rows ? g.rows : g.nvalid[spec.acc_a];
+    uint64_t v = 0;
+    valid = true;
+    switch (spec.kind) {
+        case EMIT_VALUE: v = g.acc[spec.acc_a]; valid = cnt_a > 0; break;
+        case EMIT_COUNT: v = cnt_a; break;
+        case EMIT_ROWS: v = g.rows; break;
+        case EMIT_RAW: v = g.acc[spec.acc_a]; break;
+        case EMIT_AVG: valid = cnt_a > 0; v = valid ? d2u(u2d(g.acc[spec.acc_a]) / (double)cnt_a) : 0; break;
+        case EMIT_AVG_ACC: {
+            const uint64_t c = g.acc[spec.acc_b];
+            valid = c > 0 && g.nvalid[spec.acc_a] > 0;
+            v = valid ? d2u(u2d(g.acc[spec.acc_a]) / (double)c) : 0;
+        } break;
+        default: break;
+    }
+    return valid ? v : 0;
+}
+
 // all value columns of an aggregate's output in ONE launch: blockIdx.y selects the column
 __global__ void __launch_bounds__(BLOCK)
 emit_group_values_kernel(const GroupRec* table, int64_t n_groups, EmitValueBatch batch, const ScanStatus* dev_n) {
@@ -540,36 +558,72 @@ emit_group_values_kernel(const GroupRec* table, int64_t n_groups, EmitValueBatch
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n_round; i += (int64_t)gridDim.x * BLOCK) {
         bool valid = false;
         if (i < n_groups) {
-            const GroupRec& g = table[i];
-            const uint64_t cnt_a = spec.count_is_rows ? g.rows : g.nvalid[spec.acc_a];
-            uint64_t v = 0;
-            valid = true;
-            switch (spec.kind) {
-                case EMIT_VALUE: v = g.acc[spec.acc_a]; valid = cnt_a > 0; break;
-                case EMIT_COUNT: v = cnt_a; break;
-                case EMIT_ROWS: v = g.rows; break;
-                case EMIT_RAW: v = g.acc[spec.acc_a]; break;
-                case EMIT_AVG: valid = cnt_a > 0; v = valid ? d2u(u2d(g.acc[spec.acc_a]) / (double)cnt_a) : 0; break;
-                case EMIT_AVG_ACC: {
-                    const uint64_t c = g.acc[spec.acc_b];
-                    valid = c > 0 && g.nvalid[spec.acc_a] > 0;
-                    v = valid ? d2u(u2d(g.acc[spec.acc_a]) / (double)c) : 0;
-                } break;
-                default: break;
-            }
-            if (!valid) v = 0;
-            switch (spec.dtype) {
-                case DT_INT32:
-                case DT_DATE32: reinterpret_cast<int32_t*>(data)[i] = (int32_t)(uint32_t)v; break;
-                case DT_UINT8: reinterpret_cast<uint8_t*>(data)[i] = (uint8_t)v; break;
-                default: reinterpret_cast<uint64_t*>(data)[i] = v; break;
-            }
+            const uint64_t v = emit_value_of(table[i], spec, valid);
+            dt_store(spec.dtype, data, i, v);
         }
         if (validity != nullptr) {
             const uint64_t vw = __ballot(valid);
             if ((threadIdx.x & 63) == 0) validity[i >> 6] = vw;
         }
     }
+}
+
+__global__ void __launch_bounds__(EMIT_ALL_MAX_GROUPS)
+emit_all_kernel(EmitAllArgs A) {
+    __shared__ uint32_t s_wave[EMIT_ALL_MAX_GROUPS / 64];
+    const int n = (int)A.status->n_groups;
+    const int i = threadIdx.x, lane = i & 63, wave = i >> 6;
+    const bool in = i < n;
+    const int n_words = (n + 63) >> 6;
+    const GroupRec& g = A.table[in ? i : 0];          // (threads past the count read record 0 and write nothing)
+    for (int c = 0; c < A.n_keys; ++c) {
+        const EmitKeySpec spec = A.key[c];
+        int pos = spec.pos, width = spec.width;
+        bool valid = in;
+        if (spec.nullable) { valid = in && key_get(g, pos, 1) != 0; pos += 1; width -= 1; }
+        if (A.key_validity[c] != nullptr) {
+            const uint64_t w = __ballot(valid);
+            if (lane == 0 && wave < n_words) A.key_validity[c][wave] = w;
+        }
+        if (spec.dtype == DT_UTF8) {
+            const uint32_t len = valid ? (uint32_t)key_get(g, pos, 1) : 0u;
+            uint32_t x = len;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+            if (lane == 63) s_wave[wave] = x;
+            __syncthreads();
+            uint32_t before = 0, total = 0;
+            for (int w = 0; w < EMIT_ALL_MAX_GROUPS / 64; ++w) { if (w < wave) before += s_wave[w]; total += s_wave[w]; }
+            __syncthreads();
+            const uint32_t d0 = before + x - len;
+            if (in) {
+                A.key_offsets[c][i] = (int32_t)d0;
+                uint8_t* out = reinterpret_cast<uint8_t*>(A.key_data[c]) + d0;
+                for (uint32_t b = 0; b < len; ++b) out[b] = (uint8_t)key_get(g, pos + 1 + (int)b, 1);
+            }
+            if (i == 0) { A.key_offsets[c][n] = (int32_t)total; *A.key_total[c] = total; }
+        } else if (spec.dtype == DT_BOOLEAN) {
+            const uint64_t w = __ballot(valid && (key_get(g, pos, width) & 1));
+            if (lane == 0 && wave < n_words) reinterpret_cast<uint64_t*>(A.key_data[c])[wave] = w;
+        } else if (in) {
+            dt_store(spec.dtype, A.key_data[c], i, valid ? key_get(g, pos, width) : 0);
+        }
+    }
+    for (int c = 0; c < A.n_values; ++c) {
+        bool valid = false;
+        uint64_t v = 0;
+        if (in) v = emit_value_of(g, A.value[c], valid);
+        if (in) dt_store(A.value[c].dtype, A.value_data[c], i, v);
+        if (A.value_validity[c] != nullptr) {
+            const uint64_t w = __ballot(valid);
+            if (lane == 0 && wave < n_words) A.value_validity[c][wave] = w;
+        }
+    }
+}
+hipError_t launch_emit_all(const LaunchCfg& cfg, const EmitAllArgs& A) {
+    if (A.n_keys > EMIT_ALL_MAX_KEYS || A.n_values > EMIT_ALL_MAX_VALUES) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(emit_all_kernel, dim3(1), dim3(EMIT_ALL_MAX_GROUPS), 0, cfg.stream, A);
+    return hipGetLastError();
 }
 
 // ---- join / repartition key of ONE NULL-free integer column: the packed-key image the expression VM builds

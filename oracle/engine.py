@@ -26,7 +26,16 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 NP_TYPES = {"Int32": np.int32, "Int64": np.int64, "UInt8": np.uint8, "UInt64": np.uint64,
-            "Float64": np.float64, "Date32": np.int32, "Boolean": np.bool_}
+            "Float64": np.float64, "Date32": np.int32, "Boolean": np.bool_,
+            # the other primitive types of the serde (rust/core/proto/ballista.proto:755-790)
+            "Int8": np.int8, "Int16": np.int16, "UInt16": np.uint16, "UInt32": np.uint32, "Float32": np.float32,
+            "Date64": np.int64, "Timestamp(Second)": np.int64, "Timestamp(Millisecond)": np.int64,
+            "Timestamp(Microsecond)": np.int64, "Timestamp(Nanosecond)": np.int64}
+FLOAT_TYPES = ("Float64", "Float32")
+UNSIGNED_TYPES = ("UInt8", "UInt16", "UInt32", "UInt64")
+# units per day of the temporal types (arrow's temporal casts multiply / divide by the ratio)
+TEMPORAL_UNITS = {"Date32": 1, "Timestamp(Second)": 86400, "Date64": 86400000, "Timestamp(Millisecond)": 86400000,
+                  "Timestamp(Microsecond)": 86400000000, "Timestamp(Nanosecond)": 86400000000000}
 
 
 def lib():
@@ -192,7 +201,7 @@ def _binary(op, l: OCol, r: OCol) -> OCol:
         elif op == "Multiply":
             res = a * b
         elif op == "Divide":
-            if l.dtype == "Float64":
+            if l.dtype in FLOAT_TYPES:
                 res = a / b
             else:
                 live = r.is_valid() & l.is_valid()
@@ -219,20 +228,33 @@ def _cast(x: OCol, to: str) -> OCol:
         raise NotImplementedError("cast to Utf8")
     src = x.values
     valid = x.valid
-    if x.dtype == "Float64" and to != "Float64":
+    if x.dtype in TEMPORAL_UNITS and to in TEMPORAL_UNITS:
+        uf, ut = TEMPORAL_UNITS[x.dtype], TEMPORAL_UNITS[to]
+        w = src.astype(np.int64)
+        if ut >= uf:
+            w = w * (ut // uf)
+        else:
+            d = uf // ut
+            w = (np.sign(w) * (np.abs(w) // d)).astype(np.int64)          # Rust integer division truncates toward zero
+        return OCol(to, w.astype(NP_TYPES[to]), valid)
+    if x.dtype in FLOAT_TYPES and to in FLOAT_TYPES:
+        return OCol(to, src.astype(NP_TYPES[to]), valid)
+    if x.dtype in FLOAT_TYPES:
         info = np.iinfo(NP_TYPES[to]) if to != "Boolean" else None
         with np.errstate(all="ignore"):
             t = np.trunc(src)
             ok = np.isfinite(src)
             if info is not None:
-                ok &= (t >= float(info.min)) & (t <= float(info.max)) if to != "UInt64" and to != "Int64" else \
-                    (t >= -9.223372036854775808e18 if to == "Int64" else t >= 0) & \
-                    (t < (9.223372036854775808e18 if to == "Int64" else 1.8446744073709552e19))
+                wide64 = NP_TYPES[to] in (np.int64, np.uint64)
+                signed64 = NP_TYPES[to] == np.int64
+                ok &= (t >= float(info.min)) & (t <= float(info.max)) if not wide64 else \
+                    (t >= -9.223372036854775808e18 if signed64 else t >= 0) & \
+                    (t < (9.223372036854775808e18 if signed64 else 1.8446744073709552e19))
             res = np.where(ok, t, 0).astype(NP_TYPES[to])
         valid = _and_valid(valid, ok if not ok.all() else None)
         return OCol(to, res, valid)
-    if to == "Float64":
-        return OCol(to, src.astype(np.float64), valid)
+    if to in FLOAT_TYPES:
+        return OCol(to, src.astype(NP_TYPES[to]), valid)               # (numpy rounds an int64 to float32 once, as Rust's `as f32`)
     if to == "Boolean":
         return OCol(to, src != 0, valid)
     # int -> int: out-of-range becomes NULL (arrow-rs numeric cast)
@@ -269,8 +291,21 @@ def _case(e, batch) -> OCol:
     return OCol(dtype, out, out_valid)
 
 
+# Unicode White_Space: what Rust's str::trim / trim_start / trim_end strip (DataFusion 4.0 string_expressions.rs)
+_WS = "\t\n\x0b\x0c\r \x85\xa0\u1680\u2000\u2001\u2002\u2003\u2004\u2005\u2006\u2007\u2008\u2009\u200a\u2028\u2029\u202f\u205f\u3000"
+
+
 def _scalar_fn(fun, args) -> OCol:
     x = args[0]
+    if fun in ("lower", "upper", "trim", "ltrim", "rtrim", "octet_length"):
+        if x.dtype != "Utf8":
+            raise TypeError(f"{fun} requires Utf8")
+        if fun == "octet_length":
+            return OCol("Int32", [len(s.encode()) for s in x.values], x.valid)
+        f = {"lower": str.lower, "upper": str.upper, "trim": lambda s: s.strip(_WS), "ltrim": lambda s: s.lstrip(_WS),
+             "rtrim": lambda s: s.rstrip(_WS)}[fun]
+        ok = x.is_valid()
+        return OCol("Utf8", [f(s) if k else "" for s, k in zip(x.values, ok)], x.valid)
     if x.dtype != "Float64":
         raise TypeError(f"{fun} requires Float64")
     v = x.values
@@ -341,7 +376,7 @@ def _group_sum(col: OCol, gid, ngroups, batch_rows):
     cnt = np.zeros(max(ngroups, 1), np.uint64)
     has = np.zeros(max(ngroups, 1), np.uint8)
     gid = np.ascontiguousarray(gid, np.int32)
-    if col.dtype == "Float64":
+    if col.dtype in FLOAT_TYPES:
         v = np.ascontiguousarray(col.values, np.float64)
         out = np.zeros(max(ngroups, 1), np.float64)
         L.oracle_batched_group_sum_f64(_ptr(v, ctypes.c_double), _ptr(valid, ctypes.c_uint8),
@@ -349,7 +384,7 @@ def _group_sum(col: OCol, gid, ngroups, batch_rows):
                                        ctypes.c_int32(ngroups), _ptr(out, ctypes.c_double),
                                        _ptr(cnt, ctypes.c_uint64), _ptr(has, ctypes.c_uint8))
         return out[:ngroups], cnt[:ngroups], has[:ngroups].astype(bool)
-    if col.dtype in ("Int32", "Int64", "UInt8", "UInt64", "Date32", "Boolean"):
+    if col.dtype in NP_TYPES:
         v = np.ascontiguousarray(col.values.astype(np.int64))
         out = np.zeros(max(ngroups, 1), np.int64)
         L.oracle_batched_group_sum_i64(_ptr(v, ctypes.c_int64), _ptr(valid, ctypes.c_uint8),
@@ -361,9 +396,12 @@ def _group_sum(col: OCol, gid, ngroups, batch_rows):
 
 
 def _sum_type(t):
-    if t == "Float64":
-        return "Float64"
-    if t in ("UInt8", "UInt64"):
+    """sum_return_type of DataFusion 4.0: signed -> Int64, unsigned -> UInt64, Float32 -> Float32, Float64 -> Float64.
+    (SUM(Float32) is added here in double and rounded once; the reference keeps a running float — not reproducible bit for bit,
+    compared with a float32-sized tolerance in the tests)"""
+    if t in FLOAT_TYPES:
+        return t
+    if t in UNSIGNED_TYPES:
         return "UInt64"
     return "Int64"
 
@@ -374,7 +412,7 @@ def _minmax(col: OCol, gid, ngroups, is_min):
     for v, g, o in zip(col.values, gid, ok):
         if not o:
             continue
-        if col.dtype == "Float64" and v != v:
+        if col.dtype in FLOAT_TYPES and v != v:
             continue
         cur = out[g]
         if cur is None or (v < cur if is_min else v > cur):
@@ -418,7 +456,7 @@ def hash_aggregate(batch, mode, group_exprs_names, aggr_exprs, batch_rows=32768)
                 s, c, has = _group_sum(x, gid, ng, batch_rows)
                 if a.fun == "AVG":
                     if x.dtype != "Float64":
-                        s = s.astype(np.float64)
+                        s = s.astype(np.float64)                 # (Float32: the sums are doubles already)
                     out[f"{a.name}[count]"] = OCol("UInt64", c)
                     out[f"{a.name}[sum]"] = OCol("Float64", s, has)
                 else:
@@ -569,10 +607,10 @@ def _value_bits(c: OCol, i):
     if not c.is_valid()[i]:
         return 0x6E756C6C6E756C6C  # "nullnull"
     v = c.values[i]
-    if c.dtype == "Float64":
+    if c.dtype in FLOAT_TYPES:
         if v == 0.0:
             v = 0.0
-        return int(np.float64(v).view(np.uint64))
+        return int(np.float64(v).view(np.uint64))                 # a Float32 value hashes as the double it equals
     if c.dtype == "Utf8":
         h = 0xCBF29CE484222325
         for b in v.encode():

@@ -79,7 +79,7 @@ def assert_rows_equal(got, want, ordered=False, float_rtol=0.0, key_cols=None):
     g, w = rows_of(got), rows_of(want)
     assert len(g) == len(w), f"row count {len(g)} != {len(w)}"
     names = list(want.keys())
-    fcols = [i for i, n in enumerate(names) if want[n].dtype == "Float64"]
+    fcols = [i for i, n in enumerate(names) if want[n].dtype in ("Float64", "Float32")]
     if not ordered:
         if key_cols is None:
             kidx = [i for i in range(len(names)) if i not in fcols] or list(range(len(names)))

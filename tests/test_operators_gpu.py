@@ -527,7 +527,7 @@ def test_arrow_stream_leaf(ctx):
     with pytest.raises(ba.BallistaError):
         ba.ArrowStreamExec(pa.RecordBatchReader.from_batches(schema, [batches[0], liar]), ctx).collect()
     # an unsupported column type is refused at plan time
-    bad = pa.RecordBatchReader.from_batches(pa.schema([("f", pa.float32())]), [])
+    bad = pa.RecordBatchReader.from_batches(pa.schema([("f", pa.float16())]), [])
     with pytest.raises(ba.NotImplementedOnGpu):
         ba.ArrowStreamExec(bad, ctx)
 
