@@ -522,7 +522,7 @@ StreamPtr HashJoinExec::execute_needed(int partition, const Exec& ex, const std:
             if (n == 0) return;
             const int64_t n_tiles = (n + SEL_TILE - 1) / SEL_TILE;
             Temp tmp(ex);
-            uint64_t* bitmap = tmp.get<uint64_t>((size_t)(n + 63) / 64 + 1);
+            uint64_t* bitmap = tmp.get<uint64_t>((size_t)n_tiles * (SEL_TILE / 64) + 1);       // whole tiles: the kernel writes every word of a tile
             uint32_t* tile_counts = tmp.get<uint32_t>((size_t)n_tiles + 1);
             uint64_t* tile_off = tmp.get<uint64_t>((size_t)n_tiles + 1);
             uint64_t* total = tmp.get<uint64_t>(1);

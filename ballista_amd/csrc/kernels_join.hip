@@ -152,7 +152,8 @@ rank_perm_kernel(const void* __restrict__ keys_v, const uint64_t* __restrict__ s
 }
 
 // ---- probe ---------------------------------------------------------------------------------------------------------------
-// FP_ROWS rows per lane and pass: their loads are in flight together (template parameter: 4 or 8, launch_join_filter_probe)
+// FP_ROWS rows per lane and pass: their loads are in flight together (8 rows and a three-deep pipeline were measured and dropped:
+// profiles/r02_probe_variants_q3_sf100.txt)
 
 template <int KW>
 __device__ inline uint32_t table_lookup(const NarrowJoinTable& T, typename KeyT<KW>::type key) {
@@ -184,7 +185,10 @@ struct WaveScratchT {
     uint32_t b[FP_CHUNK];        // rank map: popcount of the lower bits; then: the result (build row)
 };
 
-// NF: filter columns compiled in (0, 1 or JOIN_FILTER_MAX): registers for the ones a plan does not have would only cost occupancy
+// NF: filter columns compiled in (0, 1 or JOIN_FILTER_MAX): registers for the ones a plan does not have would only cost occupancy.
+// Every streamed load and the key-set word load are UNCONDITIONAL (row index clamped to the last row, word index 0 for rows that
+// do not need it): a predicated load costs a saved-exec branch of its own — the first version of this kernel spent as many scalar
+// as vector instructions on them (rocprofv3 SQ_INSTS_SALU 293 M vs SQ_INSTS_VALU 275 M per launch, profiles/r02_probe_variants_q3_sf100.txt).
 template <int KW, int NF, int FP_ROWS>
 __global__ void __launch_bounds__(BLOCK)
 join_filter_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void* __restrict__ rkeys_v, const uint64_t* __restrict__ rsel,
@@ -198,62 +202,69 @@ join_filter_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const voi
     __shared__ WaveScratch scratch[BLOCK / 64];
     WaveScratch& S = scratch[threadIdx.x >> 6];
     const K* __restrict__ rkeys = static_cast<const K*>(rkeys_v);
-    const int lane = threadIdx.x & 63;
+    const uint32_t lane = threadIdx.x & 63;
     const uint64_t lane_lt = (1ull << lane) - 1ull;
     const uint32_t n_tiles = (uint32_t)(((uint64_t)n_right + SEL_TILE - 1) / SEL_TILE);
-    const uint64_t n_words = ((uint64_t)n_right + 63) / 64;
+    const uint32_t last_row = n_right - 1;
     const uint32_t wave_id = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (BLOCK / 64);
     const bool ranked = T.rbits != nullptr;
+    const bool key_set = ranked || T.present != nullptr;
 
-    // the streamed inputs of one pass; the NEXT pass's are loaded before this pass walks its dependent reads
+    // the streamed inputs of one pass; the NEXT pass's are loaded before this pass walks its dependent reads.
+    // Rows are 32-bit (a batch holds < 2^32 - 16 rows and a pass starts at a multiple of 256: base + 255 does not wrap).
     struct Regs { K key[FP_ROWS]; int32_t f[NFR][FP_ROWS]; };
-    auto load = [&](uint64_t base, Regs& r) {
+    auto load = [&](uint32_t base, Regs& r) {
 #pragma unroll
         for (int k = 0; k < FP_ROWS; ++k) {
-            const uint64_t row = base + 64ull * k + lane;
-            const bool in = row < n_right;
-            r.key[k] = in ? rkeys[row] : K(0);
+            const uint32_t row = base + 64u * k + lane;
+            const uint32_t rc = row < last_row ? row : last_row;
+            r.key[k] = rkeys[rc];
 #pragma unroll
-            for (int j = 0; j < NF; ++j) r.f[j][k] = (j < F.n && in) ? F.col[j][row] : 0;
+            for (int j = 0; j < NF; ++j) r.f[j][k] = F.col[j < F.n ? j : 0][rc];
         }
     };
     Regs cur, nxt;
-    if (wave_id < n_tiles) load((uint64_t)wave_id * SEL_TILE, cur);
+    if (wave_id < n_tiles) load(wave_id * SEL_TILE, cur);
     for (uint32_t t = wave_id; t < n_tiles; t += n_waves) {
-        const uint64_t tile_base = (uint64_t)t * SEL_TILE;
+        const uint32_t tile_base = t * SEL_TILE;
         uint32_t tile_cnt = 0;
 #pragma unroll 1
         for (int c = 0; c < SEL_TILE / FP_CHUNK; ++c) {
-            const uint64_t base = tile_base + (uint64_t)c * FP_CHUNK;
+            const uint32_t base = tile_base + (uint32_t)c * FP_CHUNK;
             {
                 const bool last = c == SEL_TILE / FP_CHUNK - 1;
-                const uint64_t nbase = last ? (uint64_t)(t + n_waves) * SEL_TILE : base + FP_CHUNK;
-                if (!last || t + n_waves < n_tiles) load(nbase, nxt);
+                // (after the wave's last tile the prefetch re-reads the final rows: harmless, and no branch around the loads)
+                const uint32_t nt = t + n_waves < n_tiles ? t + n_waves : n_tiles - 1;
+                load(last ? nt * SEL_TILE : base + FP_CHUNK, nxt);
             }
-            bool in[FP_ROWS], pass[FP_ROWS], live[FP_ROWS];
-            uint32_t m[FP_ROWS];
+            bool pass[FP_ROWS], live[FP_ROWS];
+            uint32_t m[FP_ROWS], d[FP_ROWS];
+            uint64_t word[FP_ROWS];
 #pragma unroll
             for (int k = 0; k < FP_ROWS; ++k) {
-                const uint64_t row = base + 64ull * k + lane;
-                in[k] = row < n_right;
-                bool p = in[k];
+                const uint32_t row = base + 64u * k + lane;
+                bool p = row < n_right;
 #pragma unroll
                 for (int j = 0; j < NF; ++j)
                     if (j < F.n) p = p && cur.f[j][k] >= F.lo[j] && cur.f[j][k] <= F.hi[j];
                 pass[k] = p;
                 m[k] = 0xFFFFFFFFu;
-                live[k] = p && jbit_at(rsel, row);                      // NULL keys never match
+                live[k] = p;
+                if (rsel != nullptr) {                                     // NULL keys never match (wave-uniform test of the pointer)
+                    const uint32_t rc = row < last_row ? row : last_row;
+                    live[k] = live[k] && ((rsel[rc >> 6] >> (rc & 63)) & 1ull);
+                }
             }
             // ---- the exact key set: one bit per value of the window (rank map: rbits, CAS table: present) ----------------
-            uint64_t d[FP_ROWS], word[FP_ROWS];
-            if (ranked || T.present) {
+            if (key_set) {
 #pragma unroll
                 for (int k = 0; k < FP_ROWS; ++k) {
-                    d[k] = key_offset<KW>(cur.key[k], T.kmin64);
-                    live[k] = live[k] && d[k] <= T.krange;
-                    if (ranked) word[k] = live[k] ? T.rbits[d[k] >> 6] : 0ull;
-                    else word[k] = live[k] ? (uint64_t)T.present[d[k] >> 5] << (d[k] & 32) : 0ull;      // the 32-bit word at its place in the 64-bit one
+                    const uint64_t off = key_offset<KW>(cur.key[k], T.kmin64);
+                    live[k] = live[k] && off <= T.krange;
+                    d[k] = live[k] ? (uint32_t)off : 0u;                                  // the window holds <= 2^30 values
+                    if (ranked) word[k] = T.rbits[d[k] >> 6];
+                    else word[k] = (uint64_t)T.present[d[k] >> 5] << (d[k] & 32);         // the 32-bit word at its place in the 64-bit one
                 }
 #pragma unroll
                 for (int k = 0; k < FP_ROWS; ++k) live[k] = live[k] && ((word[k] >> (d[k] & 63)) & 1ull);
@@ -300,7 +311,8 @@ join_filter_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const voi
             for (int k = 0; k < FP_ROWS; ++k) {
                 const bool emit = pass[k] && (right_outer || m[k] != 0xFFFFFFFFu);
                 const uint64_t wd = __ballot(emit);
-                if (lane == 0 && (base >> 6) + k < n_words) bitmap[(base >> 6) + k] = wd;
+                // (bitmap words past the last row's word exist: the bitmap is allocated for whole tiles)
+                if (lane == 0) bitmap[(base >> 6) + k] = wd;
                 if (emit && staging) staging[tile_base + tile_cnt + (uint32_t)__popcll(wd & lane_lt)] = m[k];
                 tile_cnt += (uint32_t)__popcll(wd);
             }
@@ -377,21 +389,14 @@ hipError_t launch_join_filter_probe(const LaunchCfg& cfg, const NarrowJoinTable&
                                     uint32_t* staging, uint32_t* matched) {
     if (n_right == 0) return hipSuccess;
     const int64_t n_tiles = ((int64_t)n_right + SEL_TILE - 1) / SEL_TILE;
-    static const int per_cu = [] { const char* v = getenv("BHIP_PROBE_BLOCKS_PER_CU"); return v && atoi(v) > 0 ? atoi(v) : 8; }();
+    static const int per_cu = [] { const char* v = getenv("BHIP_PROBE_BLOCKS_PER_CU"); return v && atoi(v) > 0 ? atoi(v) : 12; }();   // profiles/r02_probe_variants_q3_sf100.txt
     int64_t grid = (int64_t)cfg.device_cus * per_cu;
     const int64_t need = (n_tiles + BLOCK / 64 - 1) / (BLOCK / 64);
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;
-    static const int rows = [] { const char* v = getenv("BHIP_PROBE_ROWS"); return v && atoi(v) == 8 ? 8 : 4; }();
 #define BHIP_PROBE(KW_, NF_)                                                                                                          \
-    do {                                                                                                                              \
-        if (rows == 8)                                                                                                                \
-            hipLaunchKernelGGL((join_filter_probe_kernel<KW_, NF_, 8>), dim3((unsigned)grid), dim3(BLOCK), 0, cfg.stream, T, F, rkeys, rsel,  \
-                               n_right, right_outer ? 1 : 0, bitmap, tile_counts, staging, matched);                                  \
-        else                                                                                                                          \
-            hipLaunchKernelGGL((join_filter_probe_kernel<KW_, NF_, 4>), dim3((unsigned)grid), dim3(BLOCK), 0, cfg.stream, T, F, rkeys, rsel,  \
-                               n_right, right_outer ? 1 : 0, bitmap, tile_counts, staging, matched);                                  \
-    } while (0)
+    hipLaunchKernelGGL((join_filter_probe_kernel<KW_, NF_, 4>), dim3((unsigned)grid), dim3(BLOCK), 0, cfg.stream, T, F, rkeys, rsel, n_right, \
+                       right_outer ? 1 : 0, bitmap, tile_counts, staging, matched)
     if (key_width == 4) {
         if (F.n == 0) BHIP_PROBE(4, 0);
         else if (F.n == 1) BHIP_PROBE(4, 1);
