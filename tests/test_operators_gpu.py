@@ -391,6 +391,20 @@ def test_sort_few_rows_edge_values(ctx):
             run_both(ba.SortExec([E.PhysicalSortExpr(col("f"), descending=desc, nulls_first=nf), E.PhysicalSortExpr(col("s"))], m), ordered=True)
 
 
+@pytest.mark.parametrize("n", [4097, 150_000])
+def test_sort_mid_size(ctx, n):
+    """several workgroups per radix pass (37 at 150 K rows): Float64 keys DESC with NULLs, ties broken by a second key, then by
+    input position — the same stable order as the oracle's sort"""
+    from collections import OrderedDict
+    rng = np.random.default_rng(n)
+    b = OrderedDict([("f", OCol("Float64", np.round(rng.normal(0, 1000, n), 1) + 0.0, rng.random(n) > 0.05)),     # (+ 0.0: no -0.0, whose tie with 0.0 is unspecified)
+                     ("d", OCol("Date32", rng.integers(8000, 10400, n))), ("i", OCol("Int64", rng.integers(-2**40, 2**40, n))),
+                     ("s", OCol("Utf8", [f"k{v % 97}" for v in range(n)]))])
+    m = helpers.memory_exec(ctx, [[b]])
+    run_both(ba.SortExec([E.PhysicalSortExpr(col("f"), descending=True, nulls_first=False), E.PhysicalSortExpr(col("d"))], m), ordered=True)
+    run_both(ba.SortExec([E.PhysicalSortExpr(col("s")), E.PhysicalSortExpr(col("i"), descending=True)], m), ordered=True)
+
+
 @pytest.mark.parametrize("n", [700, 5000])
 def test_sort_by_long_strings(ctx, n):
     """Utf8 sort keys of any length (here up to 90 bytes, sharing long prefixes, with NULLs and empty strings): one
