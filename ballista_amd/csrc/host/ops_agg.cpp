@@ -258,7 +258,6 @@ GroupRec* hash_aggregate(const Exec& ex, Temp& tmp, const ScanParams& P0, const 
             BufferPtr kb = std::make_shared<Buffer>(ex.ctx, D.spill_key, (size_t)n_spill * 8), pb2 = std::make_shared<Buffer>(ex.ctx, D.spill_seg, (size_t)n_spill * 4);
             radix_sort_pairs(ex, kb, pb2, (int64_t)n_spill);
             TIMED_LAUNCH_N(ex, "det_spill_combine", n_spill, launch_det_spill_combine(cfg, D, kb->as<uint64_t>(), pb2->as<uint32_t>(), n_spill));
-            stream_wait(ex);                 // kb / pb2 may be buffers of the sort: released here
         }
     }
     // used slots -> dense records (slot order: deterministic for a given input)
@@ -684,12 +683,16 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
     auto out = emit_table(table, n_groups, nullptr);
     if (!utf8_cols.empty()) {
         std::vector<uint64_t> host(group_.size() + 1);
-        HIP_CHECK(hipMemcpyAsync(host.data(), totals, group_.size() * 8, hipMemcpyDeviceToHost, ex.stream));
-        stream_wait(ex);
+        if (group_.size() <= (size_t)TAIL_TOTALS) {
+            const TailInfo ti = read_device(ex, info);                      // the totals sit in the info block: one pinned-slot read
+            for (size_t i = 0; i < group_.size(); ++i) host[i] = ti.totals[i];
+        } else {
+            HIP_CHECK(hipMemcpyAsync(host.data(), totals, group_.size() * 8, hipMemcpyDeviceToHost, ex.stream));
+            stream_wait(ex);
+        }
         finish_table(out, n_groups, host.data());
-    } else {
-        stream_wait(ex);
     }
+    // (no wait otherwise: everything downstream is queued on the same stream, and scratch is released in stream order)
     return {out};
 }
 

@@ -133,7 +133,6 @@ std::vector<BatchPtr> HashAggregateExec::run_wide(int partition, const Exec& ex)
         K.n = (int32_t)keys.size();
         for (size_t i = 0; i < keys.size(); ++i) K.col[i] = keys[i].ref();
         TIMED_LAUNCH(ex, "wide_key_assign", launch_wide_key_assign(cfg, K, hashes, table, cap - 1, (uint32_t)n, rep->as<uint32_t>()));
-        stream_wait(ex);                  // the scratch is released here
     }
 
     // ---- the ordinary aggregate, keyed by the representative row ---------------------------------------------
@@ -176,7 +175,6 @@ std::vector<BatchPtr> HashAggregateExec::run_wide(int partition, const Exec& ex)
         for (size_t i = 1; i < r->cols.size(); ++i) out->cols.push_back(r->cols[i]);
         outv.push_back(out);
     }
-    stream_wait(ex);
     return outv;
 }
 
@@ -284,11 +282,9 @@ std::vector<BatchPtr> HashAggregateExec::run_strings(int partition, const Exec& 
                                                                              rk.perm ? rk.perm->as<uint32_t>() : nullptr, r->n_rows, idx->as<uint32_t>()));
             std::vector<const Column*> one{&rk.strings};
             out->cols[col] = take_columns(ex, one, idx->as<uint32_t>(), r->n_rows, /*may_null=*/true, false)[0];
-            stream_wait(ex);                                    // idx is released here
         }
         outv.push_back(out);
     }
-    stream_wait(ex);
     return outv;
 }
 

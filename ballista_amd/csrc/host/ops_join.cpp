@@ -189,11 +189,11 @@ std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) co
         Temp tmp(ex);
         uint64_t* stats = tmp.get<uint64_t>(3);
         const uint64_t seed[3] = {~0ull, 0ull, 0ull};
-        uint64_t host_stats[3];
+        struct Stats3 { uint64_t v[3]; };
         HIP_CHECK(hipMemcpyAsync(stats, seed, sizeof(seed), hipMemcpyHostToDevice, ex.stream));
         TIMED_LAUNCH_N(ex, "join_key_stats", n, launch_join_key_stats(ex.cfg(), kc.data->ptr(), nkw, ksel, (uint32_t)n, stats));
-        HIP_CHECK(hipMemcpyAsync(host_stats, stats, sizeof(host_stats), hipMemcpyDeviceToHost, ex.stream));
-        stream_wait(ex);
+        const Stats3 back = read_device(ex, reinterpret_cast<const Stats3*>(stats));        // one pinned-slot read, no staged copy
+        const uint64_t* host_stats = back.v;
         const uint64_t bias = nkw == 4 ? 0x80000000ull : (1ull << 63);
         const bool any_key = host_stats[0] <= host_stats[1];
         const uint64_t range = any_key ? host_stats[1] - host_stats[0] : 0;
@@ -512,7 +512,7 @@ StreamPtr HashJoinExec::execute_needed(int partition, const Exec& ex, const std:
                 ridx = orig;
             }
             emit(outsrc, rmap, lidx, ridx, (int64_t)n_out);
-            stream_wait(ex);   // index scratch is released at the end of the iteration
+            // (no wait: the index scratch is released in stream order — host/core.cpp Context::alloc)
         };
 
         // ---- narrow build side: one pass over the probe rows: ranges -> key-set bit -> rank map / table (kernels_join.hip) -----
@@ -546,7 +546,6 @@ StreamPtr HashJoinExec::execute_needed(int partition, const Exec& ex, const std:
                 ridx = orig;
             }
             emit(outsrc, rmap, lidx, ridx, (int64_t)n_out);
-            stream_wait(ex);
         };
         ProbeFilter no_filter;
         memset(&no_filter, 0, sizeof(no_filter));
@@ -586,7 +585,6 @@ StreamPtr HashJoinExec::execute_needed(int partition, const Exec& ex, const std:
                 ridx = orig;
             }
             emit(outsrc, rmap, lidx, ridx, (int64_t)n_out);
-            stream_wait(ex);
             return true;
         };
         const bool radix_mode = bs->narrow && bs->rj_log2p >= 0 && !right_outer && !left_outer;
@@ -665,7 +663,6 @@ StreamPtr HashJoinExec::execute_needed(int partition, const Exec& ex, const std:
                 uint32_t* lidx = tmp.get<uint32_t>((size_t)n_un);
                 TIMED_LAUNCH(ex, "compact_flags", launch_compact_flags(cfg, flags, offsets, (uint32_t)n_left, lidx));
                 emit(nullptr, nullptr, lidx, nullptr, (int64_t)n_un);
-                stream_wait(ex);
             }
         }
         return out;

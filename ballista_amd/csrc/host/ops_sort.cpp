@@ -127,8 +127,7 @@ StreamPtr SortExec::execute(int partition, const Exec& ex) const {
         }
         BufferPtr perm = sort_permutation(ex, *in, self->exprs_);
         BatchPtr out = take_batch(ex, *in, perm->as<uint32_t>(), n, nullptr, /*permutation=*/true);
-        stream_wait(ex);
-        return {out};
+        return {out};                                           // (no wait: scratch is released in stream order)
     }));
 }
 
@@ -251,8 +250,7 @@ std::vector<BatchPtr> hash_partition_batch(const Exec& ex, const BatchPtr& in, c
         const int64_t cnt = (int64_t)first[p + 1] - (int64_t)first[p];
         out[p] = take_batch(ex, *in, perm->as<uint32_t>() + first[p], cnt);
     }
-    stream_wait(ex);   // `perm` is released when this returns
-    return out;
+    return out;        // (`perm` is released in stream order; callers that publish the parts to other tasks wait themselves)
 }
 
 // ---- RepartitionExec ----------------------------------------------------------------------------------------
