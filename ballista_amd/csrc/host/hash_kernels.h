@@ -22,6 +22,7 @@ struct HashAggTable {
     double* fvals;            // [n_fsum][total rows]
     uint64_t total_rows;
     uint8_t fsum_of_acc[VM_MAX_ACC];   // accumulator -> index into fvals, 0xFF = an atomic accumulator
+    int32_t slots_given;      // 1: rowslot is an INPUT (clustered input: slot = run of equal keys, launch_run_*); owner / mask: run table
 };
 struct MergeAccKinds { uint8_t kind[VM_MAX_ACC]; };
 
@@ -60,6 +61,14 @@ hipError_t launch_det_spill_combine(const LaunchCfg& cfg, const DetSum& D, const
 
 hipError_t launch_scan_agg_hash(const LaunchCfg& cfg, const ScanParams& P, const HashAggTable& T, uint32_t row_base,
                                 ScanStatus* status);
+// clustered input (kernels_hash.hip "input clustered by group key"): flags[i] = row i starts a run of equal keys;
+// runs_before = exclusive scan of flags -> rowslot[i] = run of row i, head[run] = its first row;
+// launch_run_groups: rowslot[i] = the run that owns row i's key, owner[run] = head row + 1 for owning runs, 0 otherwise
+// (table: 2 x n entries zeroed, min_head: as many entries set to 0xFFFFFFFF; *n_runs_dev = the scan's total)
+hipError_t launch_run_heads(const LaunchCfg& cfg, const uint64_t* keys128, uint32_t n, uint32_t* flags);
+hipError_t launch_run_slots(const LaunchCfg& cfg, const uint32_t* flags, const uint32_t* runs_before, uint32_t n, uint32_t* rowslot, uint32_t* head);
+hipError_t launch_run_groups(const LaunchCfg& cfg, const uint64_t* keys128, uint32_t n, const uint32_t* head, const uint64_t* n_runs_dev, uint32_t* table,
+                             uint64_t mask, uint32_t* min_head, uint32_t* slot_of_run, uint32_t* winner, uint32_t* owner, uint32_t* rowslot);
 hipError_t launch_hash_agg_init(const LaunchCfg& cfg, const HashAggTable& T, const MergeAccKinds& kinds);
 hipError_t launch_hash_agg_flags(const LaunchCfg& cfg, const HashAggTable& T, uint32_t* flags);
 hipError_t launch_hash_agg_compact(const LaunchCfg& cfg, const HashAggTable& T, const uint64_t* dense_index, bool nulls,

@@ -182,32 +182,21 @@ struct TimedLaunches {
 // high-cardinality path (device-wide hash table); filled in by ops_agg_hash.cpp
 GroupRec* hash_aggregate(const Exec& ex, Temp& tmp, const ScanParams& P0, const ProgramBuilder& pb,
                          const std::vector<BatchPtr>& inputs, bool nullable, int64_t* n_groups, ScanStatus* status,
-                         TimedLaunches& /*timer: only the register-path scan kernel is the timed (dominant) kernel*/) {
+                         TimedLaunches& /*timer: only the register-path scan kernel is the timed (dominant) kernel*/,
+                         std::atomic<int>* clustered_hint) {
     const LaunchCfg cfg = ex.cfg();
     int64_t total_rows = 0;
     for (auto& b : inputs) total_rows += b->n_rows;
     // slots are 32-bit indices into a table of >= 2 x rows entries
     if (total_rows > 0x7FFFFFF0ll) fail(BHIP_ENOTIMPL, "hash aggregate over more than 2^31 input rows per partition");
-    // capacity: power of two >= 2 x rows (every row could be its own group)
-    uint64_t cap = 1024;
-    while (cap < 2ull * (uint64_t)total_rows) cap <<= 1;
     const int n_acc = P0.n_acc > 0 ? P0.n_acc : 1;
     HashAggTable T;
     memset(&T, 0, sizeof(T));
-    T.mask = cap - 1;
     T.n_acc = P0.n_acc;
-    T.owner = tmp.get<uint32_t>(cap);
     uint64_t* keys = tmp.get<uint64_t>(2 * (size_t)total_rows);
     T.keys128 = keys;
-    T.acc = tmp.get<uint64_t>(cap * n_acc);
-    T.rows = tmp.get<uint64_t>(cap);
-    if (nullable) T.nvalid = tmp.get<uint64_t>(cap * n_acc);
-    HIP_CHECK(hipMemsetAsync(T.owner, 0, cap * 4, ex.stream));
-    HIP_CHECK(hipMemsetAsync(T.rows, 0, cap * 8, ex.stream));
-    if (nullable) HIP_CHECK(hipMemsetAsync(T.nvalid, 0, cap * n_acc * 8, ex.stream));
     MergeAccKinds kinds;
     for (int i = 0; i < VM_MAX_ACC; ++i) kinds.kind[i] = i < P0.n_acc ? P0.acc[i].kind : (uint8_t)ACC_COUNT_ROWS;
-    if (P0.n_acc > 0) TIMED_LAUNCH(ex, "hash_agg_init", launch_hash_agg_init(cfg, T, kinds));
     HIP_CHECK(hipMemsetAsync(status, 0, sizeof(ScanStatus), ex.stream));
     // SUM(Float64) accumulators are summed in row order after the scan (kernels_dagg.hip); BHIP_AGG_ATOMIC=1: atomic adds
     // (order of addition left to the scheduler: the same sums to ~1e-16 relative, not bit for bit)
@@ -218,17 +207,83 @@ GroupRec* hash_aggregate(const Exec& ex, Temp& tmp, const ScanParams& P0, const 
     if (!atomic_sums && total_rows > 0) {
         for (int a = 0; a < P0.n_acc; ++a)
             if (P0.acc[a].kind == ACC_SUM_F64) { D.acc_of_fsum[T.n_fsum] = (uint8_t)a; T.fsum_of_acc[a] = (uint8_t)T.n_fsum++; }
-        if (T.n_fsum) {
-            T.total_rows = (uint64_t)total_rows;
-            T.rowslot = tmp.get<uint32_t>((size_t)total_rows);
-            T.fvals = tmp.get<double>((size_t)total_rows * T.n_fsum);
+    }
+    T.total_rows = (uint64_t)total_rows;
+    T.rowslot = tmp.get<uint32_t>((size_t)total_rows + 1);
+    if (T.n_fsum) T.fvals = tmp.get<double>((size_t)total_rows * T.n_fsum);
+
+    // ---- the packed key of every row --------------------------------------------------------------------------------------
+    {
+        uint32_t row_base = 0;
+        for (auto& b : inputs) {
+            ScanParams P = P0;
+            ProgramBuilder::bind(P, pb.columns(), *b, nullable);
+            TIMED_LAUNCH_N(ex, "scan_keys", b->n_rows, launch_scan_keys(cfg, P, keys + 2ull * row_base, nullptr, nullptr, status));
+            row_base += (uint32_t)b->n_rows;
         }
     }
+
+    // ---- rows of a group mostly consecutive?  the table is consulted per RUN of equal keys, slots = runs (kernels_hash.hip) ------
+    // Decided on the leading rows: at most half as many runs as rows.  Not with a fused predicate (a filtered-out row would
+    // have to leave its run).  The operator remembers what it found.
+    static const bool no_runs = [] { const char* v = getenv("BHIP_NO_RUN_AGG"); return v && atoi(v) != 0; }();
+    bool runs = false;
+    if (!no_runs && P0.pred_slot < 0 && total_rows >= 4096 && clustered_hint->load() >= 0) {
+        uint32_t* flags = tmp.get<uint32_t>((size_t)total_rows + 1);
+        uint32_t* before = tmp.get<uint32_t>((size_t)total_rows + 1);
+        uint64_t* n_runs_dev = tmp.get<uint64_t>(1);
+        void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes(total_rows));
+        const int64_t sample = std::min<int64_t>(total_rows, 1 << 20);
+        TIMED_LAUNCH_N(ex, "run_heads", sample, launch_run_heads(cfg, keys, (uint32_t)sample, flags));
+        HIP_CHECK(exclusive_scan_u32_u32(ex.stream, flags, sample, before, false, n_runs_dev, scan_tmp));
+        runs = clustered_hint->load() == 1 || 2 * read_device(ex, n_runs_dev) <= (uint64_t)sample;
+        clustered_hint->store(runs ? 1 : -1);
+        if (runs) {
+            if (sample < total_rows) {
+                TIMED_LAUNCH_N(ex, "run_heads", total_rows, launch_run_heads(cfg, keys, (uint32_t)total_rows, flags));
+                HIP_CHECK(exclusive_scan_u32_u32(ex.stream, flags, total_rows, before, false, n_runs_dev, scan_tmp));
+            }
+            uint64_t tcap = 1024;
+            while (tcap < 2ull * (uint64_t)total_rows) tcap <<= 1;
+            uint32_t* table = tmp.get<uint32_t>(tcap);
+            uint32_t* min_head = tmp.get<uint32_t>(tcap);
+            uint32_t* head = tmp.get<uint32_t>((size_t)total_rows + 1);
+            uint32_t* slot_of_run = tmp.get<uint32_t>((size_t)total_rows + 1);
+            uint32_t* winner = tmp.get<uint32_t>((size_t)total_rows + 1);
+            T.owner = tmp.get<uint32_t>((size_t)total_rows + 1);
+            HIP_CHECK(hipMemsetAsync(table, 0, tcap * 4, ex.stream));
+            HIP_CHECK(hipMemsetAsync(min_head, 0xFF, tcap * 4, ex.stream));
+            HIP_CHECK(hipMemsetAsync(T.owner, 0, ((size_t)total_rows + 1) * 4, ex.stream));
+            TIMED_LAUNCH_N(ex, "run_slots", total_rows, launch_run_slots(cfg, flags, before, (uint32_t)total_rows, T.rowslot, head));
+            TIMED_LAUNCH_N(ex, "run_groups", total_rows, launch_run_groups(cfg, keys, (uint32_t)total_rows, head, n_runs_dev, table, tcap - 1, min_head, slot_of_run,
+                                                                            winner, T.owner, T.rowslot));
+        }
+    }
+
+    uint64_t cap;
+    if (runs) {
+        cap = (uint64_t)total_rows;                  // the slot space is the space of runs: at most one per row; unused ones stay empty
+        T.slots_given = 1;
+        T.mask = cap - 1;
+    } else {
+        // capacity: power of two >= 2 x rows (every row could be its own group)
+        cap = 1024;
+        while (cap < 2ull * (uint64_t)total_rows) cap <<= 1;
+        T.mask = cap - 1;
+        T.owner = tmp.get<uint32_t>(cap);
+        HIP_CHECK(hipMemsetAsync(T.owner, 0, cap * 4, ex.stream));
+    }
+    T.acc = tmp.get<uint64_t>(cap * n_acc);
+    T.rows = tmp.get<uint64_t>(cap);
+    if (nullable) T.nvalid = tmp.get<uint64_t>(cap * n_acc);
+    HIP_CHECK(hipMemsetAsync(T.rows, 0, cap * 8, ex.stream));
+    if (nullable) HIP_CHECK(hipMemsetAsync(T.nvalid, 0, cap * n_acc * 8, ex.stream));
+    if (P0.n_acc > 0) TIMED_LAUNCH(ex, "hash_agg_init", launch_hash_agg_init(cfg, T, kinds));
+
     uint32_t row_base = 0;
     for (auto& b : inputs) {
         ScanParams P = P0;
         ProgramBuilder::bind(P, pb.columns(), *b, nullable);
-        TIMED_LAUNCH_N(ex, "scan_keys", b->n_rows, launch_scan_keys(cfg, P, keys + 2ull * row_base, nullptr, nullptr, status));
         TIMED_LAUNCH_N(ex, "scan_agg_hash", b->n_rows, launch_scan_agg_hash(cfg, P, T, row_base, status));
         row_base += (uint32_t)b->n_rows;
     }
@@ -587,7 +642,7 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
             // ---- hash path: one device-wide table, atomics ----------------------------------------
             early.reset();
             sop_layout = false;              // the hash path packs keys with the VM's layout
-            table = hash_aggregate(ex, tmp, P0, pb, inputs, nullable, &n_groups, status, timer);
+            table = hash_aggregate(ex, tmp, P0, pb, inputs, nullable, &n_groups, status, timer, &clustered_hint_);
             break;
         }
         // ---- register path ----------------------------------------------------------------------

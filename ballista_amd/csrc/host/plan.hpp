@@ -215,6 +215,7 @@ private:
     SchemaPtr schema_;
     mutable std::atomic<int> path_hint_{0};    // 0 = unknown, 4/8 = register path with that many groups, -1 = hash path
     mutable std::atomic<bool> wide_keys_{false};   // a run found key values the packed key cannot hold
+    mutable std::atomic<int> clustered_hint_{0};   // hash path: 0 = unknown, 1 = the input came clustered by group key last time, -1 = it did not
 };
 
 struct JoinBuildSide;

@@ -64,13 +64,18 @@ scan_agg_hash_kernel(const ScanParams P, const HashAggTable T, uint32_t row_base
             const uint32_t grow = row_base + (uint32_t)row;
             if (live && P.pred_slot >= 0) live = L.bvals[P.pred_slot * TILE + idx] & 1;
             if (!live) {
-                if (T.n_fsum && row < P.n_rows) T.rowslot[grow] = 0xFFFFFFFFu;
+                if (T.n_fsum && !T.slots_given && row < P.n_rows) T.rowslot[grow] = 0xFFFFFFFFu;
                 continue;
             }
-            const Key128 key{T.keys128[2ull * grow], T.keys128[2ull * grow + 1]};
-            const uint32_t slot = table_upsert(T.owner, T.mask, T.keys128, key, grow);
+            uint32_t slot;
+            if (T.slots_given) {
+                slot = T.rowslot[grow];                                 // clustered input: the row's run is its group (run_* kernels below)
+            } else {
+                const Key128 key{T.keys128[2ull * grow], T.keys128[2ull * grow + 1]};
+                slot = table_upsert(T.owner, T.mask, T.keys128, key, grow);
+                if (T.n_fsum) T.rowslot[grow] = slot;
+            }
             atomicAdd(reinterpret_cast<unsigned long long*>(&T.rows[slot]), 1ull);
-            if (T.n_fsum) T.rowslot[grow] = slot;
             for (int a = 0; a < P.n_acc; ++a) {
                 const AccSpec sp = P.acc[a];
                 uint64_t v = 1;
@@ -95,6 +100,65 @@ scan_agg_hash_kernel(const ScanParams P, const HashAggTable T, uint32_t row_base
     if (err) atomicOr(&status->flags, err);
 }
 
+// ---- input clustered by group key ------------------------------------------------------------------------------------------
+// When the rows of a group tend to be consecutive (lineitem joined to its orders and grouped by the order key: TPC-H Q3, 2.6
+// rows per group), the table is consulted once per RUN of equal packed keys instead of once per row, and the slot space is the
+// dense space of runs:
+//   run_heads   flags[i] = row i starts a run                                   (then an exclusive scan: runs before row i)
+//   run_slots   rowslot[i] = run of row i; head[run] = its first row
+//   run_claim   every run looks its key up in a table keyed by head rows and records the SMALLEST head row among the runs with
+//               that key (a key that comes back later — nothing is assumed about the input — joins the earlier run)
+//   run_winner  winner[run] = the run that owns the key; owner[run] = head row + 1 for an owning run, 0 for one that joined another
+//   run_remap   rowslot[i] = winner[run of row i]
+// after which the scan adds into slot rowslot[i] (scan_agg_hash_kernel with slots_given) and the compaction runs over the run
+// space.  The group of every row is decided by key equality alone; deterministic whatever the schedule (the minimum).
+__global__ void __launch_bounds__(BLOCK)
+run_heads_kernel(const uint64_t* keys128, uint32_t n, uint32_t* flags) {
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const ulonglong2 k = reinterpret_cast<const ulonglong2*>(keys128)[i];
+        uint32_t head = 1;
+        if (i > 0) {
+            const ulonglong2 p = reinterpret_cast<const ulonglong2*>(keys128)[i - 1];
+            head = (k.x != p.x || k.y != p.y) ? 1u : 0u;
+        }
+        flags[i] = head;
+    }
+}
+__global__ void __launch_bounds__(BLOCK)
+run_slots_kernel(const uint32_t* flags, const uint32_t* runs_before, uint32_t n, uint32_t* rowslot, uint32_t* head) {
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const uint32_t run = runs_before[i] + flags[i] - 1u;
+        rowslot[i] = run;
+        if (flags[i]) head[run] = i;
+    }
+}
+__global__ void __launch_bounds__(BLOCK)
+run_claim_kernel(const uint64_t* keys128, const uint32_t* head, const uint64_t* n_runs_dev, uint32_t* table, uint64_t mask, uint32_t* min_head,
+                 uint32_t* slot_of_run) {
+    const uint32_t n_runs = (uint32_t)*n_runs_dev;
+    for (uint32_t r = blockIdx.x * BLOCK + threadIdx.x; r < n_runs; r += gridDim.x * BLOCK) {
+        const uint32_t h = head[r];
+        const Key128 key{keys128[2ull * h], keys128[2ull * h + 1]};
+        const uint32_t slot = table_upsert(table, mask, keys128, key, h);
+        atomicMin(&min_head[slot], h);
+        slot_of_run[r] = slot;
+    }
+}
+__global__ void __launch_bounds__(BLOCK)
+run_winner_kernel(const uint32_t* head, const uint64_t* n_runs_dev, const uint32_t* min_head, const uint32_t* slot_of_run, const uint32_t* run_of_row,
+                  uint32_t* winner, uint32_t* owner) {
+    const uint32_t n_runs = (uint32_t)*n_runs_dev;
+    for (uint32_t r = blockIdx.x * BLOCK + threadIdx.x; r < n_runs; r += gridDim.x * BLOCK) {
+        const uint32_t w = min_head[slot_of_run[r]];           // first row of the earliest run with this key
+        winner[r] = run_of_row[w];
+        owner[r] = w == head[r] ? w + 1u : 0u;
+    }
+}
+__global__ void __launch_bounds__(BLOCK)
+run_remap_kernel(const uint32_t* winner, uint32_t n, uint32_t* rowslot) {
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) rowslot[i] = winner[rowslot[i]];
+}
+
 // accumulator identities (min/max) must be in place before the first atomic
 __global__ void __launch_bounds__(BLOCK)
 hash_agg_init_kernel(HashAggTable T, MergeAccKinds kinds) {
@@ -117,7 +181,7 @@ hash_agg_compact_kernel(HashAggTable T, const uint64_t* dense_index, int nulls, 
     for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
         const uint32_t o = T.owner[i];
         if (o == 0) continue;
-        GroupRec& g = out[dense_index[i]];
+        GroupRec& g = out[dense_index ? dense_index[i] : i];
         g.k0 = T.keys128[2ull * (o - 1u)];
         g.k1 = T.keys128[2ull * (o - 1u) + 1];
         g.rows = T.rows[i];
@@ -508,6 +572,31 @@ hipError_t launch_scan_agg_hash(const LaunchCfg& cfg, const ScanParams& P, const
                                 ScanStatus* status) {
     return P.prog.nullable ? launch_agg_hash_n<true>(cfg, P, T, row_base, status)
                            : launch_agg_hash_n<false>(cfg, P, T, row_base, status);
+}
+
+static unsigned run_grid(const LaunchCfg& cfg, size_t n) {
+    size_t g = (n + BLOCK - 1) / BLOCK;
+    if (g > (size_t)cfg.device_cus * 16) g = (size_t)cfg.device_cus * 16;
+    return (unsigned)(g < 1 ? 1 : g);
+}
+hipError_t launch_run_heads(const LaunchCfg& cfg, const uint64_t* keys128, uint32_t n, uint32_t* flags) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(run_heads_kernel, dim3(run_grid(cfg, n)), dim3(BLOCK), 0, cfg.stream, keys128, n, flags);
+    return hipGetLastError();
+}
+hipError_t launch_run_slots(const LaunchCfg& cfg, const uint32_t* flags, const uint32_t* runs_before, uint32_t n, uint32_t* rowslot, uint32_t* head) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(run_slots_kernel, dim3(run_grid(cfg, n)), dim3(BLOCK), 0, cfg.stream, flags, runs_before, n, rowslot, head);
+    return hipGetLastError();
+}
+hipError_t launch_run_groups(const LaunchCfg& cfg, const uint64_t* keys128, uint32_t n, const uint32_t* head, const uint64_t* n_runs_dev, uint32_t* table,
+                             uint64_t mask, uint32_t* min_head, uint32_t* slot_of_run, uint32_t* winner, uint32_t* owner, uint32_t* rowslot) {
+    if (n == 0) return hipSuccess;
+    const unsigned g = run_grid(cfg, n);                         // the run count is only known on the device: sized for n, bounded by it there
+    hipLaunchKernelGGL(run_claim_kernel, dim3(g), dim3(BLOCK), 0, cfg.stream, keys128, head, n_runs_dev, table, mask, min_head, slot_of_run);
+    hipLaunchKernelGGL(run_winner_kernel, dim3(g), dim3(BLOCK), 0, cfg.stream, head, n_runs_dev, min_head, slot_of_run, rowslot, winner, owner);
+    hipLaunchKernelGGL(run_remap_kernel, dim3(g), dim3(BLOCK), 0, cfg.stream, winner, n, rowslot);
+    return hipGetLastError();
 }
 
 static int grid_n(const LaunchCfg& cfg, size_t n) {

@@ -211,6 +211,35 @@ def test_hash_aggregate_group_by(ctx, gi):
     run_both(fin, ordered=False, float_rtol=1e-9, key_cols=[n for _, n in names])
 
 
+@pytest.mark.parametrize("shape", ["clustered", "clustered_two_keys", "comes_back", "descending", "with_predicate"])
+def test_hash_aggregate_over_input_clustered_by_group(ctx, shape):
+    """many groups whose rows are consecutive (lineitem joined to orders, grouped by the order key): every run of equal keys is a
+    group and no table is needed — IF no key comes back later, which the same pass checks (every key change an increase of the
+    packed image).  'comes_back' / 'descending' fail that check and take the table; a fused predicate does too.  Several input
+    batches, NULLs in the summed column, runs that straddle 1024-row tiles and batch boundaries."""
+    from collections import OrderedDict
+    rng = np.random.default_rng(7)
+    n = 40_000
+    sizes = rng.integers(1, 9, n)
+    sizes[100] = 5000                                               # one run longer than several tiles
+    key = np.repeat(np.arange(len(sizes), dtype=np.int64) * 3 + 10, sizes)[:n]
+    if shape == "comes_back":
+        key[n - 50:] = key[5]                                       # an early key again at the very end
+    if shape == "descending":
+        key = key[::-1].copy()
+    b = OrderedDict([("k", OCol("Int64", key)), ("k2", OCol("Int32", (key % 7).astype(np.int32))),
+                     ("x", OCol("Float64", np.round(rng.normal(0, 10, n), 3), rng.random(n) > 0.1)), ("q", OCol("Int32", rng.integers(0, 50, n)))])
+    parts = [[helpers.slice_batch(b, 0, 13_000)], [helpers.slice_batch(b, 13_000, n)]]
+    m = ba.MergeExec(helpers.memory_exec(ctx, parts))               # ONE partition, two batches: runs cross the batch boundary
+    src = ba.FilterExec(col("q") < lit(40, E.INT32), m) if shape == "with_predicate" else m
+    group = [(col("k"), "k")] + ([(col("k2"), "k2")] if shape == "clustered_two_keys" else [])
+    aggs = [E.Sum(col("x"), "sx"), E.Count(col("x"), "cx"), E.Count(lit(1, E.UINT8), "n"), E.Min(col("q"), "mn"), E.Avg(col("q"), "aq")]
+    plan = ba.HashAggregateExec(ba.plan.PARTIAL, group, aggs, src)
+    for _ in range(2):                                              # the second run uses what the first one learned about the input
+        got = run_both(plan, ordered=False, float_rtol=1e-12, key_cols=[nm for _, nm in group])
+    assert len(got["k"].values) > 5000
+
+
 def test_aggregate_over_projection_and_filter_fuses(ctx):
     b = random_batch(5000, seed=77)
     m = helpers.memory_exec(ctx, [[b]])
