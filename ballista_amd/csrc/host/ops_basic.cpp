@@ -73,7 +73,7 @@ Column take_column(const Exec& ex, const Column& c, const uint32_t* idx, int64_t
         if (bytes > 0x7FFFFFFFull) fail(BHIP_EEXEC, "Utf8 column exceeds 2 GiB of value bytes");
         out.data_bytes = (int64_t)bytes;
         out.data = make_buffer(ex, (size_t)bytes + 8);
-        TIMED_LAUNCH_N(ex, "take_utf8_copy", n, launch_take_utf8_copy(cfg, c.offsets->as<int32_t>(), c.data->as<uint8_t>(), idx, n,
+        TIMED_LAUNCH_N(ex, "take_utf8_copy", n, launch_take_utf8_copy(cfg, c.offsets->as<int32_t>(), c.data->as<uint8_t>(), c.data_bytes, idx, n,
                                         out.offsets->as<int32_t>(), out.data->as<uint8_t>()));
     } else if (c.dtype == DT_BOOLEAN) {
         out.data = make_buffer(ex, bitmap_bytes(n) + 8);

@@ -293,14 +293,54 @@ take_utf8_lengths_kernel(const int32_t* offsets, const uint32_t* idx, int64_t n,
     }
 }
 
+// The 64 strings a wave gathers land back to back in the output.  They are assembled in LDS (one 8-byte load per short string,
+// byte stores into LDS) and written out with coalesced 4-byte stores: ~7x fewer global-memory instructions than a byte loop per
+// row for TPC-H's short names.  A wave whose strings exceed the staging area copies row by row.
+constexpr int TAKE_STAGE = 2048;
+struct __attribute__((packed)) Unaligned64 { uint64_t v; };
+struct __attribute__((packed)) Unaligned32 { uint32_t v; };
+
 __global__ void __launch_bounds__(BLOCK)
-take_utf8_copy_kernel(const int32_t* src_off, const uint8_t* src, const uint32_t* idx, int64_t n,
+take_utf8_copy_kernel(const int32_t* src_off, const uint8_t* src, int64_t src_bytes, const uint32_t* idx, int64_t n,
                       const int32_t* dst_off, uint8_t* dst) {
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
-        const uint32_t j = idx[i];
-        if (j == NULL_INDEX) continue;
-        const int32_t s0 = src_off[j], len = src_off[j + 1] - s0, d0 = dst_off[i];
-        for (int32_t b = 0; b < len; ++b) dst[d0 + b] = src[s0 + b];
+    __shared__ uint8_t s_stage[BLOCK / 64][TAKE_STAGE];
+    uint8_t* stage = s_stage[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
+    const int64_t n_round = (n + 63) & ~(int64_t)63;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n_round; i += (int64_t)gridDim.x * BLOCK) {
+        const int64_t i0 = i - lane;                                          // first row of this wave's 64
+        const int64_t i1 = i0 + 64 < n ? i0 + 64 : n;
+        const int32_t wave_d0 = dst_off[i0], total = dst_off[i1] - wave_d0;     // wave-uniform
+        int32_t s0 = 0, len = 0, d0 = 0;
+        if (i < n) {
+            const uint32_t j = idx[i];
+            d0 = dst_off[i];
+            if (j != NULL_INDEX) { s0 = src_off[j]; len = src_off[j + 1] - s0; }
+        }
+        if (total <= TAKE_STAGE) {
+            const int off = d0 - wave_d0;
+            if (len > 0 && len <= 8 && (int64_t)s0 + 8 <= src_bytes) {
+                uint64_t v = reinterpret_cast<const Unaligned64*>(src + s0)->v;
+                for (int b = 0; b < len; ++b) { stage[off + b] = (uint8_t)v; v >>= 8; }
+            } else {
+                for (int b = 0; b < len; ++b) stage[off + b] = src[s0 + b];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            uint8_t* out = dst + wave_d0;
+            for (int p = lane * 4; p < total; p += 256) {
+                if (p + 4 <= total) {
+                    uint32_t w;
+                    __builtin_memcpy(&w, stage + p, 4);
+                    reinterpret_cast<Unaligned32*>(out + p)->v = w;
+                } else {
+                    for (int b = p; b < total; ++b) out[b] = stage[b];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();                                  // the next round overwrites the staging area
+        } else {
+            for (int32_t b = 0; b < len; ++b) dst[d0 + b] = src[s0 + b];
+        }
     }
 }
 
@@ -348,10 +388,10 @@ hipError_t launch_take_utf8_lengths(const LaunchCfg& cfg, const int32_t* offsets
     return hipGetLastError();
 }
 
-hipError_t launch_take_utf8_copy(const LaunchCfg& cfg, const int32_t* src_off, const uint8_t* src, const uint32_t* idx,
+hipError_t launch_take_utf8_copy(const LaunchCfg& cfg, const int32_t* src_off, const uint8_t* src, int64_t src_bytes, const uint32_t* idx,
                                  int64_t n, const int32_t* dst_off, uint8_t* dst) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(take_utf8_copy_kernel, dim3(grid_for(cfg, n)), dim3(BLOCK), 0, cfg.stream, src_off, src, idx, n,
+    hipLaunchKernelGGL(take_utf8_copy_kernel, dim3(grid_for(cfg, n)), dim3(BLOCK), 0, cfg.stream, src_off, src, src_bytes, idx, n,
                        dst_off, dst);
     return hipGetLastError();
 }
