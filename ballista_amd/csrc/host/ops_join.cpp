@@ -26,6 +26,8 @@ struct JoinBuildSide {
     int narrow_width = 0;           // its key bytes (4: Int32 / Date32, 8: Int64 / UInt64)
     BufferPtr slots, present, rbits, rprefix, rperm;
     NarrowJoinTable ntable;
+    Column key_holder;              // two-column join: the key column built for it (packed pair, or the first key with both validities)
+    bool resid = false;             // two-column join by the first key; the second is compared on every match (ntable.resid_build)
     // BHIP_JOIN_RADIX=1: the build side in partition order for the LDS join (kernels_radix_join.hip), the A/B partner
     BufferPtr rj_keys, rj_rows, rj_first;
     int rj_log2p = -1;
@@ -130,7 +132,32 @@ static void side_keys(const Exec& ex, const Batch& b, const std::vector<std::str
 }
 
 // ONE key pair of integer columns of the same width on both sides: 4 (Int32 / Date32), 8 (Int64 / UInt64), else 0
+bool HashJoinExec::pair_keys() const {
+    if (on_.size() != 2) return false;
+    const Schema &ls = *left_->schema(), &rs = *right_->schema();
+    auto four = [](int t) { return t == DT_INT32 || t == DT_DATE32 || t == DT_UINT32; };
+    for (auto& p : on_) {
+        const int lt = ls.fields[ls.index_of(p.first)].dtype, rt = rs.fields[rs.index_of(p.second)].dtype;
+        if (!four(lt) || lt != rt) return false;
+    }
+    return true;
+}
+
+// the key column the single-key path works on: the column itself, or the two 4-byte key columns packed into one Int64 column
+static Column pack_key_pair(const Exec& ex, const Column& a, const Column& b, int64_t n) {
+    Column k;
+    k.dtype = DT_INT64;
+    k.length = n;
+    k.data = make_buffer(ex, (size_t)n * 8 + 8);
+    if (a.validity || b.validity) k.validity = make_buffer(ex, bitmap_bytes(n) + 8);
+    TIMED_LAUNCH_N(ex, "pack_key_pair", n, launch_pack_key_pair(ex.cfg(), a.data->ptr(), b.data->ptr(), a.validity ? a.validity->as<uint64_t>() : nullptr,
+                                                                 b.validity ? b.validity->as<uint64_t>() : nullptr, n, k.data->as<uint64_t>(),
+                                                                 k.validity ? k.validity->as<uint64_t>() : nullptr));
+    return k;
+}
+
 int HashJoinExec::narrow_key_width() const {
+    if (pair_keys()) return 8;
     if (on_.size() != 1) return 0;
     const Schema &ls = *left_->schema(), &rs = *right_->schema();
     const int lt = ls.fields[ls.index_of(on_[0].first)].dtype, rt = rs.fields[rs.index_of(on_[0].second)].dtype;
@@ -176,10 +203,9 @@ std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) co
     static const bool narrow_disabled = [] { const char* v = getenv("BHIP_NO_NARROW_JOIN"); return v && atoi(v) != 0; }();
     // BHIP_JOIN_TABLE=1: always the CAS table (+ key-set bitmap), the round-1 design — the A/B partner of the rank map
     static const bool force_table = [] { const char* v = getenv("BHIP_JOIN_TABLE"); return v && atoi(v) != 0; }();
-    const int nkw = narrow_disabled ? 0 : narrow_key_width();
-    if (nkw && n > 0) {
+    // the single-key structures over key column `kc` of width `nkw`: rank map, else CAS table; false: the keys are not unique
+    auto try_narrow = [&](const Column& kc, int nkw) -> bool {
         // optimistic: the build side of a key join is almost always unique
-        const Column& kc = bs->batch->cols[bs->batch->schema->index_of(lcols[0])];
         const uint64_t* ksel = kc.validity ? kc.validity->as<uint64_t>() : nullptr;
         memset(&bs->ntable, 0, sizeof(bs->ntable));
         bs->narrow_width = nkw;
@@ -240,8 +266,7 @@ std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) co
                     radix_partition_side(ex, kc.data->as<uint32_t>(), n, lg, bs->rj_keys, bs->rj_rows, bs->rj_first);
                     stream_wait(ex);
                 }
-                cache_->built = bs;
-                return bs;
+                return true;
             }
             bs->rbits.reset();
             bs->rprefix.reset();
@@ -272,13 +297,41 @@ std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) co
                     bs->ntable.krange = (uint32_t)range;
                 }
                 bs->narrow = bs->unique = true;
-                cache_->built = bs;
-                return bs;
+                return true;
             }
             bs->slots.reset();
             bs->present.reset();
         }
         memset(&bs->ntable, 0, sizeof(bs->ntable));
+            return false;
+    };
+    const int nkw = narrow_disabled ? 0 : narrow_key_width();
+    if (nkw && n > 0) {
+        const Schema& lsch = *bs->batch->schema;
+        const Column& c0 = bs->batch->cols[lsch.index_of(lcols[0])];
+        if (pair_keys()) {
+            const Column& c1 = bs->batch->cols[lsch.index_of(lcols[1])];
+            // ON (a, b) = (c, d), 4-byte integers.  First choice: the build side unique on `a` alone (a key and an attribute it determines:
+            // TPC-H Q5's s_suppkey, s_nationkey) — the join goes by `a` (rank map where the keys are dense) and a match stands only if
+            // the second columns agree (join_filter_probe_kernel<RESID>).  Second: both columns packed into one 8-byte key.
+            Column first = c0;
+            if (c1.validity) {                         // a build row with a NULL in either part matches nothing
+                first.validity = make_buffer(ex, bitmap_bytes(n) + 8);
+                HIP_CHECK(launch_and_bitmaps(ex.cfg(), c0.validity ? c0.validity->as<uint64_t>() : nullptr, c1.validity->as<uint64_t>(), n, first.validity->as<uint64_t>()));
+            }
+            if (try_narrow(first, 4)) {
+                bs->key_holder = first;
+                bs->ntable.resid_build = c1.data->as<uint32_t>();
+                bs->resid = true;
+                cache_->built = bs;
+                return bs;
+            }
+            const Column packed = pack_key_pair(ex, c0, c1, n);
+            if (try_narrow(packed, 8)) { bs->key_holder = packed; cache_->built = bs; return bs; }
+        } else if (try_narrow(c0, nkw)) {
+            cache_->built = bs;
+            return bs;
+        }
     }
     side_keys(ex, *bs->batch, lcols, bs->keys, bs->sel, bs->has_sel);
     bs->owner = make_buffer(ex, cap * 8);
@@ -518,7 +571,7 @@ StreamPtr HashJoinExec::execute_needed(int partition, const Exec& ex, const std:
         // ---- narrow build side: one pass over the probe rows: ranges -> key-set bit -> rank map / table (kernels_join.hip) -----
         // n probe rows whose keys are `kc`; output columns come from `outsrc` (row remap[i] of it for probe row i; nullptr: row i)
         auto process_fused = [&](int64_t n, const ProbeFilter& F, const Column& kc, const Batch* outsrc, const std::vector<int>* rmap,
-                                 const uint32_t* remap) {
+                                 const uint32_t* remap, const Column* resid = nullptr) {
             if (n == 0) return;
             const int64_t n_tiles = (n + SEL_TILE - 1) / SEL_TILE;
             Temp tmp(ex);
@@ -532,7 +585,8 @@ StreamPtr HashJoinExec::execute_needed(int partition, const Exec& ex, const std:
             TIMED_LAUNCH_B(ex, "join_filter_probe", n, (uint64_t)n * (uint64_t)(bs->narrow_width + 4 * F.n) + (uint64_t)n / 8,
                            launch_join_filter_probe(cfg, bs->ntable, F, kc.data->ptr(), bs->narrow_width,
                                                     kc.validity ? kc.validity->as<uint64_t>() : nullptr, (uint32_t)n, right_outer, bitmap,
-                                                    tile_counts, staging, left_outer ? matched->as<uint32_t>() : nullptr));
+                                                    tile_counts, staging, left_outer ? matched->as<uint32_t>() : nullptr,
+                                                    resid ? resid->data->as<uint32_t>() : nullptr));
             HIP_CHECK(exclusive_scan_u32_u64(ex.stream, tile_counts, n_tiles, tile_off, false, total, scan_tmp));
             const uint64_t n_out = read_device(ex, total);
             if (n_out == 0) return;
@@ -589,6 +643,22 @@ StreamPtr HashJoinExec::execute_needed(int partition, const Exec& ex, const std:
         };
         const bool radix_mode = bs->narrow && bs->rj_log2p >= 0 && !right_outer && !left_outer;
 
+        const bool pair = self->pair_keys();
+        // the probe side's key for a two-column join: the first key (+ the second as the residual) when the build side went that way,
+        // else both packed into one 8-byte key; a NULL in either part never matches
+        struct ProbeKey { Column key, second; bool resid; };
+        auto probe_key = [&](const Column& a, const Column& b2, int64_t rows) {
+            ProbeKey pk;
+            pk.resid = bs->resid;
+            if (!bs->resid) { pk.key = pack_key_pair(ex, a, b2, rows); return pk; }
+            pk.key = a;
+            pk.second = b2;
+            if (b2.validity) {
+                pk.key.validity = make_buffer(ex, bitmap_bytes(rows) + 8);
+                HIP_CHECK(launch_and_bitmaps(cfg, a.validity ? a.validity->as<uint64_t>() : nullptr, b2.validity->as<uint64_t>(), rows, pk.key.validity->as<uint64_t>()));
+            }
+            return pk;
+        };
         const ProbeChain chain = probe_chain(self->right_);
         static const bool fused_disabled = [] { const char* v = getenv("BHIP_NO_FUSED_PROBE"); return v && atoi(v) != 0; }();
         if (chain.ok) {
@@ -621,7 +691,12 @@ StreamPtr HashJoinExec::execute_needed(int partition, const Exec& ex, const std:
                     if (process_radix(n_probe, keys, b.get(), &rmap, remap)) continue;
                 }
                 if (bs->narrow && !fused_disabled && int_ranges_of(chain.pred, *b, F)) {
-                    process_fused(b->n_rows, F, b->cols[key_src[0]], b.get(), &rmap, nullptr);
+                    if (pair) {
+                        const ProbeKey pk = probe_key(b->cols[key_src[0]], b->cols[key_src[1]], b->n_rows);
+                        process_fused(b->n_rows, F, pk.key, b.get(), &rmap, nullptr, pk.resid ? &pk.second : nullptr);
+                    } else {
+                        process_fused(b->n_rows, F, b->cols[key_src[0]], b.get(), &rmap, nullptr);
+                    }
                     continue;
                 }
                 const uint32_t* remap = nullptr;
@@ -639,13 +714,20 @@ StreamPtr HashJoinExec::execute_needed(int partition, const Exec& ex, const std:
                 } else {
                     for (int ci : key_src) kb->cols.push_back(b->cols[ci]);
                 }
-                if (bs->narrow) process_fused(kb->n_rows, no_filter, kb->cols[0], b.get(), &rmap, remap);
+                if (bs->narrow && pair) {
+                    const ProbeKey pk = probe_key(kb->cols[0], kb->cols[1], kb->n_rows);
+                    process_fused(kb->n_rows, no_filter, pk.key, b.get(), &rmap, remap, pk.resid ? &pk.second : nullptr);
+                } else if (bs->narrow) process_fused(kb->n_rows, no_filter, kb->cols[0], b.get(), &rmap, remap);
                 else process(*kb, b.get(), &rmap, remap);
             }
         } else {
             auto rs = self->right_->execute(partition, ex);
             while (BatchPtr rb = rs->next()) {
-                if (bs->narrow) process_fused(rb->n_rows, no_filter, rb->cols[rb->schema->index_of(rcols[0])], rb.get(), nullptr, nullptr);
+                if (bs->narrow && pair) {
+                    const ProbeKey pk = probe_key(rb->cols[rb->schema->index_of(rcols[0])], rb->cols[rb->schema->index_of(rcols[1])], rb->n_rows);
+                    process_fused(rb->n_rows, no_filter, pk.key, rb.get(), nullptr, nullptr, pk.resid ? &pk.second : nullptr);
+                } else if (bs->narrow)
+                    process_fused(rb->n_rows, no_filter, rb->cols[rb->schema->index_of(rcols[0])], rb.get(), nullptr, nullptr);
                 else process(*rb, rb.get(), nullptr, nullptr);
             }
         }

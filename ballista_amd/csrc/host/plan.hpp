@@ -241,6 +241,7 @@ private:
     SchemaPtr schema_;
     std::vector<int> right_cols_;   // right columns kept in the output
     int narrow_key_width() const;
+    bool pair_keys() const;          // TWO 4-byte integer key pairs: packed into one 8-byte key per side, then the single-key machinery
     // the build side (hash table over the whole left child) is built once and shared by every
     // partition's task, like DataFusion's collect-left build future
     struct BuildCache { std::mutex mu; std::shared_ptr<const JoinBuildSide> built; };

@@ -183,17 +183,20 @@ template <int FP_CHUNK>
 struct WaveScratchT {
     uint64_t a[FP_CHUNK];        // rank map: word index; table: the key
     uint32_t b[FP_CHUNK];        // rank map: popcount of the lower bits; then: the result (build row)
+    uint32_t c[FP_CHUNK];        // residual key (second key column of a two-column join) of the probe row
 };
 
 // NF: filter columns compiled in (0, 1 or JOIN_FILTER_MAX): registers for the ones a plan does not have would only cost occupancy.
 // Every streamed load and the key-set word load are UNCONDITIONAL (row index clamped to the last row, word index 0 for rows that
 // do not need it): a predicated load costs a saved-exec branch of its own — the first version of this kernel spent as many scalar
 // as vector instructions on them (rocprofv3 SQ_INSTS_SALU 293 M vs SQ_INSTS_VALU 275 M per launch, profiles/r02_probe_variants_q3_sf100.txt).
-template <int KW, int NF, int FP_ROWS>
+// RESID: a second 4-byte key column on both sides (ON a = c AND b = d with the build side unique on `a` alone): the lookup goes by
+// the first key, a match stands only if the second keys are equal too (T.resid_build[build row] vs the probe row's value).
+template <int KW, int NF, int FP_ROWS, bool RESID>
 __global__ void __launch_bounds__(BLOCK)
 join_filter_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void* __restrict__ rkeys_v, const uint64_t* __restrict__ rsel,
                          uint32_t n_right, int right_outer, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts,
-                         uint32_t* __restrict__ staging, uint32_t* matched) {
+                         uint32_t* __restrict__ staging, uint32_t* matched, const uint32_t* __restrict__ resid_probe) {
     using K = typename KeyT<KW>::type;
     constexpr int NFR = NF > 0 ? NF : 1;
     constexpr int FP_CHUNK = 64 * FP_ROWS;           // rows of one pass of a wave
@@ -213,13 +216,14 @@ join_filter_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const voi
 
     // the streamed inputs of one pass; the NEXT pass's are loaded before this pass walks its dependent reads.
     // Rows are 32-bit (a batch holds < 2^32 - 16 rows and a pass starts at a multiple of 256: base + 255 does not wrap).
-    struct Regs { K key[FP_ROWS]; int32_t f[NFR][FP_ROWS]; };
+    struct Regs { K key[FP_ROWS]; int32_t f[NFR][FP_ROWS]; uint32_t g[RESID ? FP_ROWS : 1]; };
     auto load = [&](uint32_t base, Regs& r) {
 #pragma unroll
         for (int k = 0; k < FP_ROWS; ++k) {
             const uint32_t row = base + 64u * k + lane;
             const uint32_t rc = row < last_row ? row : last_row;
             r.key[k] = rkeys[rc];
+            if (RESID) r.g[RESID ? k : 0] = resid_probe[rc];
 #pragma unroll
             for (int j = 0; j < NF; ++j) r.f[j][k] = F.col[j < F.n ? j : 0][rc];
         }
@@ -282,6 +286,7 @@ join_filter_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const voi
                     if (live[k]) {
                         if (ranked) { S.a[idx[k]] = d[k] >> 6; S.b[idx[k]] = (uint32_t)__popcll(word[k] & ((1ull << (d[k] & 63)) - 1ull)); }
                         else S.a[idx[k]] = (uint64_t)cur.key[k];
+                        if (RESID) S.c[idx[k]] = cur.g[RESID ? k : 0];
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -294,6 +299,7 @@ join_filter_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const voi
                     } else {
                         r = table_lookup<KW>(T, (K)S.a[j]);
                     }
+                    if (RESID && r != 0xFFFFFFFFu && T.resid_build[r] != S.c[j]) r = 0xFFFFFFFFu;
                     S.b[j] = r;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -335,6 +341,19 @@ join_compact_staged_kernel(const uint32_t* __restrict__ staging, const uint64_t*
         const uint32_t cnt = (uint32_t)(end - off);
         for (uint32_t j = lane; j < cnt; j += 64) out[off + j] = staging[(uint64_t)t * SEL_TILE + j];
     }
+}
+
+// two 4-byte integer key columns -> ONE 8-byte key (first column in the high half): a two-column equi-join runs the
+// single-key machinery; a row is valid when both parts are
+__global__ void __launch_bounds__(BLOCK)
+pack_key_pair_kernel(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, int64_t n, uint64_t* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK)
+        out[i] = ((uint64_t)a[i] << 32) | (uint64_t)b[i];
+}
+__global__ void __launch_bounds__(BLOCK)
+and_bitmaps_kernel(const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, int64_t n_words, uint64_t* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n_words; i += (int64_t)gridDim.x * BLOCK)
+        out[i] = (a ? a[i] : ~0ull) & (b ? b[i] : ~0ull);
 }
 
 int rows_grid(const LaunchCfg& cfg, size_t n) {
@@ -386,8 +405,9 @@ hipError_t launch_rank_perm(const LaunchCfg& cfg, const void* keys, int key_widt
 
 hipError_t launch_join_filter_probe(const LaunchCfg& cfg, const NarrowJoinTable& T, const ProbeFilter& F, const void* rkeys, int key_width,
                                     const uint64_t* rsel, uint32_t n_right, bool right_outer, uint64_t* bitmap, uint32_t* tile_counts,
-                                    uint32_t* staging, uint32_t* matched) {
+                                    uint32_t* staging, uint32_t* matched, const uint32_t* resid_probe) {
     if (n_right == 0) return hipSuccess;
+    if ((resid_probe != nullptr) != (T.resid_build != nullptr)) return hipErrorInvalidValue;
     const int64_t n_tiles = ((int64_t)n_right + SEL_TILE - 1) / SEL_TILE;
     static const int per_cu = [] { const char* v = getenv("BHIP_PROBE_BLOCKS_PER_CU"); return v && atoi(v) > 0 ? atoi(v) : 12; }();   // profiles/r02_probe_variants_q3_sf100.txt
     int64_t grid = (int64_t)cfg.device_cus * per_cu;
@@ -395,8 +415,14 @@ hipError_t launch_join_filter_probe(const LaunchCfg& cfg, const NarrowJoinTable&
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;
 #define BHIP_PROBE(KW_, NF_)                                                                                                          \
-    hipLaunchKernelGGL((join_filter_probe_kernel<KW_, NF_, 4>), dim3((unsigned)grid), dim3(BLOCK), 0, cfg.stream, T, F, rkeys, rsel, n_right, \
-                       right_outer ? 1 : 0, bitmap, tile_counts, staging, matched)
+    do {                                                                                                                              \
+        if (resid_probe)                                                                                                              \
+            hipLaunchKernelGGL((join_filter_probe_kernel<KW_, NF_, 4, true>), dim3((unsigned)grid), dim3(BLOCK), 0, cfg.stream, T, F, rkeys,  \
+                               rsel, n_right, right_outer ? 1 : 0, bitmap, tile_counts, staging, matched, resid_probe);               \
+        else                                                                                                                          \
+            hipLaunchKernelGGL((join_filter_probe_kernel<KW_, NF_, 4, false>), dim3((unsigned)grid), dim3(BLOCK), 0, cfg.stream, T, F, rkeys, \
+                               rsel, n_right, right_outer ? 1 : 0, bitmap, tile_counts, staging, matched, resid_probe);               \
+    } while (0)
     if (key_width == 4) {
         if (F.n == 0) BHIP_PROBE(4, 0);
         else if (F.n == 1) BHIP_PROBE(4, 1);
@@ -407,6 +433,21 @@ hipError_t launch_join_filter_probe(const LaunchCfg& cfg, const NarrowJoinTable&
         else BHIP_PROBE(8, JOIN_FILTER_MAX);
     }
 #undef BHIP_PROBE
+    return hipGetLastError();
+}
+
+hipError_t launch_and_bitmaps(const LaunchCfg& cfg, const uint64_t* a, const uint64_t* b, int64_t n_bits, uint64_t* out) {
+    if (n_bits == 0) return hipSuccess;
+    hipLaunchKernelGGL(and_bitmaps_kernel, dim3(rows_grid(cfg, (size_t)(n_bits + 63) / 64)), dim3(BLOCK), 0, cfg.stream, a, b, (n_bits + 63) / 64, out);
+    return hipGetLastError();
+}
+hipError_t launch_pack_key_pair(const LaunchCfg& cfg, const void* a, const void* b, const uint64_t* va, const uint64_t* vb, int64_t n, uint64_t* out,
+                                uint64_t* validity_out) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_key_pair_kernel, dim3(rows_grid(cfg, (size_t)n)), dim3(BLOCK), 0, cfg.stream, static_cast<const uint32_t*>(a),
+                       static_cast<const uint32_t*>(b), n, out);
+    if (validity_out)
+        hipLaunchKernelGGL(and_bitmaps_kernel, dim3(rows_grid(cfg, (size_t)(n + 63) / 64)), dim3(BLOCK), 0, cfg.stream, va, vb, (n + 63) / 64, validity_out);
     return hipGetLastError();
 }
 

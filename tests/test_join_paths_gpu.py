@@ -60,6 +60,37 @@ def test_table_variants(ctx, jt, key_type, unique, nulls):
 
 
 @pytest.mark.parametrize("jt", JOIN_TYPES)
+@pytest.mark.parametrize("unique", ["first_column", "pairs", "no"])
+@pytest.mark.parametrize("nulls", [False, True])
+@pytest.mark.parametrize("filtered", [False, True])
+def test_two_four_byte_keys(ctx, jt, unique, nulls, filtered):
+    """ON (a, b) = (c, d) over Int32 / Date32 columns (TPC-H Q5's supplier join: suppkey, nationkey).  Build side unique on `a`
+    alone: the join goes by `a` and every match is confirmed on the second column inside the probe kernel; unique as pairs only:
+    both columns packed into one 8-byte key, CAS table; duplicate pairs: the general tables.  A NULL in either part never matches"""
+    rng = np.random.default_rng(3)
+    nl, nr = 700, 6000
+    la, lb = rng.integers(-20, 60, nl).astype(np.int32), rng.integers(9000, 9012, nl).astype(np.int32)
+    if unique == "pairs":
+        pairs = sorted({(int(a), int(b)) for a, b in zip(la, lb)})
+        rng.shuffle(pairs)
+        la, lb = np.array([p[0] for p in pairs], np.int32), np.array([p[1] for p in pairs], np.int32)
+        nl = len(la)
+    if unique == "first_column":
+        la = (rng.permutation(90)[:80] - 22).astype(np.int32)
+        nl = len(la)
+        lb = rng.integers(9000, 9012, nl).astype(np.int32)
+    ra, rb = rng.integers(-25, 65, nr).astype(np.int32), rng.integers(8998, 9014, nr).astype(np.int32)
+    v = lambda n: (rng.random(n) > 0.1) if nulls else None
+    left = OrderedDict([("la", OCol("Int32", la, v(nl))), ("lb", OCol("Date32", lb, v(nl))), ("lx", OCol("Float64", rng.random(nl)))])
+    right = OrderedDict([("ra", OCol("Int32", ra, v(nr))), ("rb", OCol("Date32", rb, v(nr))), ("ry", OCol("Int64", rng.integers(0, 100, nr))),
+                         ("rs", OCol("Utf8", [f"r{i % 7}" for i in range(nr)]))])
+    lm = helpers.memory_exec(ctx, [[left]])
+    rm = helpers.memory_exec(ctx, [[helpers.slice_batch(right, 0, 2500), helpers.slice_batch(right, 2500, nr)]])
+    probe = ba.FilterExec(E.coerce(col("ry") < lit(60), {"ry": "Int64"}), rm) if filtered else rm
+    check(ba.HashJoinExec(lm, probe, [("la", "ra"), ("lb", "rb")], jt), ["la", "lb", "ra", "rb", "ry", "lx"])
+
+
+@pytest.mark.parametrize("jt", JOIN_TYPES)
 def test_probe_side_projection_over_filter(ctx, jt):
     """the Q3 shape: HashJoin(build, Projection(Filter(probe))) with a renamed and a dropped column"""
     left, right = sides(600, 4000, "Int32", True, False, seed=5)
