@@ -368,8 +368,13 @@ int rows_grid(const LaunchCfg& cfg, size_t n) {
 hipError_t launch_join_key_stats(const LaunchCfg& cfg, const void* keys, int key_width, const uint64_t* sel, uint32_t n, uint64_t* stats) {
     if (n == 0) return hipSuccess;
     auto st = reinterpret_cast<unsigned long long*>(stats);
-    if (key_width == 4) hipLaunchKernelGGL(join_key_stats_kernel<4>, dim3(rows_grid(cfg, n)), dim3(BLOCK), 0, cfg.stream, keys, sel, n, st);
-    else hipLaunchKernelGGL(join_key_stats_kernel<8>, dim3(rows_grid(cfg, n)), dim3(BLOCK), 0, cfg.stream, keys, sel, n, st);
+    // every workgroup ends with three atomics on the SAME three words: few, long-running workgroups (4096 of them cost ~0.1 ms of
+    // serialised atomics on a 5 M-row build side)
+    size_t g = ((size_t)n + BLOCK * 8 - 1) / (BLOCK * 8);
+    if (g > (size_t)cfg.device_cus * 2) g = (size_t)cfg.device_cus * 2;
+    const unsigned stats_grid = (unsigned)(g < 1 ? 1 : g);
+    if (key_width == 4) hipLaunchKernelGGL(join_key_stats_kernel<4>, dim3(stats_grid), dim3(BLOCK), 0, cfg.stream, keys, sel, n, st);
+    else hipLaunchKernelGGL(join_key_stats_kernel<8>, dim3(stats_grid), dim3(BLOCK), 0, cfg.stream, keys, sel, n, st);
     return hipGetLastError();
 }
 

@@ -44,8 +44,18 @@ if tr:
             tl.append(f"{(int(r['Start_Timestamp']) - t0) / 1e3:10.1f} | {(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:8.1f} | {r['Kernel_Name'][:100]}")
         open(f"gpurun_out/{q}_step_timeline.txt", "w").write("\n".join(tl) + "\n")
 top = stats[0]["Name"]
-json.dump({"kernel": top, "dispatches": fs.get(top, (0, 0))[1], "avg_ms": float(stats[0]["AverageNs"]) / 1e6,
-           "fetch_size_kb_per_launch": fs.get(top, (0, 0))[0], "write_size_kb_per_launch": ws.get(top, (0, 0))[0],
+# the template instantiations of the dominant kernel count as ONE kernel (bench.py times them under one name): launch-weighted averages
+import re
+base = re.sub(r"<.*", "", top.split("(")[0]).split("::")[-1]
+same = [r for r in stats if base in r["Name"]]
+calls = sum(int(r["Calls"]) for r in same)
+def wavg(m):
+    tot = sum(m.get(r["Name"], (0, 0))[0] * m.get(r["Name"], (0, 0))[1] for r in same)
+    n = sum(m.get(r["Name"], (0, 0))[1] for r in same)
+    return tot / n if n else 0.0
+json.dump({"kernel": base, "variants": [r["Name"][:120] for r in same], "dispatches": calls,
+           "avg_ms": sum(float(r["TotalDurationNs"]) for r in same) / max(calls, 1) / 1e6,
+           "fetch_size_kb_per_launch": wavg(fs), "write_size_kb_per_launch": wavg(ws),
            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; KB = 1024 B; gfx950: FETCH_SIZE x2 for wide streaming reads; "
                    "average over the kernel's launches of the run (a join query launches it once per probe side)",
            "query": q, "rows_per_launch": int(os.environ.get("ROWS", "600037902"))}, open(f"gpurun_out/pmc_traffic_{q}.json", "w"), indent=1)
