@@ -197,6 +197,13 @@ struct Column {
     BufferPtr offsets;     // Utf8
     BufferPtr validity;    // may be null
     int64_t data_bytes = 0;   // Utf8 value bytes
+    // A VIEW (only between a HashJoinExec and the HashJoinExec that asked for it, host/ops_join.cpp): row i is row view_idx[i] of
+    // *view_base, NULL where the index is 0xFFFFFFFF; data / offsets / validity are unset.  take_columns composes the indices, so a
+    // payload column that passes through several joins is gathered ONCE, for the rows that survive them all.
+    std::shared_ptr<const Column> view_base;
+    BufferPtr view_idx;
+    bool view_may_null = false;
+    bool is_view() const { return (bool)view_base; }
     ColumnRef ref() const {
         ColumnRef r;
         r.data = data ? data->ptr() : nullptr;

@@ -100,8 +100,70 @@ static Column take_column_v(const Exec& ex, const Column& c, const uint32_t* idx
 
 // several columns by the same index vector: the fixed-width values and all bitmaps go in ONE launch
 // (a Q1 result batch is 10 columns x 4 rows: ten launches of four threads otherwise); Utf8 columns one by one
-std::vector<Column> take_columns(const Exec& ex, const std::vector<const Column*>& cols, const uint32_t* idx, int64_t n,
-                                 bool may_null, bool permutation) {
+std::vector<Column> take_columns(const Exec& ex, const std::vector<const Column*>& cols_in, const uint32_t* idx, int64_t n,
+                                 bool may_null, bool permutation, bool keep_views) {
+    // ---- views in, views out (host/core.hpp Column::view_base) ------------------------------------------------------------
+    bool any_view = keep_views;
+    for (auto* c : cols_in) any_view = any_view || c->is_view();
+    if (any_view) {
+        std::vector<Column> out(cols_in.size());
+        std::map<const Buffer*, BufferPtr> composed;          // a batch's view columns share their index vector: composed once
+        BufferPtr own_idx;                                     // `idx` as a buffer the new views can keep
+        std::vector<const Column*> plain;
+        std::vector<size_t> plain_pos;
+        std::map<const Buffer*, std::pair<std::vector<const Column*>, std::vector<size_t>>> through;   // bases to gather, by composed index vector
+        std::map<const Buffer*, bool> through_null;
+        for (size_t i = 0; i < cols_in.size(); ++i) {
+            const Column& c = *cols_in[i];
+            if (c.is_view()) {
+                BufferPtr& comp = composed[c.view_idx.get()];
+                if (!comp) {
+                    comp = make_buffer(ex, (size_t)n * 4 + 8);
+                    TIMED_LAUNCH_N(ex, "compose_indices", n, launch_compose_indices(ex.cfg(), c.view_idx->as<uint32_t>(), idx, n, comp->as<uint32_t>()));
+                }
+                if (keep_views) {
+                    Column& o = out[i];
+                    o.dtype = c.dtype;
+                    o.length = n;
+                    o.view_base = c.view_base;
+                    o.view_idx = comp;
+                    o.view_may_null = c.view_may_null || may_null;
+                } else {
+                    auto& grp = through[comp.get()];
+                    grp.first.push_back(c.view_base.get());
+                    grp.second.push_back(i);
+                    through_null[comp.get()] = through_null[comp.get()] || c.view_may_null || may_null;
+                }
+            } else if (keep_views) {
+                if (!own_idx) {
+                    own_idx = make_buffer(ex, (size_t)n * 4 + 8);
+                    if (n) HIP_CHECK(hipMemcpyAsync(own_idx->ptr(), idx, (size_t)n * 4, hipMemcpyDeviceToDevice, ex.stream));
+                }
+                Column& o = out[i];
+                o.dtype = c.dtype;
+                o.length = n;
+                o.view_base = std::make_shared<Column>(c);
+                o.view_idx = own_idx;
+                o.view_may_null = may_null;
+            } else {
+                plain.push_back(&c);
+                plain_pos.push_back(i);
+            }
+        }
+        for (auto& kv : through) {
+            BufferPtr comp;
+            for (auto& cc : composed)
+                if (cc.second.get() == kv.first) comp = cc.second;
+            auto got = take_columns(ex, kv.second.first, comp->as<uint32_t>(), n, through_null[kv.first], false, false);
+            for (size_t k = 0; k < got.size(); ++k) out[kv.second.second[k]] = std::move(got[k]);
+        }
+        if (!plain.empty()) {
+            auto got = take_columns(ex, plain, idx, n, may_null, permutation, false);
+            for (size_t k = 0; k < got.size(); ++k) out[plain_pos[k]] = std::move(got[k]);
+        }
+        return out;
+    }
+    const std::vector<const Column*>& cols = cols_in;
     std::vector<Column> out(cols.size());
     TakeMany tm;
     tm.n = 0;
@@ -148,6 +210,19 @@ BatchPtr take_batch(const Exec& ex, const Batch& in, const uint32_t* idx, int64_
     std::vector<const Column*> cols;
     for (const auto& c : in.cols) cols.push_back(&c);
     out->cols = take_columns(ex, cols, idx, n_out, false, permutation);
+    return out;
+}
+
+Column materialize_column(const Exec& ex, const Column& c) {
+    if (!c.is_view()) return c;
+    return take_column_v(ex, *c.view_base, c.view_idx->as<uint32_t>(), c.length, c.view_may_null);
+}
+BatchPtr materialize_batch(const Exec& ex, const BatchPtr& b) {
+    bool any = false;
+    for (auto& c : b->cols) any = any || c.is_view();
+    if (!any) return b;
+    auto out = std::make_shared<Batch>(*b);
+    for (auto& c : out->cols) c = materialize_column(ex, c);
     return out;
 }
 

@@ -167,17 +167,65 @@ int HashJoinExec::narrow_key_width() const {
     return 0;
 }
 
+// A child of a join, executed so that the columns this join only passes on (everything but its keys) may arrive as views: the
+// child is a HashJoinExec, or a projection of plain columns over one (the shape of TPC-H's join chains).  Anything else: execute().
+static StreamPtr open_join_child(const PlanPtr& child, int partition, const Exec& ex, const std::vector<std::string>& key_names) {
+    static const bool no_views = [] { const char* v = getenv("BHIP_NO_JOIN_VIEWS"); return v && atoi(v) != 0; }();
+    auto is_key = [&](const std::string& n) { return std::find(key_names.begin(), key_names.end(), n) != key_names.end(); };
+    if (no_views) return child->execute(partition, ex);
+    if (auto hj = dynamic_cast<const HashJoinExec*>(child.get())) {
+        const Schema& js = *hj->schema();
+        std::vector<bool> needed(js.fields.size(), true), defer(js.fields.size(), false);
+        for (size_t i = 0; i < js.fields.size(); ++i) defer[i] = !is_key(js.fields[i].name);
+        return hj->execute_needed(partition, ex, needed, defer);
+    }
+    auto pr = dynamic_cast<const ProjectionExec*>(child.get());
+    const HashJoinExec* hj = pr ? dynamic_cast<const HashJoinExec*>(pr->input().get()) : nullptr;
+    if (!hj) return child->execute(partition, ex);
+    const Schema& js = *hj->schema();
+    std::vector<int> src;
+    for (auto& en : pr->exprs()) {
+        if (en.first->kind != BHIP_EXPR_COLUMN) return child->execute(partition, ex);
+        const int i = js.index_of(en.first->name);
+        if (i < 0) return child->execute(partition, ex);
+        src.push_back(i);
+    }
+    std::vector<bool> needed(js.fields.size(), false), defer(js.fields.size(), true);
+    for (size_t k = 0; k < src.size(); ++k) {
+        needed[src[k]] = true;
+        if (is_key(pr->exprs()[k].second)) defer[src[k]] = false;          // a key of the parent join (possibly under another output name too)
+    }
+    std::shared_ptr<RecordBatchStream> inner(hj->execute_needed(partition, ex, needed, defer).release());
+    const SchemaPtr sch = pr->schema();
+    return StreamPtr(new LazyStream(sch, [inner, sch, src]() {
+        std::vector<BatchPtr> out;
+        while (BatchPtr b = inner->next()) {
+            auto nb = std::make_shared<Batch>();
+            nb->schema = sch;
+            nb->ctx = b->ctx;
+            nb->n_rows = b->n_rows;
+            for (int i : src) nb->cols.push_back(b->cols[i]);
+            out.push_back(nb);
+        }
+        return out;
+    }));
+}
+
 std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) const {
     std::lock_guard<std::mutex> g(cache_->mu);
     if (cache_->built) return cache_->built;
     auto bs = std::make_shared<JoinBuildSide>();
     std::vector<BatchPtr> parts;
     const int np = left_->output_partitioning().count;
+    std::vector<std::string> left_keys;
+    for (auto& p : on_) left_keys.push_back(p.first);
     for (int p = 0; p < np; ++p) {
-        auto s = left_->execute(p, ex);
+        auto s = open_join_child(left_, p, ex, left_keys);
         while (BatchPtr b = s->next())
             if (b->n_rows > 0) parts.push_back(b);
     }
+    if (parts.size() > 1)
+        for (auto& b : parts) b = materialize_batch(ex, b);       // concat works on ordinary columns
     if (parts.empty()) {
         auto e = std::make_shared<Batch>();
         e->schema = left_->schema();
@@ -452,12 +500,13 @@ StreamPtr HashJoinExec::execute(int partition, const Exec& ex) const {
     return execute_needed(partition, ex, std::vector<bool>(schema_->fields.size(), true));
 }
 
-StreamPtr HashJoinExec::execute_needed(int partition, const Exec& ex, const std::vector<bool>& needed_in) const {
+StreamPtr HashJoinExec::execute_needed(int partition, const Exec& ex, const std::vector<bool>& needed_in, const std::vector<bool>& deferrable_in) const {
     check_partition(*this, partition);
     auto self = std::static_pointer_cast<const HashJoinExec>(shared_from_this());
-    std::vector<bool> needed = needed_in;
+    std::vector<bool> needed = needed_in, deferrable = deferrable_in;
     needed.resize(schema_->fields.size(), true);
-    return StreamPtr(new LazyStream(schema_, [self, partition, ex, needed]() {
+    deferrable.resize(schema_->fields.size(), false);
+    return StreamPtr(new LazyStream(schema_, [self, partition, ex, needed, deferrable]() {
         std::vector<BatchPtr> out;
         auto bs = self->build_side(ex);
         const Batch& L = *bs->batch;
@@ -485,28 +534,32 @@ StreamPtr HashJoinExec::execute_needed(int partition, const Exec& ex, const std:
             b->n_rows = n_out;
             b->cols.resize(self->schema_->fields.size());
             for (size_t i = 0; i < b->cols.size(); ++i) { b->cols[i].dtype = self->schema_->fields[i].dtype; b->cols[i].length = n_out; }
-            std::vector<const Column*> lc, rc;
-            std::vector<size_t> lpos, rpos;
+            // [0]: gathered now; [1]: handed on as views (the parent asked for them that way; a column that arrives as a view is
+            // composed with this join's indices either way)
+            std::vector<const Column*> lc[2], rc[2];
+            std::vector<size_t> lpos[2], rpos[2];
             for (size_t i = 0; i < n_lcols; ++i)
-                if (needed[i]) { lc.push_back(&L.cols[i]); lpos.push_back(i); }
-            if (!lc.empty()) {
+                if (needed[i]) { lc[deferrable[i] ? 1 : 0].push_back(&L.cols[i]); lpos[deferrable[i] ? 1 : 0].push_back(i); }
+            for (int v = 0; v < 2; ++v) {
+                if (lc[v].empty()) continue;
                 if (lidx) {
-                    auto got = take_columns(ex, lc, lidx, n_out, right_outer);
-                    for (size_t k = 0; k < got.size(); ++k) b->cols[lpos[k]] = std::move(got[k]);
+                    auto got = take_columns(ex, lc[v], lidx, n_out, right_outer, false, v == 1);
+                    for (size_t k = 0; k < got.size(); ++k) b->cols[lpos[v][k]] = std::move(got[k]);
                 } else {
-                    for (size_t k = 0; k < lc.size(); ++k) b->cols[lpos[k]] = null_column(ex, lc[k]->dtype, n_out);
+                    for (size_t k = 0; k < lc[v].size(); ++k) b->cols[lpos[v][k]] = null_column(ex, lc[v][k]->dtype, n_out);
                 }
             }
             for (size_t k = 0; k < self->right_cols_.size(); ++k) {
                 const size_t oi = n_lcols + k;
                 if (!needed[oi]) continue;
                 if (!R) { b->cols[oi] = null_column(ex, self->schema_->fields[oi].dtype, n_out); continue; }
-                rc.push_back(&R->cols[rmap ? (*rmap)[k] : self->right_cols_[k]]);
-                rpos.push_back(oi);
+                rc[deferrable[oi] ? 1 : 0].push_back(&R->cols[rmap ? (*rmap)[k] : self->right_cols_[k]]);
+                rpos[deferrable[oi] ? 1 : 0].push_back(oi);
             }
-            if (!rc.empty()) {
-                auto got = take_columns(ex, rc, ridx, n_out, left_outer);
-                for (size_t k = 0; k < got.size(); ++k) b->cols[rpos[k]] = std::move(got[k]);
+            for (int v = 0; v < 2; ++v) {
+                if (rc[v].empty()) continue;
+                auto got = take_columns(ex, rc[v], ridx, n_out, left_outer, false, v == 1);
+                for (size_t k = 0; k < got.size(); ++k) b->cols[rpos[v][k]] = std::move(got[k]);
             }
             out.push_back(b);
         };
@@ -721,7 +774,7 @@ StreamPtr HashJoinExec::execute_needed(int partition, const Exec& ex, const std:
                 else process(*kb, b.get(), &rmap, remap);
             }
         } else {
-            auto rs = self->right_->execute(partition, ex);
+            auto rs = open_join_child(self->right_, partition, ex, rcols);          // payload columns of a join below may arrive as views
             while (BatchPtr rb = rs->next()) {
                 if (bs->narrow && pair) {
                     const ProbeKey pk = probe_key(rb->cols[rb->schema->index_of(rcols[0])], rb->cols[rb->schema->index_of(rcols[1])], rb->n_rows);

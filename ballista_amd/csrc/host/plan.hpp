@@ -231,7 +231,9 @@ public:
     // the same stream with only the output columns a parent reads materialised (needed[i]: column i of schema()); the other
     // columns of the batches are placeholders without buffers.  Called by ProjectionExec / HashAggregateExec above a join
     // (the reference's join copies every column of both sides and the parent then drops most of them).
-    StreamPtr execute_needed(int partition, const Exec& ex, const std::vector<bool>& needed) const;
+    // needed[i]: a parent reads output column i (others stay placeholders).  deferrable[i]: the parent only hands column i on to
+    // take_columns (another HashJoinExec passing a payload column through): it may come back as a VIEW (core.hpp Column::view_base)
+    StreamPtr execute_needed(int partition, const Exec& ex, const std::vector<bool>& needed, const std::vector<bool>& deferrable = {}) const;
     std::string describe() const override;
 private:
     std::shared_ptr<const JoinBuildSide> build_side(const Exec& ex) const;
@@ -320,7 +322,10 @@ BatchPtr project_batch(const Exec& ex, const Batch& in, const std::vector<std::p
 Column take_batch_column(const Exec& ex, const Column& c, const uint32_t* idx, int64_t n);
 // columns gathered by one index vector; may_null: the indices may hold 0xFFFFFFFF (outer joins) -> validity always built
 std::vector<Column> take_columns(const Exec& ex, const std::vector<const Column*>& cols, const uint32_t* idx, int64_t n,
-                                 bool may_null, bool permutation = false);
+                                 bool may_null, bool permutation = false, bool keep_views = false);
+// view columns (core.hpp Column::view_base) as ordinary columns
+Column materialize_column(const Exec& ex, const Column& c);
+BatchPtr materialize_batch(const Exec& ex, const BatchPtr& b);
 // n NULLs of the given type
 Column null_column(const Exec& ex, int dtype, int64_t n);
 // gather where indices may hold 0xFFFFFFFF (= NULL row): always carries a validity bitmap

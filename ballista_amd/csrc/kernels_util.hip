@@ -344,6 +344,15 @@ take_utf8_copy_kernel(const int32_t* src_off, const uint8_t* src, int64_t src_by
     }
 }
 
+// out[i] = inner[idx[i]], NULL_INDEX where idx[i] is NULL_INDEX (indices of a view column seen through another gather)
+__global__ void __launch_bounds__(BLOCK)
+compose_indices_kernel(const uint32_t* inner, const uint32_t* idx, int64_t n, uint32_t* out) {
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+        const uint32_t j = idx[i];
+        out[i] = j == NULL_INDEX ? NULL_INDEX : inner[j];
+    }
+}
+
 static int grid_for(const LaunchCfg& cfg, int64_t n, int per_thread = 1) {
     int64_t g = (n + (int64_t)BLOCK * per_thread - 1) / ((int64_t)BLOCK * per_thread);
     const int64_t cap = (int64_t)cfg.device_cus * 16;
@@ -369,6 +378,11 @@ hipError_t launch_take_fixed(const LaunchCfg& cfg, const void* src, int width, c
     return hipGetLastError();
 }
 
+hipError_t launch_compose_indices(const LaunchCfg& cfg, const uint32_t* inner, const uint32_t* idx, int64_t n, uint32_t* out) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(compose_indices_kernel, dim3(grid_for(cfg, n)), dim3(BLOCK), 0, cfg.stream, inner, idx, n, out);
+    return hipGetLastError();
+}
 hipError_t launch_take_many(const LaunchCfg& cfg, const TakeMany& d, const uint32_t* idx, int64_t n) {
     if (n == 0 || d.n == 0) return hipSuccess;
     hipLaunchKernelGGL(take_many_kernel, dim3(grid_for(cfg, n), d.n), dim3(BLOCK), 0, cfg.stream, d, idx, n);

@@ -90,6 +90,37 @@ def test_two_four_byte_keys(ctx, jt, unique, nulls, filtered):
     check(ba.HashJoinExec(lm, probe, [("la", "ra"), ("lb", "rb")], jt), ["la", "lb", "ra", "rb", "ry", "lx"])
 
 
+@pytest.mark.parametrize("jt_top", JOIN_TYPES)
+@pytest.mark.parametrize("jt_mid", JOIN_TYPES)
+@pytest.mark.parametrize("shape", ["probe_chain", "build_chain"])
+def test_payload_columns_pass_through_joins_as_views(ctx, jt_top, jt_mid, shape):
+    """three joins in a row with column projections between them (the shape of TPC-H Q3 / Q5): a column a join only passes on
+    travels as (source column, row indices) and is gathered once, by the last join — through Inner / Left / Right joins (NULL
+    partners), Utf8 / Boolean / nullable payloads, on the build and on the probe side of the next join"""
+    rng = np.random.default_rng(5)
+    na, nb, nc, nd = 60, 900, 4000, 300
+    a = OrderedDict([("ak", OCol("Int32", np.arange(na, dtype=np.int32))), ("aname", OCol("Utf8", [f"name-{i % 13}" for i in range(na)], rng.random(na) > 0.1))])
+    b = OrderedDict([("bk", OCol("Int32", np.arange(nb, dtype=np.int32) + 5)), ("b_ak", OCol("Int32", rng.integers(-3, na + 3, nb).astype(np.int32), rng.random(nb) > 0.05)),
+                     ("bflag", OCol("Boolean", rng.random(nb) > 0.5, rng.random(nb) > 0.2))])
+    c = OrderedDict([("c_bk", OCol("Int32", rng.integers(0, nb + 20, nc).astype(np.int32))), ("cx", OCol("Float64", rng.random(nc), rng.random(nc) > 0.1)),
+                     ("cs", OCol("Utf8", [f"c{i % 29}" for i in range(nc)])), ("c_dk", OCol("Int32", rng.integers(0, nd + 10, nc).astype(np.int32)))])
+    d = OrderedDict([("dk", OCol("Int32", np.arange(nd, dtype=np.int32))), ("dy", OCol("Int64", rng.integers(0, 1000, nd)))])
+    A, B, C, D = (helpers.memory_exec(ctx, [[t]]) for t in (a, b, c, d))
+    proj = lambda names, p: ba.ProjectionExec([(col(n), n) for n in names], p)
+    j1 = proj(["bk", "aname", "bflag"], ba.HashJoinExec(A, B, [("ak", "b_ak")], jt_mid))              # a |x| b
+    if shape == "probe_chain":
+        j2 = proj(["aname", "bflag", "cx", "cs", "c_dk"], ba.HashJoinExec(j1, C, [("bk", "c_bk")], jt_mid))    # (a b) |x| c: j1 is the BUILD side
+        top = ba.HashJoinExec(D, j2, [("dk", "c_dk")], jt_top)                                          # d |x| (a b c): j2 is the PROBE side
+        keys = ["dk", "c_dk", "cx", "cs", "aname"]
+    else:
+        j2 = proj(["c_dk", "aname", "cx", "bflag"], ba.HashJoinExec(j1, C, [("bk", "c_bk")], jt_mid))
+        top = ba.HashJoinExec(j2, D, [("c_dk", "dk")], jt_top)                                          # (a b c) |x| d: j2 is the BUILD side
+        keys = ["c_dk", "dk", "cx", "aname", "dy"]
+    check(top, keys)
+    agg = ba.HashAggregateExec(ba.plan.PARTIAL, [(col("aname"), "aname")], [E.Sum(col("cx"), "s"), E.Count(col("bflag"), "c")], top)
+    helpers.assert_rows_equal(helpers.concat(helpers.collect_product(agg)), plan_eval.collect(agg), ordered=False, float_rtol=1e-9, key_cols=["aname"])
+
+
 @pytest.mark.parametrize("jt", JOIN_TYPES)
 def test_probe_side_projection_over_filter(ctx, jt):
     """the Q3 shape: HashJoin(build, Projection(Filter(probe))) with a renamed and a dropped column"""
