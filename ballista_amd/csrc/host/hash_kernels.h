@@ -149,13 +149,13 @@ struct ProbeFilter {
 };
 hipError_t launch_join_filter_probe(const LaunchCfg& cfg, const NarrowJoinTable& T, const ProbeFilter& F, const void* rkeys, int key_width,
                                     const uint64_t* rsel, uint32_t n_right, bool right_outer, uint64_t* bitmap, uint32_t* tile_counts,
-                                    uint32_t* staging, uint32_t* matched, const uint32_t* resid_probe = nullptr);
+                                    uint32_t* staging, uint32_t* matched, const uint32_t* resid_probe = nullptr, uint32_t* staging_rows = nullptr);
 hipError_t launch_and_bitmaps(const LaunchCfg& cfg, const uint64_t* a, const uint64_t* b, int64_t n_bits, uint64_t* out);
 // out[i] = a[i] << 32 | b[i] (4-byte integer columns); validity_out (when not null) = va & vb (a null input bitmap = all valid)
 hipError_t launch_pack_key_pair(const LaunchCfg& cfg, const void* a, const void* b, const uint64_t* va, const uint64_t* vb, int64_t n, uint64_t* out,
                                 uint64_t* validity_out);
 hipError_t launch_join_compact_staged(const LaunchCfg& cfg, const uint32_t* staging, const uint64_t* tile_off, uint64_t total,
-                                      int64_t n_tiles, uint32_t* out);
+                                      int64_t n_tiles, uint32_t* out, const uint32_t* staging2 = nullptr, uint32_t* out2 = nullptr);
 // ---- radix-partitioned join with LDS-resident tables (kernels_radix_join.hip): the measured alternative, BHIP_JOIN_RADIX=1 ----
 // sort keys (partition id << 32) | key + row ids; partition bounds of a sorted side; the per-partition LDS build + probe.
 // flags[0] != 0: a build partition outgrew the LDS table; flags[1] != 0: duplicate build keys.

@@ -10,6 +10,7 @@
 // execute() folds the FilterExec / CoalesceBatchesExec / ProjectionExec chain below the
 // aggregate into the aggregate's own kernel (predicate fused, projection expressions
 // substituted), i.e. the whole of TPC-H Q1/Q6 stage 1 is one kernel launch per input batch.
+#include "../sort_kernels.h"
 #include "../util_kernels.h"
 #include "hash_kernels.h"
 #include "plan.hpp"
@@ -484,6 +485,24 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
     for (auto& b : inputs) {
         if (use_lean && !(sop_columns_bindable(sop, *b, true) && lean_bindable(sop, *b))) use_lean = false;
         if (use_sop && !sop_columns_bindable(sop, *b)) use_sop = false;
+    }
+    // A Utf8 key longer than the fast paths hold (3 bytes wide-load, 7 bytes register kernel) sends them back empty-handed after a
+    // whole pass over the input each.  Short codes (Q1's flags: 1 byte on average) are taken on trust; a key column that averages
+    // more than 2 bytes per value has the longest string of its leading 64 Ki rows measured first (one small launch).
+    if ((use_lean || use_sop) && !inputs.empty() && inputs[0]->n_rows >= (1 << 17)) {
+        const Batch& b0 = *inputs[0];
+        uint32_t longest = 0;
+        for (auto& g : f.group) {
+            if (g->kind != BHIP_EXPR_COLUMN) continue;
+            const int ci = src_schema.index_of(g->name);
+            if (ci < 0 || b0.cols[ci].dtype != DT_UTF8 || b0.cols[ci].data_bytes <= 2 * b0.n_rows) continue;
+            Temp t2(ex);
+            uint32_t* dev = t2.get<uint32_t>(1);
+            TIMED_LAUNCH(ex, "utf8_max_len", launch_utf8_max_len(ex.cfg(), b0.cols[ci].offsets->as<int32_t>(), std::min<int64_t>(b0.n_rows, 65536), dev));
+            longest = std::max(longest, read_device(ex, dev));
+        }
+        if (longest > 3) use_lean = false;
+        if (longest > 7) use_sop = false;
     }
     bool sop_layout = false;             // the pass that produced `table` packed keys the fast path's way
 

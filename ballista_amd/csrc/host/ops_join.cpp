@@ -634,19 +634,22 @@ StreamPtr HashJoinExec::execute_needed(int partition, const Exec& ex, const std:
             uint64_t* total = tmp.get<uint64_t>(1);
             void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes(n_tiles));
             uint32_t* staging = need_left ? tmp.get<uint32_t>((size_t)n_tiles * SEL_TILE) : nullptr;
+            // the emitted rows are staged per tile like their partners: the compaction below yields both index vectors, no pass over
+            // the selection bitmap (a semi-join — no build column read — has nothing else to compact and takes the bitmap route)
+            uint32_t* staging_rows = need_left ? tmp.get<uint32_t>((size_t)n_tiles * SEL_TILE) : nullptr;
             // algorithmic bytes: the predicate columns and the key column once, one selection bit per row
             TIMED_LAUNCH_B(ex, "join_filter_probe", n, (uint64_t)n * (uint64_t)(bs->narrow_width + 4 * F.n) + (uint64_t)n / 8,
                            launch_join_filter_probe(cfg, bs->ntable, F, kc.data->ptr(), bs->narrow_width,
                                                     kc.validity ? kc.validity->as<uint64_t>() : nullptr, (uint32_t)n, right_outer, bitmap,
                                                     tile_counts, staging, left_outer ? matched->as<uint32_t>() : nullptr,
-                                                    resid ? resid->data->as<uint32_t>() : nullptr));
+                                                    resid ? resid->data->as<uint32_t>() : nullptr, staging_rows));
             HIP_CHECK(exclusive_scan_u32_u64(ex.stream, tile_counts, n_tiles, tile_off, false, total, scan_tmp));
             const uint64_t n_out = read_device(ex, total);
             if (n_out == 0) return;
             uint32_t* ridx = tmp.get<uint32_t>((size_t)n_out);
             uint32_t* lidx = need_left ? tmp.get<uint32_t>((size_t)n_out) : nullptr;
-            TIMED_LAUNCH_N(ex, "select_indices", n, launch_select_indices(cfg, bitmap, tile_off, n, ridx));
-            if (need_left) TIMED_LAUNCH_N(ex, "join_compact_staged", n, launch_join_compact_staged(cfg, staging, tile_off, n_out, n_tiles, lidx));
+            if (need_left) TIMED_LAUNCH_N(ex, "join_compact_staged", n, launch_join_compact_staged(cfg, staging, tile_off, n_out, n_tiles, lidx, staging_rows, ridx));
+            else TIMED_LAUNCH_N(ex, "select_indices", n, launch_select_indices(cfg, bitmap, tile_off, n, ridx));
             if (remap) {
                 uint32_t* orig = tmp.get<uint32_t>((size_t)n_out);
                 TIMED_LAUNCH_N(ex, "take_fixed", n_out, launch_take_fixed(cfg, remap, 4, ridx, (int64_t)n_out, orig));

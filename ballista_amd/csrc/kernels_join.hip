@@ -196,7 +196,8 @@ template <int KW, int NF, int FP_ROWS, bool RESID>
 __global__ void __launch_bounds__(BLOCK)
 join_filter_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void* __restrict__ rkeys_v, const uint64_t* __restrict__ rsel,
                          uint32_t n_right, int right_outer, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts,
-                         uint32_t* __restrict__ staging, uint32_t* matched, const uint32_t* __restrict__ resid_probe) {
+                         uint32_t* __restrict__ staging, uint32_t* matched, const uint32_t* __restrict__ resid_probe,
+                         uint32_t* __restrict__ staging_rows) {
     using K = typename KeyT<KW>::type;
     constexpr int NFR = NF > 0 ? NF : 1;
     constexpr int FP_CHUNK = 64 * FP_ROWS;           // rows of one pass of a wave
@@ -319,7 +320,11 @@ join_filter_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const voi
                 const uint64_t wd = __ballot(emit);
                 // (bitmap words past the last row's word exist: the bitmap is allocated for whole tiles)
                 if (lane == 0) bitmap[(base >> 6) + k] = wd;
-                if (emit && staging) staging[tile_base + tile_cnt + (uint32_t)__popcll(wd & lane_lt)] = m[k];
+                if (emit && (staging || staging_rows)) {
+                    const uint32_t at = tile_base + tile_cnt + (uint32_t)__popcll(wd & lane_lt);
+                    if (staging) staging[at] = m[k];
+                    if (staging_rows) staging_rows[at] = base + 64u * k + lane;            // the emitted row itself: no bitmap -> index pass later
+                }
                 tile_cnt += (uint32_t)__popcll(wd);
             }
             cur = nxt;
@@ -331,7 +336,7 @@ join_filter_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const voi
 // out[tile_off[t] + j] = staging[t * 1024 + j] for the tile's first (tile_off[t + 1] - tile_off[t]) entries
 __global__ void __launch_bounds__(BLOCK)
 join_compact_staged_kernel(const uint32_t* __restrict__ staging, const uint64_t* __restrict__ tile_off, uint64_t total, uint32_t n_tiles,
-                           uint32_t* __restrict__ out) {
+                           uint32_t* __restrict__ out, const uint32_t* __restrict__ staging2, uint32_t* __restrict__ out2) {
     const int lane = threadIdx.x & 63;
     const uint32_t wave_id = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (BLOCK / 64);
@@ -339,7 +344,10 @@ join_compact_staged_kernel(const uint32_t* __restrict__ staging, const uint64_t*
         const uint64_t off = tile_off[t];
         const uint64_t end = t + 1 < n_tiles ? tile_off[t + 1] : total;
         const uint32_t cnt = (uint32_t)(end - off);
-        for (uint32_t j = lane; j < cnt; j += 64) out[off + j] = staging[(uint64_t)t * SEL_TILE + j];
+        for (uint32_t j = lane; j < cnt; j += 64) {
+            if (staging) out[off + j] = staging[(uint64_t)t * SEL_TILE + j];
+            if (staging2) out2[off + j] = staging2[(uint64_t)t * SEL_TILE + j];
+        }
     }
 }
 
@@ -410,7 +418,7 @@ hipError_t launch_rank_perm(const LaunchCfg& cfg, const void* keys, int key_widt
 
 hipError_t launch_join_filter_probe(const LaunchCfg& cfg, const NarrowJoinTable& T, const ProbeFilter& F, const void* rkeys, int key_width,
                                     const uint64_t* rsel, uint32_t n_right, bool right_outer, uint64_t* bitmap, uint32_t* tile_counts,
-                                    uint32_t* staging, uint32_t* matched, const uint32_t* resid_probe) {
+                                    uint32_t* staging, uint32_t* matched, const uint32_t* resid_probe, uint32_t* staging_rows) {
     if (n_right == 0) return hipSuccess;
     if ((resid_probe != nullptr) != (T.resid_build != nullptr)) return hipErrorInvalidValue;
     const int64_t n_tiles = ((int64_t)n_right + SEL_TILE - 1) / SEL_TILE;
@@ -423,10 +431,10 @@ hipError_t launch_join_filter_probe(const LaunchCfg& cfg, const NarrowJoinTable&
     do {                                                                                                                              \
         if (resid_probe)                                                                                                              \
             hipLaunchKernelGGL((join_filter_probe_kernel<KW_, NF_, 4, true>), dim3((unsigned)grid), dim3(BLOCK), 0, cfg.stream, T, F, rkeys,  \
-                               rsel, n_right, right_outer ? 1 : 0, bitmap, tile_counts, staging, matched, resid_probe);               \
+                               rsel, n_right, right_outer ? 1 : 0, bitmap, tile_counts, staging, matched, resid_probe, staging_rows); \
         else                                                                                                                          \
             hipLaunchKernelGGL((join_filter_probe_kernel<KW_, NF_, 4, false>), dim3((unsigned)grid), dim3(BLOCK), 0, cfg.stream, T, F, rkeys, \
-                               rsel, n_right, right_outer ? 1 : 0, bitmap, tile_counts, staging, matched, resid_probe);               \
+                               rsel, n_right, right_outer ? 1 : 0, bitmap, tile_counts, staging, matched, resid_probe, staging_rows); \
     } while (0)
     if (key_width == 4) {
         if (F.n == 0) BHIP_PROBE(4, 0);
@@ -457,13 +465,13 @@ hipError_t launch_pack_key_pair(const LaunchCfg& cfg, const void* a, const void*
 }
 
 hipError_t launch_join_compact_staged(const LaunchCfg& cfg, const uint32_t* staging, const uint64_t* tile_off, uint64_t total,
-                                      int64_t n_tiles, uint32_t* out) {
+                                      int64_t n_tiles, uint32_t* out, const uint32_t* staging2, uint32_t* out2) {
     if (n_tiles == 0 || total == 0) return hipSuccess;
     int64_t grid = (int64_t)cfg.device_cus * 8;
     const int64_t need = (n_tiles + BLOCK / 64 - 1) / (BLOCK / 64);
     if (grid > need) grid = need;
     hipLaunchKernelGGL(join_compact_staged_kernel, dim3((unsigned)grid), dim3(BLOCK), 0, cfg.stream, staging, tile_off, total,
-                       (uint32_t)n_tiles, out);
+                       (uint32_t)n_tiles, out, staging2, out2);
     return hipGetLastError();
 }
 
