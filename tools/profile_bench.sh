@@ -46,7 +46,7 @@ if tr:
 top = stats[0]["Name"]
 # the template instantiations of the dominant kernel count as ONE kernel (bench.py times them under one name): launch-weighted averages
 import re
-base = re.sub(r"<.*", "", top.split("(")[0]).split("::")[-1]
+base = re.split(r"[<(]", top.replace("(anonymous namespace)::", ""))[0].split("::")[-1].split()[-1]
 same = [r for r in stats if base in r["Name"]]
 calls = sum(int(r["Calls"]) for r in same)
 def wavg(m):
