@@ -645,7 +645,7 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
     for (auto& b : inputs) total_in += b->n_rows;
     // (not for the wide-load path: its plans have at most two 32-bit key parts — flags, short codes — and its launches are the
     // ones the bench's roofline line and the rocprofv3 averages are about)
-    if (hint == 0 && gmax > 0 && !group_.empty() && total_in >= (1 << 20) && !use_lean) {
+    if (hint == 0 && gmax > 0 && !group_.empty() && total_in >= (1 << 17) && !use_lean) {
         auto head = std::make_shared<Batch>(*inputs[0]);
         head->n_rows = std::min<int64_t>(head->n_rows, 32768);
         sample.push_back(head);

@@ -192,7 +192,9 @@ struct WaveScratchT {
 // as vector instructions on them (rocprofv3 SQ_INSTS_SALU 293 M vs SQ_INSTS_VALU 275 M per launch, profiles/r02_probe_variants_q3_sf100.txt).
 // RESID: a second 4-byte key column on both sides (ON a = c AND b = d with the build side unique on `a` alone): the lookup goes by
 // the first key, a match stands only if the second keys are equal too (T.resid_build[build row] vs the probe row's value).
-template <int KW, int NF, int FP_ROWS, bool RESID>
+// FAST: the common configuration fixed at compile time — rank map, no NULL keys on the probe side, not a left join — so that the
+// per-row-slot tests of those run-time options (wave-uniform branches around every load) disappear from the loop
+template <int KW, int NF, int FP_ROWS, bool RESID, bool FAST>
 __global__ void __launch_bounds__(BLOCK)
 join_filter_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void* __restrict__ rkeys_v, const uint64_t* __restrict__ rsel,
                          uint32_t n_right, int right_outer, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts,
@@ -212,8 +214,9 @@ join_filter_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const voi
     const uint32_t last_row = n_right - 1;
     const uint32_t wave_id = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (BLOCK / 64);
-    const bool ranked = T.rbits != nullptr;
-    const bool key_set = ranked || T.present != nullptr;
+    const bool ranked = FAST || T.rbits != nullptr;
+    const bool key_set = FAST || ranked || T.present != nullptr;
+    if (FAST) { rsel = nullptr; matched = nullptr; }
 
     // the streamed inputs of one pass; the NEXT pass's are loaded before this pass walks its dependent reads.
     // Rows are 32-bit (a batch holds < 2^32 - 16 rows and a pass starts at a multiple of 256: base + 255 does not wrap).
@@ -256,7 +259,7 @@ join_filter_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const voi
                 pass[k] = p;
                 m[k] = 0xFFFFFFFFu;
                 live[k] = p;
-                if (rsel != nullptr) {                                     // NULL keys never match (wave-uniform test of the pointer)
+                if (!FAST && rsel != nullptr) {                            // NULL keys never match (wave-uniform test of the pointer)
                     const uint32_t rc = row < last_row ? row : last_row;
                     live[k] = live[k] && ((rsel[rc >> 6] >> (rc & 63)) & 1ull);
                 }
@@ -296,7 +299,7 @@ join_filter_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const voi
                     uint32_t r;
                     if (ranked) {
                         r = T.rprefix[S.a[j]] + S.b[j];
-                        if (T.rperm) r = T.rperm[r];
+                        if (T.rperm) r = T.rperm[r];                      // (unsorted build side; a uniform test once per lookup round)
                     } else {
                         r = table_lookup<KW>(T, (K)S.a[j]);
                     }
@@ -427,14 +430,14 @@ hipError_t launch_join_filter_probe(const LaunchCfg& cfg, const NarrowJoinTable&
     const int64_t need = (n_tiles + BLOCK / 64 - 1) / (BLOCK / 64);
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;
+    const bool fast = T.rbits != nullptr && rsel == nullptr && matched == nullptr;
+#define BHIP_PROBE_L(KW_, NF_, RESID_, FAST_)                                                                                         \
+    hipLaunchKernelGGL((join_filter_probe_kernel<KW_, NF_, 4, RESID_, FAST_>), dim3((unsigned)grid), dim3(BLOCK), 0, cfg.stream, T, F, rkeys,  \
+                       rsel, n_right, right_outer ? 1 : 0, bitmap, tile_counts, staging, matched, resid_probe, staging_rows)
 #define BHIP_PROBE(KW_, NF_)                                                                                                          \
     do {                                                                                                                              \
-        if (resid_probe)                                                                                                              \
-            hipLaunchKernelGGL((join_filter_probe_kernel<KW_, NF_, 4, true>), dim3((unsigned)grid), dim3(BLOCK), 0, cfg.stream, T, F, rkeys,  \
-                               rsel, n_right, right_outer ? 1 : 0, bitmap, tile_counts, staging, matched, resid_probe, staging_rows); \
-        else                                                                                                                          \
-            hipLaunchKernelGGL((join_filter_probe_kernel<KW_, NF_, 4, false>), dim3((unsigned)grid), dim3(BLOCK), 0, cfg.stream, T, F, rkeys, \
-                               rsel, n_right, right_outer ? 1 : 0, bitmap, tile_counts, staging, matched, resid_probe, staging_rows); \
+        if (resid_probe) { if (fast) BHIP_PROBE_L(KW_, NF_, true, true); else BHIP_PROBE_L(KW_, NF_, true, false); }                  \
+        else { if (fast) BHIP_PROBE_L(KW_, NF_, false, true); else BHIP_PROBE_L(KW_, NF_, false, false); }                            \
     } while (0)
     if (key_width == 4) {
         if (F.n == 0) BHIP_PROBE(4, 0);
@@ -446,6 +449,7 @@ hipError_t launch_join_filter_probe(const LaunchCfg& cfg, const NarrowJoinTable&
         else BHIP_PROBE(8, JOIN_FILTER_MAX);
     }
 #undef BHIP_PROBE
+#undef BHIP_PROBE_L
     return hipGetLastError();
 }
 
