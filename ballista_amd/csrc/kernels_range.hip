@@ -61,27 +61,27 @@ range_bitmap_kernel(const SopProgram* __restrict__ Sp, uint64_t* bitmap, uint32_
 
     // TPI consecutive tiles per pass: every load of the pass is issued before the first comparison (a predicate over one
     // 4-byte column has only two 8-byte loads per thread and tile, too little in flight to cover HBM latency)
-    auto tiles = [&](auto tpi_c, const int64_t t0) {
-        constexpr int TPI = decltype(tpi_c)::value;
-        LeanU4 rv[TPI][NRANGE][U];
+    // the loads of one tile
+    auto load_tile = [&](const int64_t t, LeanU4 (&dst)[NRANGE][U]) {
+        const int64_t row0 = t * RB_TILE;
 #pragma unroll
-        for (int q = 0; q < TPI; ++q) {
-            const int64_t row0 = (t0 + q) * RB_TILE;
+        for (int p = 0; p < NRANGE; ++p)
+            if (p < n_ranges) {
+                if (r32[p]) {
 #pragma unroll
-            for (int p = 0; p < NRANGE; ++p)
-                if (p < n_ranges) {
-                    if (r32[p]) {
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            const LeanU2 v = lean_ld2(rp[p] + row0 * 4 + u * (RB_SUB * 4) + t8);
-                            rv[q][p][u].x = v.x; rv[q][p][u].y = v.y; rv[q][p][u].z = 0; rv[q][p][u].w = 0;
-                        }
-                    } else {
-#pragma unroll
-                        for (int u = 0; u < U; ++u) rv[q][p][u] = lean_ld4(rp[p] + row0 * 8 + u * (RB_SUB * 8) + t16);
+                    for (int u = 0; u < U; ++u) {
+                        const LeanU2 v = lean_ld2(rp[p] + row0 * 4 + u * (RB_SUB * 4) + t8);
+                        dst[p][u].x = v.x; dst[p][u].y = v.y; dst[p][u].z = 0; dst[p][u].w = 0;
                     }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) dst[p][u] = lean_ld4(rp[p] + row0 * 8 + u * (RB_SUB * 8) + t16);
                 }
-        }
+            }
+    };
+    // TPI consecutive tiles per pass, already loaded into rv
+    auto tiles = [&](auto tpi_c, const int64_t t0, LeanU4 (&rv)[decltype(tpi_c)::value][NRANGE][U]) {
+        constexpr int TPI = decltype(tpi_c)::value;
 #pragma unroll
         for (int q = 0; q < TPI; ++q) {
             const int64_t t = t0 + q;
@@ -135,11 +135,36 @@ range_bitmap_kernel(const SopProgram* __restrict__ Sp, uint64_t* bitmap, uint32_
             if (lane == 0 && cnt) atomicAdd(&tile_counts[t], cnt);
         }
     };
-    constexpr int TPI_MAIN = NRANGE == 1 ? 4 : 1;
-    const int64_t n_packs = n_tiles / TPI_MAIN;                       // packs of TPI_MAIN full tiles, then the full tiles left over
-    for (int64_t g = blockIdx.x; g < n_packs; g += grid) tiles(std::integral_constant<int, TPI_MAIN>{}, g * TPI_MAIN);
-    if (TPI_MAIN > 1)
-        for (int64_t t = n_packs * TPI_MAIN + blockIdx.x; t < n_tiles; t += grid) tiles(std::integral_constant<int, 1>{}, t);
+    if (NRANGE == 1) {
+        // one column: four consecutive tiles per pass, every load issued before the first comparison (two 8-byte loads per thread
+        // and tile are too little in flight to cover HBM latency)
+        constexpr int TPI_MAIN = 4;
+        const int64_t n_packs = n_tiles / TPI_MAIN;                   // packs of TPI_MAIN full tiles, then the full tiles left over
+        for (int64_t g = blockIdx.x; g < n_packs; g += grid) {
+            LeanU4 rv[TPI_MAIN][NRANGE][U];
+#pragma unroll
+            for (int q = 0; q < TPI_MAIN; ++q) load_tile(g * TPI_MAIN + q, rv[q]);
+            tiles(std::integral_constant<int, TPI_MAIN>{}, g * TPI_MAIN, rv);
+        }
+        for (int64_t t = n_packs * TPI_MAIN + blockIdx.x; t < n_tiles; t += grid) {
+            LeanU4 rv[1][NRANGE][U];
+            load_tile(t, rv[0]);
+            tiles(std::integral_constant<int, 1>{}, t, rv);
+        }
+    } else {
+        // several columns (Q6's filter: 20 B per row over three): the NEXT tile of this workgroup is loaded while the current one
+        // is compared, so the loads never drain between tiles
+        LeanU4 cur[1][NRANGE][U], nxt[1][NRANGE][U];
+        if ((int64_t)blockIdx.x < n_tiles) load_tile(blockIdx.x, cur[0]);
+        for (int64_t t = blockIdx.x; t < n_tiles; t += grid) {
+            if (t + grid < n_tiles) load_tile(t + grid, nxt[0]);
+            tiles(std::integral_constant<int, 1>{}, t, cur);
+#pragma unroll
+            for (int p = 0; p < NRANGE; ++p)
+#pragma unroll
+                for (int u = 0; u < U; ++u) cur[0][p][u] = nxt[0][p][u];
+        }
+    }
 
     // ragged tail (< 1024 rows): one row per lane, the ballot is already in row order
     if ((int64_t)blockIdx.x == n_tiles % grid && n_tiles * RB_TILE < n_rows) {
