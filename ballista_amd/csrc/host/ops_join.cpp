@@ -697,7 +697,7 @@ StreamPtr HashJoinExec::execute_needed(int partition, const Exec& ex, const std:
             emit(outsrc, rmap, lidx, ridx, (int64_t)n_out);
             return true;
         };
-        const bool radix_mode = bs->narrow && bs->rj_log2p >= 0 && !right_outer && !left_outer;
+        const bool radix_mode = bs->narrow && bs->rj_log2p >= 0 && !bs->resid && !right_outer && !left_outer;     // (the LDS join knows one key only)
 
         const bool pair = self->pair_keys();
         // the probe side's key for a two-column join: the first key (+ the second as the residual) when the build side went that way,
