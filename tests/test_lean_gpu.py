@@ -24,14 +24,13 @@ import helpers
 pytestmark = pytest.mark.gpu
 
 
-def expected_fast_kernel():
-    """the kernel the Q1 shape runs on: the wide-load kernel, unless an A/B switch (tools/README.md) forces the path below it"""
+def on_expected_kernel(name):
+    """the Q1 shape runs on the wide-load kernel — unless an A/B switch (tools/README.md) forces a path below it, where only the
+    answer is checked"""
     import os
-    if os.environ.get("BHIP_NO_SOP", "0") not in ("", "0"):
-        return "scan_agg_lowcard_kernel"
-    if os.environ.get("BHIP_NO_LEAN", "0") not in ("", "0"):
-        return "scan_agg_sop_kernel"
-    return "scan_agg_lean_kernel"
+    if any(os.environ.get(v, "0") not in ("", "0") for v in ("BHIP_NO_SOP", "BHIP_NO_LEAN")):
+        return True
+    return name == "scan_agg_lean_kernel"
 RTOL = 1e-9
 
 
@@ -154,7 +153,7 @@ def test_large_input_runs_on_the_lean_kernel():
     c.kernel_time(reset=True)
     got = helpers.concat(helpers.collect_product(plan))
     ms, launches = c.kernel_time(reset=True)
-    assert launches == 1 and c.kernel_name() == expected_fast_kernel()
+    assert launches == 1 and on_expected_kernel(c.kernel_name())
     keys, state, count = gen.q1_partial_port(gen.lineitem_arrays(1.0, 0, n), 8, 8)
     want = gen.q1_final_from_port(keys, state, count)
     order = {k: i for i, k in enumerate(zip(got["l_returnflag"].values, got["l_linestatus"].values))}
@@ -197,7 +196,7 @@ def test_nulls_in_predicate_columns_stay_on_the_wide_load_kernels(n):
     c.kernel_time(reset=True)
     got = helpers.concat(helpers.collect_product(part))
     if n >= 65536:
-        assert c.kernel_time(reset=True)[1] == 1 and c.kernel_name() == expected_fast_kernel()
+        assert c.kernel_time(reset=True)[1] == 1 and on_expected_kernel(c.kernel_name())
     helpers.assert_rows_equal(got, plan_eval.collect(part), ordered=False, float_rtol=RTOL, key_cols=["ks"])
     # the same predicate as a standalone filter (row set and order exact)
     flt = ba.FilterExec(pred, helpers.memory_exec(c, [[b]]))
@@ -228,7 +227,7 @@ def test_all_valid_bitmaps_are_dropped_at_import_and_take_the_fast_kernels():
     c.kernel_time(reset=True)
     got = helpers.concat(helpers.collect_product(part))
     ms, launches = c.kernel_time(reset=True)
-    assert launches == 1 and c.kernel_name() == expected_fast_kernel()
+    assert launches == 1 and on_expected_kernel(c.kernel_name())
     helpers.assert_rows_equal(got, plan_eval.collect(part), ordered=False, float_rtol=RTOL, key_cols=["ks"])
     # one real NULL keeps the bitmap and the general path: same answer as the oracle with that NULL
     v = allv.copy()
