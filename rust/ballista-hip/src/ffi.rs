@@ -109,6 +109,8 @@ extern "C" {
     pub fn bhip_plan_output_partitioning(plan: *const bhip_plan, scheme: *mut i32, partition_count: *mut i32) -> bhip_status;
     pub fn bhip_plan_display(plan: *const bhip_plan, buf: *mut c_char, cap: usize) -> bhip_status;
     pub fn bhip_plan_execute(plan: *mut bhip_plan, partition: i32, out: *mut *mut bhip_stream) -> bhip_status;
+    /// datafusion::physical_plan::collect: every output partition in turn, all batches (at most `cap`) in partition order
+    pub fn bhip_plan_collect(plan: *mut bhip_plan, cap: i32, out: *mut *mut bhip_batch, n_out: *mut i32) -> bhip_status;
     pub fn bhip_plan_release(plan: *mut bhip_plan);
 
     pub fn bhip_stream_next(stream: *mut bhip_stream, out: *mut *mut bhip_batch) -> bhip_status;
