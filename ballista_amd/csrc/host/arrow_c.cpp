@@ -21,7 +21,7 @@ int dtype_from_format(const char* f) {
     static const struct { const char* fmt; int dt; } table[] = {
         {"i", DT_INT32}, {"l", DT_INT64}, {"C", DT_UINT8}, {"L", DT_UINT64}, {"g", DT_FLOAT64}, {"tdD", DT_DATE32}, {"b", DT_BOOLEAN},
         {"u", DT_UTF8}, {"c", DT_INT8}, {"s", DT_INT16}, {"S", DT_UINT16}, {"I", DT_UINT32}, {"f", DT_FLOAT32}, {"tdm", DT_DATE64},
-        {"tss:", DT_TIMESTAMP_S}, {"tsm:", DT_TIMESTAMP_MS}, {"tsu:", DT_TIMESTAMP_US}, {"tsn:", DT_TIMESTAMP_NS}};
+        {"tss:", DT_TIMESTAMP_S}, {"tsm:", DT_TIMESTAMP_MS}, {"tsu:", DT_TIMESTAMP_US}, {"tsn:", DT_TIMESTAMP_NS}, {"U", DT_LARGE_UTF8}};
     for (auto& e : table)
         if (!strcmp(f, e.fmt)) return e.dt;
     return 0;
@@ -46,6 +46,7 @@ const char* format_of_dtype(int dt) {
         case DT_TIMESTAMP_MS: return "tsm:";
         case DT_TIMESTAMP_US: return "tsu:";
         case DT_TIMESTAMP_NS: return "tsn:";
+        case DT_LARGE_UTF8: return "U";
         default: return "u";
     }
 }
@@ -60,7 +61,7 @@ const char* format_of(int dt) { return format_of_dtype(dt); }
 // (BHIP_ENOTIMPL: keep the CPU operator); timestamps with a time zone likewise
 int device_dtype_from_format(const char* f) {
     const int dt = dtype_from_format(f);
-    return (dt >= DT_INT32 && dt <= DT_LAST) ? dt : 0;
+    return (dt >= DT_INT32 && dt <= DT_LAST) || dt == DT_LARGE_UTF8 ? dt : 0;
 }
 
 // copy n bits starting at bit `off` of src into a fresh, zero-padded bitmap
@@ -118,7 +119,7 @@ void export_schema(const Schema& schema, ArrowSchema* out) {
     top->child_storage.resize(schema.fields.size());
     for (size_t i = 0; i < schema.fields.size(); ++i) {
         auto* cp = new ExportedSchema();
-        cp->format = format_of(schema.fields[i].dtype);
+        cp->format = format_of(schema.fields[i].large ? (int)DT_LARGE_UTF8 : schema.fields[i].dtype);
         cp->name = schema.fields[i].name;
         ArrowSchema& c = top->child_storage[i];
         memset(&c, 0, sizeof(c));
@@ -201,7 +202,16 @@ void export_batch(const Batch& b, ArrowArray* out) {
         const void* validity = c.validity ? host_copy(c.validity->ptr(), (size_t)((n + 7) / 8)) : nullptr;
         cp->buffers.push_back(validity);
         if (c.dtype == DT_UTF8) {
-            cp->buffers.push_back(host_copy(c.offsets->ptr(), (size_t)(n + 1) * 4));
+            const void* off32 = host_copy(c.offsets->ptr(), (size_t)(n + 1) * 4);
+            if (i < b.schema->fields.size() && b.schema->fields[i].large) {              // LargeUtf8: the same offsets as int64
+                auto* wide = static_cast<int64_t*>(malloc(((size_t)n + 1) * 8));
+                if (!wide) fail(BHIP_EOOM, "host allocation failed");
+                cp->owned.push_back(wide);
+                for (int64_t r = 0; r <= n; ++r) wide[r] = static_cast<const int32_t*>(off32)[r];
+                cp->buffers.push_back(wide);
+            } else {
+                cp->buffers.push_back(off32);
+            }
             cp->buffers.push_back(host_copy(c.data->ptr(), (size_t)c.data_bytes));
         } else if (c.dtype == DT_BOOLEAN) {
             cp->buffers.push_back(host_copy(c.data->ptr(), (size_t)((n + 7) / 8)));
@@ -277,6 +287,7 @@ bhip_status bhip_batch_import_arrow(bhip_ctx* ctx, struct ArrowArray* array, str
         std::vector<bhip_column_desc> descs(n_cols);
         std::vector<std::vector<uint8_t>> bit_storage;
         std::vector<std::vector<int32_t>> off_storage;
+        std::vector<bool> large_cols;
         for (int i = 0; i < n_cols; ++i) {
             const ArrowSchema* cs = schema->children[i];
             const ArrowArray* ca = array->children[i];
@@ -285,21 +296,38 @@ bhip_status bhip_batch_import_arrow(bhip_ctx* ctx, struct ArrowArray* array, str
             if (ca->dictionary) fail(BHIP_ENOTIMPL, "dictionary arrays are not supported");
             // the array must have the buffers its declared format implies (a producer whose batches do not match
             // the stream's schema would otherwise be read out of bounds)
-            const int64_t need_buffers = dt == DT_UTF8 ? 3 : 2;
+            const bool large = dt == DT_LARGE_UTF8;
+            const int64_t need_buffers = (dt == DT_UTF8 || large) ? 3 : 2;
             if (ca->n_buffers < need_buffers || ca->length != n_rows)
                 fail(BHIP_EINVAL, std::string("Arrow array of column ") + (cs->name ? cs->name : "") + " does not match its schema");
             const int64_t off = ca->offset + array->offset;
             bhip_column_desc& d = descs[i];
             memset(&d, 0, sizeof(d));
             d.name = cs->name ? cs->name : "";
-            d.dtype = dt;
+            d.dtype = large ? (int)DT_UTF8 : dt;
             d.nullable = (cs->flags & ARROW_FLAG_NULLABLE) ? 1 : 0;
+            large_cols.push_back(large);
             const uint8_t* validity = ca->n_buffers > 0 ? static_cast<const uint8_t*>(ca->buffers[0]) : nullptr;
             if (validity && ca->null_count != 0) {
                 bit_storage.push_back(realign_bits(validity, off, n_rows));
                 d.validity = bit_storage.back().data();
             }
-            if (dt == DT_UTF8) {
+            if (large) {
+                // 64-bit offsets, rebased to 0 and narrowed: a batch's strings must fit the device column's int32 offsets
+                const int64_t* offsets = static_cast<const int64_t*>(ca->buffers[1]) + off;
+                off_storage.emplace_back((size_t)n_rows + 1);
+                auto& o = off_storage.back();
+                if (!ca->buffers[1] && n_rows > 0)
+                    fail(BHIP_EINVAL, std::string("Arrow array of column ") + (cs->name ? cs->name : "") + " has no offsets buffer");
+                const int64_t first = ca->buffers[1] ? offsets[0] : 0;
+                if (ca->buffers[1] && offsets[n_rows] - first > 0x7FFFFFFFll)
+                    fail(BHIP_ENOTIMPL, std::string("LargeUtf8 column ") + (cs->name ? cs->name : "") + " holds more than 2 GiB of value bytes in one batch");
+                for (int64_t r = 0; r <= n_rows; ++r) o[(size_t)r] = ca->buffers[1] ? (int32_t)(offsets[r] - first) : 0;
+                d.offsets = o.data();
+                d.data = static_cast<const uint8_t*>(ca->buffers[2]) + first;
+                d.data_bytes = o[(size_t)n_rows];
+                if (!ca->buffers[2]) d.data = "";
+            } else if (dt == DT_UTF8) {
                 const int32_t* offsets = static_cast<const int32_t*>(ca->buffers[1]) + off;
                 // rebase to 0 so only the referenced bytes are shipped
                 off_storage.emplace_back((size_t)n_rows + 1);
@@ -323,7 +351,10 @@ bhip_status bhip_batch_import_arrow(bhip_ctx* ctx, struct ArrowArray* array, str
         BatchPtr b = batch_from_host(ctx->p, n_cols, descs.data(), n_rows, false);
         // schema nullability follows the Arrow field flag
         auto s = std::make_shared<Schema>(*b->schema);
-        for (int i = 0; i < n_cols; ++i) s->fields[i].nullable = descs[i].nullable || descs[i].validity;
+        for (int i = 0; i < n_cols; ++i) {
+            s->fields[i].nullable = descs[i].nullable || descs[i].validity;
+            s->fields[i].large = large_cols[i];
+        }
         auto nb = std::make_shared<Batch>(*b);
         nb->schema = s;
         auto h = new bhip_batch();
@@ -428,7 +459,7 @@ bhip_status bhip_plan_arrow_streams(bhip_ctx* ctx, int32_t n_partitions, struct 
             const ArrowSchema* cs = sch.children[i];
             const int dt = device_dtype_from_format(cs->format);
             if (!dt) err = std::string("unsupported Arrow type '") + cs->format + "' for column " + (cs->name ? cs->name : "");
-            else schema->fields.push_back(bhip::Field{cs->name ? cs->name : "", dt, (cs->flags & ARROW_FLAG_NULLABLE) != 0});
+            else schema->fields.push_back(bhip::Field{cs->name ? cs->name : "", dt == DT_LARGE_UTF8 ? (int)DT_UTF8 : dt, (cs->flags & ARROW_FLAG_NULLABLE) != 0, dt == DT_LARGE_UTF8});
         }
         if (sch.release) sch.release(&sch);
         if (!err.empty()) fail(strncmp(err.c_str(), "unsupported", 11) == 0 ? BHIP_ENOTIMPL : BHIP_EINVAL, err);

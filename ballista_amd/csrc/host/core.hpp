@@ -220,6 +220,9 @@ struct Field {
     std::string name;
     int dtype;
     bool nullable;
+    // LargeUtf8 at the boundary (Arrow C data, IPC files, wire schemas): 64-bit offsets there; the device column is an ordinary Utf8
+    // column (int32 offsets: < 2 GiB of value bytes per batch, refused beyond).  The flag follows the column through the operators.
+    bool large = false;
 };
 
 struct Schema {

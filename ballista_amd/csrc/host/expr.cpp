@@ -240,6 +240,24 @@ int expr_type(const ExprPtr& e, const Schema& schema) {
     }
 }
 
+bool expr_large(const ExprPtr& e, const Schema& schema) {
+    switch (e->kind) {
+        case BHIP_EXPR_COLUMN: {
+            const int i = schema.index_of(e->name);
+            return i >= 0 && schema.fields[i].large;
+        }
+        case BHIP_EXPR_SCALAR_FN: return str_fn(e->name) >= 0 && expr_large(e->args[0], schema);
+        case BHIP_EXPR_CASE: {
+            size_t fw, np;
+            case_layout(*e, fw, np);
+            for (size_t i = 0; i < np; ++i)
+                if (expr_large(e->args[fw + 2 * i + 1], schema)) return true;
+            return e->has_else && expr_large(e->args.back(), schema);
+        }
+        default: return false;
+    }
+}
+
 // ---- coercion -------------------------------------------------------------------------------------
 // DataFusion's numerical_coercion (datafusion 4.0.0-SNAPSHOT rev 46161d2, physical_plan/expressions/coercion.rs — the crate is not
 // vendored in the reference; rust/Cargo.lock:497-500 pins it): equal types stay; otherwise the FIRST of

@@ -71,6 +71,8 @@ struct Operand {
     int col = -1;
 };
 
+// a Utf8-valued expression whose Arrow form is LargeUtf8 (Field::large of the columns it comes from)
+bool expr_large(const ExprPtr& e, const Schema& schema);
 // index of a string-valued scalar function (lower, upper, trim, ltrim, rtrim; evaluated as columns, utf8_exprs.cpp), -1 otherwise
 int str_fn(const std::string& name);
 

@@ -189,7 +189,7 @@ FbTable fb_root(const uint8_t* p, size_t len) {
 }
 
 // ---- Arrow type <-> Flatbuffers Type union ---------------------------------------------------------------------------------
-enum { T_Int = 2, T_FloatingPoint = 3, T_Utf8 = 5, T_Bool = 6, T_Date = 8, T_Timestamp = 10 };
+enum { T_Int = 2, T_FloatingPoint = 3, T_Utf8 = 5, T_Bool = 6, T_Date = 8, T_Timestamp = 10, T_LargeUtf8 = 20 };
 
 uint32_t write_type(Fb& fb, int dt, uint8_t& type_tag) {
     auto int_type = [&](int bits, bool is_signed) {
@@ -215,6 +215,7 @@ uint32_t write_type(Fb& fb, int dt, uint8_t& type_tag) {
             type_tag = T_FloatingPoint;
             return fb.end_table();
         case DT_UTF8: fb.start_table(0); type_tag = T_Utf8; return fb.end_table();
+        case DT_LARGE_UTF8: fb.start_table(0); type_tag = T_LargeUtf8; return fb.end_table();
         case DT_BOOLEAN: fb.start_table(0); type_tag = T_Bool; return fb.end_table();
         case DT_DATE32:
         case DT_DATE64:
@@ -254,6 +255,7 @@ int read_type(uint8_t tag, const FbTable& t, const std::string& field_name) {
             break;
         }
         case T_Utf8: return DT_UTF8;
+        case T_LargeUtf8: return DT_LARGE_UTF8;
         case T_Bool: return DT_BOOLEAN;
         case T_Date: return t.scalar<int16_t>(0, 1) == 0 ? DT_DATE32 : DT_DATE64;
         case T_Timestamp:
@@ -269,7 +271,7 @@ uint32_t write_schema(Fb& fb, const Schema& s) {
     for (auto& f : s.fields) {
         const uint32_t name = fb.string(f.name);
         uint8_t tag = 0;
-        const uint32_t type = write_type(fb, f.dtype, tag);
+        const uint32_t type = write_type(fb, f.large ? (int)DT_LARGE_UTF8 : f.dtype, tag);
         const uint32_t children = fb.offsets_vector({});
         fb.start_table(7);                                     // Field: name, nullable, type_type, type, dictionary, children, custom_metadata
         fb.add_offset(0, name);
@@ -298,6 +300,7 @@ SchemaPtr read_schema(const FbTable& st) {
         fld.nullable = f.scalar<uint8_t>(1, 0) != 0;
         if (f.field(4)) fail(BHIP_ENOTIMPL, "Arrow IPC: dictionary-encoded column '" + fld.name + "'");
         fld.dtype = read_type(f.scalar<uint8_t>(2, 0), f.table(3), fld.name);
+        if (fld.dtype == DT_LARGE_UTF8) { fld.dtype = DT_UTF8; fld.large = true; }
         s->fields.push_back(fld);
     }
     return s;
@@ -358,7 +361,21 @@ void column_pieces(const ArrowArray& a, int dt, std::vector<BodyPiece>& out, int
     } else {
         out.push_back(BodyPiece{nullptr, 0, {}});                  // V5: an absent validity buffer has length 0
     }
-    if (dt == DT_UTF8) {
+    if (dt == DT_LARGE_UTF8) {
+        const int64_t* o = static_cast<const int64_t*>(a.buffers[1]) + off;
+        const char* d = static_cast<const char*>(a.buffers[2]);
+        BodyPiece po{nullptr, (n + 1) * 8, {}};
+        const int64_t base = a.buffers[1] ? o[0] : 0;
+        if (!a.buffers[1]) po.owned.assign(16, 0);
+        else if (base == 0) po.ptr = o;
+        else {
+            po.owned.resize((size_t)(n + 1) * 8);
+            int64_t* r = reinterpret_cast<int64_t*>(po.owned.data());
+            for (int64_t i = 0; i <= n; ++i) r[i] = o[i] - base;
+        }
+        out.push_back(std::move(po));
+        out.push_back(BodyPiece{d ? d + base : nullptr, (n && a.buffers[1]) ? (int64_t)(o[n] - base) : 0, {}});
+    } else if (dt == DT_UTF8) {
         const int32_t* o = static_cast<const int32_t*>(a.buffers[1]) + off;
         const char* d = static_cast<const char*>(a.buffers[2]);
         BodyPiece po{nullptr, (n + 1) * 4, {}};
@@ -393,7 +410,7 @@ SchemaPtr schema_of_c(const ArrowSchema& sch) {
         const ArrowSchema* c = sch.children[i];
         const int dt = dtype_from_format(c->format);
         if (!dt) fail(BHIP_ENOTIMPL, std::string("Arrow IPC: unsupported Arrow type '") + c->format + "' for column " + (c->name ? c->name : ""));
-        s->fields.push_back(Field{c->name ? c->name : "", dt, (c->flags & ARROW_FLAG_NULLABLE) != 0});
+        s->fields.push_back(Field{c->name ? c->name : "", dt == DT_LARGE_UTF8 ? (int)DT_UTF8 : dt, (c->flags & ARROW_FLAG_NULLABLE) != 0, dt == DT_LARGE_UTF8});
     }
     return s;
 }
@@ -439,7 +456,7 @@ void ipc_write_file(ArrowArrayStream* stream, const std::string& path, uint64_t*
             if (a.length != arr.length) fail(BHIP_EINVAL, "Arrow IPC: column length differs from the batch length");
             const size_t first = pieces.size();
             int64_t nulls = 0;
-            column_pieces(a, schema->fields[c].dtype, pieces, nulls);
+            column_pieces(a, schema->fields[c].large ? (int)DT_LARGE_UTF8 : schema->fields[c].dtype, pieces, nulls);
             nodes.push_back({a.length, nulls});
             for (size_t k = first; k < pieces.size(); ++k) {
                 buffers.push_back({body, pieces[k].bytes});
@@ -587,13 +604,22 @@ void export_next(const std::shared_ptr<IpcFile>& Fp, ArrowArray* out) {
         a.length = rb.rd<int64_t>(nodes + 16 * c);
         a.null_count = rb.rd<int64_t>(nodes + 16 * c + 8);
         if (a.length != n_rows) fail(BHIP_EEXEC, "Arrow IPC: field node length differs from the batch length");
-        const int dt = F.schema->fields[c].dtype;
+        const int dt = F.schema->fields[c].large ? (int)DT_LARGE_UTF8 : F.schema->fields[c].dtype;
         int64_t bl;
         const void* validity = next_buf(bl);
         if (a.null_count > 0 && (!validity || bl < (n_rows + 7) / 8)) fail(BHIP_EEXEC, "Arrow IPC: validity buffer too short");
         X->buffers[c].push_back(a.null_count > 0 ? validity : nullptr);
-        static const int32_t zero_offset[2] = {0, 0};
-        if (dt == DT_UTF8) {
+        static const int32_t zero_offset[4] = {0, 0, 0, 0};
+        if (dt == DT_LARGE_UTF8) {
+            const void* o = next_buf(bl);
+            if (n_rows > 0 && bl < (n_rows + 1) * 8) fail(BHIP_EEXEC, "Arrow IPC: offsets buffer too short");
+            const int64_t* oi = o ? static_cast<const int64_t*>(o) : reinterpret_cast<const int64_t*>(zero_offset);
+            int64_t dl;
+            const void* d = next_buf(dl);
+            if (n_rows > 0 && (oi[0] < 0 || oi[n_rows] < oi[0] || oi[n_rows] > dl)) fail(BHIP_EEXEC, "Arrow IPC: string offsets outside the data buffer");
+            X->buffers[c].push_back(oi);
+            X->buffers[c].push_back(d ? d : (const void*)zero_offset);
+        } else if (dt == DT_UTF8) {
             const void* o = next_buf(bl);
             if (n_rows > 0 && bl < (n_rows + 1) * 4) fail(BHIP_EEXEC, "Arrow IPC: offsets buffer too short");
             const int32_t* oi = o ? static_cast<const int32_t*>(o) : zero_offset;
@@ -642,7 +668,7 @@ void export_schema_c(const Schema& s, ArrowSchema* out) {
     for (size_t i = 0; i < s.fields.size(); ++i) {
         ArrowSchema& c = H->children[i];
         memset(&c, 0, sizeof(c));
-        c.format = format_of_dtype(s.fields[i].dtype);
+        c.format = format_of_dtype(s.fields[i].large ? (int)DT_LARGE_UTF8 : s.fields[i].dtype);
         c.name = H->names[i].c_str();
         c.flags = s.fields[i].nullable ? ARROW_FLAG_NULLABLE : 0;
         c.release = release_schema_child;

@@ -43,7 +43,10 @@ HashAggregateExec::HashAggregateExec(int mode, std::vector<std::pair<ExprPtr, st
     if (mode != BHIP_AGG_PARTIAL && mode != BHIP_AGG_FINAL) fail(BHIP_EINVAL, "Unsupported aggregate mode");
     const Schema& in = *input_->schema();
     auto s = std::make_shared<Schema>();
-    for (auto& g : group_) s->fields.push_back(Field{g.second, expr_type(g.first, in), expr_nullable(g.first, in)});
+    for (auto& g : group_) {
+        const int t = expr_type(g.first, in);
+        s->fields.push_back(Field{g.second, t, expr_nullable(g.first, in), t == DT_UTF8 && expr_large(g.first, in)});
+    }
     size_t state_pos = group_.size();
     for (auto& a : aggr_) {
         if (a.fn < BHIP_AGG_SUM || a.fn > BHIP_AGG_MAX) fail(BHIP_ENOTIMPL, "Unsupported aggregate function");
@@ -58,8 +61,8 @@ HashAggregateExec::HashAggregateExec(int mode, std::vector<std::pair<ExprPtr, st
                     s->fields.push_back(Field{a.name + "[sum]", DT_FLOAT64, true});
                     break;
                 case BHIP_AGG_COUNT: s->fields.push_back(Field{a.name + "[count]", DT_UINT64, false}); break;
-                case BHIP_AGG_MIN: s->fields.push_back(Field{a.name + "[min]", t, true}); break;
-                default: s->fields.push_back(Field{a.name + "[max]", t, true}); break;
+                case BHIP_AGG_MIN: s->fields.push_back(Field{a.name + "[min]", t, true, t == DT_UTF8 && expr_large(a.arg, in)}); break;
+                default: s->fields.push_back(Field{a.name + "[max]", t, true, t == DT_UTF8 && expr_large(a.arg, in)}); break;
             }
         } else {
             const size_t need = a.fn == BHIP_AGG_AVG ? 2 : 1;
@@ -67,7 +70,7 @@ HashAggregateExec::HashAggregateExec(int mode, std::vector<std::pair<ExprPtr, st
             switch (a.fn) {
                 case BHIP_AGG_AVG: s->fields.push_back(Field{a.name, DT_FLOAT64, true}); break;
                 case BHIP_AGG_COUNT: s->fields.push_back(Field{a.name, DT_UINT64, false}); break;
-                default: s->fields.push_back(Field{a.name, in.fields[state_pos].dtype, true}); break;
+                default: s->fields.push_back(Field{a.name, in.fields[state_pos].dtype, true, in.fields[state_pos].large}); break;
             }
             state_pos += need;
         }

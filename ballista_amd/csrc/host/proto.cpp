@@ -121,7 +121,7 @@ int decode_arrow_type(Pb r, std::string* name_out) {
             case 12: dt = DT_FLOAT32; name = "Float32"; break;
             case 13: dt = DT_FLOAT64; name = "Float64"; break;
             case 14: dt = DT_UTF8; name = "Utf8"; break;
-            case 32: name = "LargeUtf8"; break;
+            case 32: dt = DT_LARGE_UTF8; name = "LargeUtf8"; break;      // schemas only: decode_field turns it into Utf8 + Field::large
             case 15: name = "Binary"; break;
             case 17: dt = DT_DATE32; name = "Date32"; break;
             case 18: dt = DT_DATE64; name = "Date64"; break;
@@ -159,6 +159,7 @@ Field decode_field(Pb r) {
         else r.skip(wt);
     }
     if (!fld.dtype) fail(BHIP_ENOTIMPL, "field '" + fld.name + "' has type " + tname + ", which the GPU path does not carry");
+    if (fld.dtype == DT_LARGE_UTF8) { fld.dtype = DT_UTF8; fld.large = true; }
     return fld;
 }
 
@@ -354,7 +355,7 @@ ExprPtr decode_expr(Pb r) {
                 uint32_t cf, cwt;
                 while (c.next(cf, cwt)) {
                     if (cf == 1 && cwt == 2) e->args = {decode_expr(c.sub())};
-                    else if (cf == 2 && cwt == 2) e->dtype = decode_arrow_type(c.sub(), &tname);
+                    else if (cf == 2 && cwt == 2) { e->dtype = decode_arrow_type(c.sub(), &tname); if (e->dtype == DT_LARGE_UTF8) e->dtype = 0; }
                     else c.skip(cwt);
                 }
                 if (e->args.empty()) fail(BHIP_EINVAL, "protobuf: CastNode without an operand");

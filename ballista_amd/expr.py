@@ -26,6 +26,7 @@ FLOAT64, DATE32, BOOLEAN, UTF8 = "Float64", "Date32", "Boolean", "Utf8"
 INT8, INT16, UINT16, UINT32, FLOAT32, DATE64 = "Int8", "Int16", "UInt16", "UInt32", "Float32", "Date64"
 TIMESTAMP_S, TIMESTAMP_MS = "Timestamp(Second)", "Timestamp(Millisecond)"
 TIMESTAMP_US, TIMESTAMP_NS = "Timestamp(Microsecond)", "Timestamp(Nanosecond)"
+LARGE_UTF8 = "LargeUtf8"       # schemas only (Arrow / IPC form of a Utf8 device column with 64-bit offsets)
 ALL_TYPES = (INT32, INT64, UINT8, UINT64, FLOAT64, DATE32, BOOLEAN, UTF8, INT8, INT16, UINT16, UINT32, FLOAT32, DATE64,
              TIMESTAMP_S, TIMESTAMP_MS, TIMESTAMP_US, TIMESTAMP_NS)
 

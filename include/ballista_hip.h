@@ -99,7 +99,9 @@ typedef enum {
     BHIP_DATE32 = 6, BHIP_BOOLEAN = 7, BHIP_UTF8 = 8,
     /* the other primitive types of the serde (rust/core/proto/ballista.proto:755-790) */
     BHIP_INT8 = 9, BHIP_INT16 = 10, BHIP_UINT16 = 11, BHIP_UINT32 = 12, BHIP_FLOAT32 = 13, BHIP_DATE64 = 14,
-    BHIP_TIMESTAMP_S = 15, BHIP_TIMESTAMP_MS = 16, BHIP_TIMESTAMP_US = 17, BHIP_TIMESTAMP_NS = 18
+    BHIP_TIMESTAMP_S = 15, BHIP_TIMESTAMP_MS = 16, BHIP_TIMESTAMP_US = 17, BHIP_TIMESTAMP_NS = 18,
+    /* schemas only: a Utf8 column whose Arrow / IPC form is LargeUtf8 (64-bit offsets); on the device it is BHIP_UTF8 */
+    BHIP_LARGE_UTF8 = 19
 } bhip_dtype;
 
 typedef struct bhip_ctx bhip_ctx;        /* one GPU: allocator, stream pool */

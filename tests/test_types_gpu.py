@@ -234,3 +234,40 @@ def test_arrow_and_ipc_edges_carry_every_type(ctx, tmp_path):
     assert back.schema.types == rb.schema.types
     want = pa.Table.from_batches([rb]).sort_by("ord")
     assert back.equals(want)
+
+
+def test_large_utf8_at_the_boundary(ctx, tmp_path):
+    """LargeUtf8 (64-bit offsets) comes in through the Arrow C stream, is an ordinary Utf8 column on the device, keeps its schema
+    type through Filter / Sort / Projection / GROUP BY / MIN, and leaves as LargeUtf8 again — as an Arrow array and in the IPC file"""
+    import pyarrow as pa
+    import pyarrow.compute as pc
+    rng = np.random.default_rng(43)
+    n = 3000
+    words = ["alpha", "", "Beta ", "gamma-gamma", "é日本", "z"]
+    s = pa.array([None if rng.random() < 0.1 else words[k] for k in rng.integers(0, len(words), n)], pa.large_string())
+    t = pa.table({"s": s, "k": pa.array(rng.integers(0, 9, n).astype(np.int32)), "u": pa.array([f"u{i % 5}" for i in range(n)], pa.string())})
+    leaf = ba.ArrowStreamExec(pa.RecordBatchReader.from_batches(t.schema, t.to_batches(max_chunksize=1100)), ctx)
+    assert [ty for _, ty, _ in leaf.schema()] == ["LargeUtf8", "Int32", "Utf8"]
+    flt = ba.FilterExec(E.coerce(col("k") < lit(5), {"k": "Int32"}), leaf)
+    plan = ba.SortExec([E.PhysicalSortExpr(col("s"), nulls_first=False), E.PhysicalSortExpr(col("k")), E.PhysicalSortExpr(col("u"))],
+                       ba.ProjectionExec([(col("s"), "s"), (col("k"), "k"), (col("u"), "u"), (E.ScalarFunctionExpr("trim", [col("s")]), "ts")], flt))
+    assert [ty for _, ty, _ in plan.schema()] == ["LargeUtf8", "Int32", "Utf8", "LargeUtf8"]
+    got = pa.Table.from_batches([b.to_pyarrow() for b in plan.collect()])
+    assert got.schema.field("s").type == pa.large_string() and got.schema.field("ts").type == pa.large_string()
+    want = t.filter(pc.less(t["k"], 5)).sort_by([("s", "ascending"), ("k", "ascending"), ("u", "ascending")])
+    # (pyarrow sorts NULLs last: nulls_first=False above)
+    assert got["s"].to_pylist() == want["s"].to_pylist() and got["k"].to_pylist() == want["k"].to_pylist()
+    assert got["ts"].to_pylist() == [None if v is None else v.strip() for v in want["s"].to_pylist()]
+    # the stage file carries the type, and reads back the same way
+    path = str(tmp_path / "large.arrow")
+    plan.execute(0).write_ipc(path)
+    back = pa.ipc.open_file(path).read_all()
+    assert back.schema.field("s").type == pa.large_string() and back.equals(got)
+    again = ba.IpcFileExec([path], ctx)
+    assert [ty for _, ty, _ in again.schema()][:1] == ["LargeUtf8"]
+    assert pa.Table.from_batches([b.to_pyarrow() for b in again.collect()]).equals(got)
+    # GROUP BY and MIN keep it too
+    agg = ba.HashAggregateExec(ba.plan.PARTIAL, [(col("s"), "s")], [E.Min(col("s"), "m"), E.Count(col("k"), "c")], leaf)
+    assert [ty for _, ty, _ in agg.schema()][:2] == ["LargeUtf8", "LargeUtf8"]
+    out = pa.Table.from_batches([b.to_pyarrow() for b in agg.collect()])
+    assert out.schema.field("s").type == pa.large_string() and out.num_rows == len(words) + 1
