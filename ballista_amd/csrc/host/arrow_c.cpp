@@ -21,7 +21,7 @@ int dtype_from_format(const char* f) {
     static const struct { const char* fmt; int dt; } table[] = {
         {"i", DT_INT32}, {"l", DT_INT64}, {"C", DT_UINT8}, {"L", DT_UINT64}, {"g", DT_FLOAT64}, {"tdD", DT_DATE32}, {"b", DT_BOOLEAN},
         {"u", DT_UTF8}, {"c", DT_INT8}, {"s", DT_INT16}, {"S", DT_UINT16}, {"I", DT_UINT32}, {"f", DT_FLOAT32}, {"tdm", DT_DATE64},
-        {"tss:", DT_TIMESTAMP_S}, {"tsm:", DT_TIMESTAMP_MS}, {"tsu:", DT_TIMESTAMP_US}, {"tsn:", DT_TIMESTAMP_NS}, {"U", DT_LARGE_UTF8}};
+        {"tss:", DT_TIMESTAMP_S}, {"tsm:", DT_TIMESTAMP_MS}, {"tsu:", DT_TIMESTAMP_US}, {"tsn:", DT_TIMESTAMP_NS}, {"U", DT_LARGE_UTF8}, {"z", DT_BINARY}};
     for (auto& e : table)
         if (!strcmp(f, e.fmt)) return e.dt;
     return 0;
@@ -47,6 +47,7 @@ const char* format_of_dtype(int dt) {
         case DT_TIMESTAMP_US: return "tsu:";
         case DT_TIMESTAMP_NS: return "tsn:";
         case DT_LARGE_UTF8: return "U";
+        case DT_BINARY: return "z";
         default: return "u";
     }
 }
@@ -61,7 +62,7 @@ const char* format_of(int dt) { return format_of_dtype(dt); }
 // (BHIP_ENOTIMPL: keep the CPU operator); timestamps with a time zone likewise
 int device_dtype_from_format(const char* f) {
     const int dt = dtype_from_format(f);
-    return (dt >= DT_INT32 && dt <= DT_LAST) || dt == DT_LARGE_UTF8 ? dt : 0;
+    return (dt >= DT_INT32 && dt <= DT_LAST) || dt == DT_LARGE_UTF8 || dt == DT_BINARY ? dt : 0;
 }
 
 // copy n bits starting at bit `off` of src into a fresh, zero-padded bitmap
@@ -119,7 +120,7 @@ void export_schema(const Schema& schema, ArrowSchema* out) {
     top->child_storage.resize(schema.fields.size());
     for (size_t i = 0; i < schema.fields.size(); ++i) {
         auto* cp = new ExportedSchema();
-        cp->format = format_of(schema.fields[i].large ? (int)DT_LARGE_UTF8 : schema.fields[i].dtype);
+        cp->format = format_of(schema.fields[i].binary ? (int)DT_BINARY : schema.fields[i].large ? (int)DT_LARGE_UTF8 : schema.fields[i].dtype);
         cp->name = schema.fields[i].name;
         ArrowSchema& c = top->child_storage[i];
         memset(&c, 0, sizeof(c));
@@ -287,7 +288,7 @@ bhip_status bhip_batch_import_arrow(bhip_ctx* ctx, struct ArrowArray* array, str
         std::vector<bhip_column_desc> descs(n_cols);
         std::vector<std::vector<uint8_t>> bit_storage;
         std::vector<std::vector<int32_t>> off_storage;
-        std::vector<bool> large_cols;
+        std::vector<bool> large_cols, binary_cols;
         for (int i = 0; i < n_cols; ++i) {
             const ArrowSchema* cs = schema->children[i];
             const ArrowArray* ca = array->children[i];
@@ -296,17 +297,18 @@ bhip_status bhip_batch_import_arrow(bhip_ctx* ctx, struct ArrowArray* array, str
             if (ca->dictionary) fail(BHIP_ENOTIMPL, "dictionary arrays are not supported");
             // the array must have the buffers its declared format implies (a producer whose batches do not match
             // the stream's schema would otherwise be read out of bounds)
-            const bool large = dt == DT_LARGE_UTF8;
-            const int64_t need_buffers = (dt == DT_UTF8 || large) ? 3 : 2;
+            const bool large = dt == DT_LARGE_UTF8, binary = dt == DT_BINARY;
+            const int64_t need_buffers = (dt == DT_UTF8 || large || binary) ? 3 : 2;
             if (ca->n_buffers < need_buffers || ca->length != n_rows)
                 fail(BHIP_EINVAL, std::string("Arrow array of column ") + (cs->name ? cs->name : "") + " does not match its schema");
             const int64_t off = ca->offset + array->offset;
             bhip_column_desc& d = descs[i];
             memset(&d, 0, sizeof(d));
             d.name = cs->name ? cs->name : "";
-            d.dtype = large ? (int)DT_UTF8 : dt;
+            d.dtype = (large || binary) ? (int)DT_UTF8 : dt;
             d.nullable = (cs->flags & ARROW_FLAG_NULLABLE) ? 1 : 0;
             large_cols.push_back(large);
+            binary_cols.push_back(binary);
             const uint8_t* validity = ca->n_buffers > 0 ? static_cast<const uint8_t*>(ca->buffers[0]) : nullptr;
             if (validity && ca->null_count != 0) {
                 bit_storage.push_back(realign_bits(validity, off, n_rows));
@@ -327,7 +329,7 @@ bhip_status bhip_batch_import_arrow(bhip_ctx* ctx, struct ArrowArray* array, str
                 d.data = static_cast<const uint8_t*>(ca->buffers[2]) + first;
                 d.data_bytes = o[(size_t)n_rows];
                 if (!ca->buffers[2]) d.data = "";
-            } else if (dt == DT_UTF8) {
+            } else if (dt == DT_UTF8 || binary) {
                 const int32_t* offsets = static_cast<const int32_t*>(ca->buffers[1]) + off;
                 // rebase to 0 so only the referenced bytes are shipped
                 off_storage.emplace_back((size_t)n_rows + 1);
@@ -354,6 +356,7 @@ bhip_status bhip_batch_import_arrow(bhip_ctx* ctx, struct ArrowArray* array, str
         for (int i = 0; i < n_cols; ++i) {
             s->fields[i].nullable = descs[i].nullable || descs[i].validity;
             s->fields[i].large = large_cols[i];
+            s->fields[i].binary = binary_cols[i];
         }
         auto nb = std::make_shared<Batch>(*b);
         nb->schema = s;
@@ -459,7 +462,7 @@ bhip_status bhip_plan_arrow_streams(bhip_ctx* ctx, int32_t n_partitions, struct 
             const ArrowSchema* cs = sch.children[i];
             const int dt = device_dtype_from_format(cs->format);
             if (!dt) err = std::string("unsupported Arrow type '") + cs->format + "' for column " + (cs->name ? cs->name : "");
-            else schema->fields.push_back(bhip::Field{cs->name ? cs->name : "", dt == DT_LARGE_UTF8 ? (int)DT_UTF8 : dt, (cs->flags & ARROW_FLAG_NULLABLE) != 0, dt == DT_LARGE_UTF8});
+            else schema->fields.push_back(bhip::Field{cs->name ? cs->name : "", (dt == DT_LARGE_UTF8 || dt == DT_BINARY) ? (int)DT_UTF8 : dt, (cs->flags & ARROW_FLAG_NULLABLE) != 0, dt == DT_LARGE_UTF8, dt == DT_BINARY});
         }
         if (sch.release) sch.release(&sch);
         if (!err.empty()) fail(strncmp(err.c_str(), "unsupported", 11) == 0 ? BHIP_ENOTIMPL : BHIP_EINVAL, err);

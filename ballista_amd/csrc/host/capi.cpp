@@ -367,7 +367,7 @@ static void fill_schema(const Schema& s, std::vector<std::string>* keep, int32_t
     if (n_cols) *n_cols = (int32_t)s.fields.size();
     for (int i = 0; i < cap && i < (int)s.fields.size(); ++i) {
         if (names) names[i] = s.fields[i].name.c_str();
-        if (dtypes) dtypes[i] = s.fields[i].large ? (int32_t)DT_LARGE_UTF8 : s.fields[i].dtype;
+        if (dtypes) dtypes[i] = s.fields[i].binary ? (int32_t)DT_BINARY : s.fields[i].large ? (int32_t)DT_LARGE_UTF8 : s.fields[i].dtype;
         if (nullable) nullable[i] = s.fields[i].nullable;
     }
 }

@@ -223,6 +223,8 @@ struct Field {
     // LargeUtf8 at the boundary (Arrow C data, IPC files, wire schemas): 64-bit offsets there; the device column is an ordinary Utf8
     // column (int32 offsets: < 2 GiB of value bytes per batch, refused beyond).  The flag follows the column through the operators.
     bool large = false;
+    // Binary at the boundary (sha224 .. sha512 produce it): the same buffers as Utf8, nothing reads them as text
+    bool binary = false;
 };
 
 struct Schema {

@@ -52,8 +52,12 @@ int str_fn(const std::string& name) {
     return -1;
 }
 
+int sha_fn(const std::string& name) {
+    return name == "sha224" ? 224 : name == "sha256" ? 256 : name == "sha384" ? 384 : name == "sha512" ? 512 : 0;
+}
+
 void check_scalar_function(const std::string& name, int n_args) {
-    if (math_fn(name) < 0 && str_fn(name) < 0 && name != "octet_length")
+    if (math_fn(name) < 0 && str_fn(name) < 0 && sha_fn(name) == 0 && name != "octet_length")
         fail(BHIP_ENOTIMPL, "scalar function '" + name + "' is not supported");
     if (n_args != 1) fail(BHIP_EINVAL, "scalar function takes one argument");
 }
@@ -235,7 +239,7 @@ int expr_type(const ExprPtr& e, const Schema& schema) {
             case_layout(*e, fw, np);
             return expr_type(e->args[fw + 1], schema);
         }
-        case BHIP_EXPR_SCALAR_FN: return str_fn(e->name) >= 0 ? DT_UTF8 : (e->name == "octet_length" ? DT_INT32 : DT_FLOAT64);
+        case BHIP_EXPR_SCALAR_FN: return (str_fn(e->name) >= 0 || sha_fn(e->name)) ? DT_UTF8 : (e->name == "octet_length" ? DT_INT32 : DT_FLOAT64);
         default: fail(BHIP_ENOTIMPL, "unsupported expression kind");
     }
 }
@@ -253,6 +257,22 @@ bool expr_large(const ExprPtr& e, const Schema& schema) {
             for (size_t i = 0; i < np; ++i)
                 if (expr_large(e->args[fw + 2 * i + 1], schema)) return true;
             return e->has_else && expr_large(e->args.back(), schema);
+        }
+        default: return false;
+    }
+}
+
+bool expr_binary(const ExprPtr& e, const Schema& schema) {
+    switch (e->kind) {
+        case BHIP_EXPR_COLUMN: {
+            const int i = schema.index_of(e->name);
+            return i >= 0 && schema.fields[i].binary;
+        }
+        case BHIP_EXPR_SCALAR_FN: return sha_fn(e->name) != 0;
+        case BHIP_EXPR_CASE: {
+            size_t fw, np;
+            case_layout(*e, fw, np);
+            return np > 0 && expr_binary(e->args[fw + 1], schema);
         }
         default: return false;
     }
@@ -840,7 +860,7 @@ Operand ProgramBuilder::compile_uncached(const ExprPtr& ep) {
                 instrs_.back().ins.c = (uint8_t)a.col;
                 return o;
             }
-            if (str_fn(e.name) >= 0) fail(BHIP_ENOTIMPL, "expression producing Utf8: " + e.name + "() (evaluated as a column, host/utf8_exprs.cpp)");
+            if (str_fn(e.name) >= 0 || sha_fn(e.name)) fail(BHIP_ENOTIMPL, "expression producing Utf8 / Binary: " + e.name + "() (evaluated as a column, host/utf8_exprs.cpp)");
             if (expr_type(e.args[0], schema_) != DT_FLOAT64) fail(BHIP_EINVAL, e.name + " requires a Float64 argument");
             Operand a = materialize(compile(e.args[0]));
             return emit(OP_MATH_F64, &a, nullptr, false, VC_F64, DT_FLOAT64, (uint16_t)math_fn(e.name));

@@ -73,6 +73,8 @@ struct Operand {
 
 // a Utf8-valued expression whose Arrow form is LargeUtf8 (Field::large of the columns it comes from)
 bool expr_large(const ExprPtr& e, const Schema& schema);
+bool expr_binary(const ExprPtr& e, const Schema& schema);         // ... is Binary (a Binary column, sha224 .. sha512)
+int sha_fn(const std::string& name);                              // digest bits of sha224 / sha256 / sha384 / sha512, 0 otherwise
 // index of a string-valued scalar function (lower, upper, trim, ltrim, rtrim; evaluated as columns, utf8_exprs.cpp), -1 otherwise
 int str_fn(const std::string& name);
 

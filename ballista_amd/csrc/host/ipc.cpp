@@ -189,7 +189,7 @@ FbTable fb_root(const uint8_t* p, size_t len) {
 }
 
 // ---- Arrow type <-> Flatbuffers Type union ---------------------------------------------------------------------------------
-enum { T_Int = 2, T_FloatingPoint = 3, T_Utf8 = 5, T_Bool = 6, T_Date = 8, T_Timestamp = 10, T_LargeUtf8 = 20 };
+enum { T_Int = 2, T_FloatingPoint = 3, T_Binary = 4, T_Utf8 = 5, T_Bool = 6, T_Date = 8, T_Timestamp = 10, T_LargeUtf8 = 20 };
 
 uint32_t write_type(Fb& fb, int dt, uint8_t& type_tag) {
     auto int_type = [&](int bits, bool is_signed) {
@@ -216,6 +216,7 @@ uint32_t write_type(Fb& fb, int dt, uint8_t& type_tag) {
             return fb.end_table();
         case DT_UTF8: fb.start_table(0); type_tag = T_Utf8; return fb.end_table();
         case DT_LARGE_UTF8: fb.start_table(0); type_tag = T_LargeUtf8; return fb.end_table();
+        case DT_BINARY: fb.start_table(0); type_tag = T_Binary; return fb.end_table();
         case DT_BOOLEAN: fb.start_table(0); type_tag = T_Bool; return fb.end_table();
         case DT_DATE32:
         case DT_DATE64:
@@ -256,6 +257,7 @@ int read_type(uint8_t tag, const FbTable& t, const std::string& field_name) {
         }
         case T_Utf8: return DT_UTF8;
         case T_LargeUtf8: return DT_LARGE_UTF8;
+        case T_Binary: return DT_BINARY;
         case T_Bool: return DT_BOOLEAN;
         case T_Date: return t.scalar<int16_t>(0, 1) == 0 ? DT_DATE32 : DT_DATE64;
         case T_Timestamp:
@@ -271,7 +273,7 @@ uint32_t write_schema(Fb& fb, const Schema& s) {
     for (auto& f : s.fields) {
         const uint32_t name = fb.string(f.name);
         uint8_t tag = 0;
-        const uint32_t type = write_type(fb, f.large ? (int)DT_LARGE_UTF8 : f.dtype, tag);
+        const uint32_t type = write_type(fb, f.binary ? (int)DT_BINARY : f.large ? (int)DT_LARGE_UTF8 : f.dtype, tag);
         const uint32_t children = fb.offsets_vector({});
         fb.start_table(7);                                     // Field: name, nullable, type_type, type, dictionary, children, custom_metadata
         fb.add_offset(0, name);
@@ -301,6 +303,7 @@ SchemaPtr read_schema(const FbTable& st) {
         if (f.field(4)) fail(BHIP_ENOTIMPL, "Arrow IPC: dictionary-encoded column '" + fld.name + "'");
         fld.dtype = read_type(f.scalar<uint8_t>(2, 0), f.table(3), fld.name);
         if (fld.dtype == DT_LARGE_UTF8) { fld.dtype = DT_UTF8; fld.large = true; }
+        if (fld.dtype == DT_BINARY) { fld.dtype = DT_UTF8; fld.binary = true; }
         s->fields.push_back(fld);
     }
     return s;
@@ -410,7 +413,7 @@ SchemaPtr schema_of_c(const ArrowSchema& sch) {
         const ArrowSchema* c = sch.children[i];
         const int dt = dtype_from_format(c->format);
         if (!dt) fail(BHIP_ENOTIMPL, std::string("Arrow IPC: unsupported Arrow type '") + c->format + "' for column " + (c->name ? c->name : ""));
-        s->fields.push_back(Field{c->name ? c->name : "", dt == DT_LARGE_UTF8 ? (int)DT_UTF8 : dt, (c->flags & ARROW_FLAG_NULLABLE) != 0, dt == DT_LARGE_UTF8});
+        s->fields.push_back(Field{c->name ? c->name : "", (dt == DT_LARGE_UTF8 || dt == DT_BINARY) ? (int)DT_UTF8 : dt, (c->flags & ARROW_FLAG_NULLABLE) != 0, dt == DT_LARGE_UTF8, dt == DT_BINARY});
     }
     return s;
 }
@@ -668,7 +671,7 @@ void export_schema_c(const Schema& s, ArrowSchema* out) {
     for (size_t i = 0; i < s.fields.size(); ++i) {
         ArrowSchema& c = H->children[i];
         memset(&c, 0, sizeof(c));
-        c.format = format_of_dtype(s.fields[i].large ? (int)DT_LARGE_UTF8 : s.fields[i].dtype);
+        c.format = format_of_dtype(s.fields[i].binary ? (int)DT_BINARY : s.fields[i].large ? (int)DT_LARGE_UTF8 : s.fields[i].dtype);
         c.name = H->names[i].c_str();
         c.flags = s.fields[i].nullable ? ARROW_FLAG_NULLABLE : 0;
         c.release = release_schema_child;

@@ -45,7 +45,7 @@ HashAggregateExec::HashAggregateExec(int mode, std::vector<std::pair<ExprPtr, st
     auto s = std::make_shared<Schema>();
     for (auto& g : group_) {
         const int t = expr_type(g.first, in);
-        s->fields.push_back(Field{g.second, t, expr_nullable(g.first, in), t == DT_UTF8 && expr_large(g.first, in)});
+        s->fields.push_back(Field{g.second, t, expr_nullable(g.first, in), t == DT_UTF8 && expr_large(g.first, in), t == DT_UTF8 && expr_binary(g.first, in)});
     }
     size_t state_pos = group_.size();
     for (auto& a : aggr_) {

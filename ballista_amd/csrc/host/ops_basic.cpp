@@ -441,7 +441,7 @@ ProjectionExec::ProjectionExec(std::vector<std::pair<ExprPtr, std::string>> expr
     std::vector<ExprPtr> lowered;
     for (auto& en : exprs_) {
         const int t = expr_type(en.first, in);
-        s->fields.push_back(Field{en.second, t, expr_nullable(en.first, in), t == DT_UTF8 && expr_large(en.first, in)});
+        s->fields.push_back(Field{en.second, t, expr_nullable(en.first, in), t == DT_UTF8 && expr_large(en.first, in), t == DT_UTF8 && expr_binary(en.first, in)});
         lowered.push_back(low.rewrite(en.first, /*output=*/true));
     }
     low.validate();

@@ -122,7 +122,7 @@ int decode_arrow_type(Pb r, std::string* name_out) {
             case 13: dt = DT_FLOAT64; name = "Float64"; break;
             case 14: dt = DT_UTF8; name = "Utf8"; break;
             case 32: dt = DT_LARGE_UTF8; name = "LargeUtf8"; break;      // schemas only: decode_field turns it into Utf8 + Field::large
-            case 15: name = "Binary"; break;
+            case 15: dt = DT_BINARY; name = "Binary"; break;               // schemas only, as LargeUtf8
             case 17: dt = DT_DATE32; name = "Date32"; break;
             case 18: dt = DT_DATE64; name = "Date64"; break;
             case 20: {                                 // Timestamp{time_unit = 1, timezone = 2}
@@ -160,6 +160,7 @@ Field decode_field(Pb r) {
     }
     if (!fld.dtype) fail(BHIP_ENOTIMPL, "field '" + fld.name + "' has type " + tname + ", which the GPU path does not carry");
     if (fld.dtype == DT_LARGE_UTF8) { fld.dtype = DT_UTF8; fld.large = true; }
+    if (fld.dtype == DT_BINARY) { fld.dtype = DT_UTF8; fld.binary = true; }
     return fld;
 }
 
@@ -355,7 +356,7 @@ ExprPtr decode_expr(Pb r) {
                 uint32_t cf, cwt;
                 while (c.next(cf, cwt)) {
                     if (cf == 1 && cwt == 2) e->args = {decode_expr(c.sub())};
-                    else if (cf == 2 && cwt == 2) { e->dtype = decode_arrow_type(c.sub(), &tname); if (e->dtype == DT_LARGE_UTF8) e->dtype = 0; }
+                    else if (cf == 2 && cwt == 2) { e->dtype = decode_arrow_type(c.sub(), &tname); if (e->dtype == DT_LARGE_UTF8 || e->dtype == DT_BINARY) e->dtype = 0; }
                     else c.skip(cwt);
                 }
                 if (e->args.empty()) fail(BHIP_EINVAL, "protobuf: CastNode without an operand");

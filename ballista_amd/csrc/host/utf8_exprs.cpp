@@ -12,7 +12,7 @@
 namespace bhip {
 
 static bool produces_utf8(const ExprPtr& e, const Schema& schema) {
-    if (e->kind == BHIP_EXPR_SCALAR_FN) return str_fn(e->name) >= 0;
+    if (e->kind == BHIP_EXPR_SCALAR_FN) return str_fn(e->name) >= 0 || sha_fn(e->name) != 0;
     if (e->kind == BHIP_EXPR_CASE) return expr_type(e, schema) == DT_UTF8;
     return false;
 }
@@ -116,6 +116,24 @@ Column eval_transform(const Exec& ex, const Batch& in, const Expr& e) {
     return out;
 }
 
+// sha224 / sha256 / sha384 / sha512: fixed-length digests, one per row, NULL where the argument is
+Column eval_sha(const Exec& ex, const Batch& in, const Expr& e) {
+    const int bits = sha_fn(e.name);
+    const Column arg = eval_utf8(ex, in, e.args[0]);
+    const int64_t n = in.n_rows;
+    if ((uint64_t)n * (bits / 8) > 0x7FFFFFFFull) fail(BHIP_EEXEC, "Binary column exceeds 2 GiB of value bytes");
+    Column out;
+    out.dtype = DT_UTF8;
+    out.length = n;
+    out.offsets = make_buffer(ex, (size_t)(n + 1) * 4);
+    out.data_bytes = n * (bits / 8);
+    out.data = make_buffer(ex, (size_t)out.data_bytes + 8);
+    if (arg.validity) HIP_CHECK(hipMemsetAsync(out.data->ptr(), 0, (size_t)out.data_bytes + 8, ex.stream));    // a NULL row's bytes stay defined
+    TIMED_LAUNCH_N(ex, "sha2", n, launch_sha2(ex.cfg(), bits, arg.ref(), n, out.offsets->as<int32_t>(), out.data->as<uint8_t>()));
+    out.validity = arg.validity;
+    return out;
+}
+
 Column eval_case(const Exec& ex, const Batch& in, const Expr& e) {
     const size_t fw = e.has_base ? 1 : 0;
     const size_t np = (e.args.size() - fw - (e.has_else ? 1 : 0)) / 2;
@@ -170,6 +188,7 @@ Column eval_utf8(const Exec& ex, const Batch& in, const ExprPtr& e) {
             return eval_literal(ex, *e, in.n_rows);
         case BHIP_EXPR_SCALAR_FN:
             if (str_fn(e->name) >= 0) return eval_transform(ex, in, *e);
+            if (sha_fn(e->name)) return eval_sha(ex, in, *e);
             break;
         case BHIP_EXPR_CASE: return eval_case(ex, in, *e);
         default: break;
@@ -210,7 +229,7 @@ void Utf8Lowering::validate() const {
                 if (e->dtype != DT_UTF8) fail(BHIP_EINVAL, "expected a Utf8 literal");
                 break;
             case BHIP_EXPR_SCALAR_FN:
-                if (str_fn(e->name) < 0) fail(BHIP_ENOTIMPL, "expression producing Utf8: " + e->to_string());
+                if (str_fn(e->name) < 0 && !sha_fn(e->name)) fail(BHIP_ENOTIMPL, "expression producing Utf8: " + e->to_string());
                 walk(e->args[0]);
                 break;
             case BHIP_EXPR_CASE: {

@@ -135,6 +135,130 @@ str_select_write_kernel(StrSelectArgs A, int64_t n, const int32_t* out_offsets, 
     }
 }
 
+// ---- SHA-2 (FIPS 180-4) of every string: sha224 / sha256 / sha384 / sha512 (rust/core/src/serde/logical_plan/from_proto.rs:924-927) --
+// one thread per row, the message schedule kept as a 16-word ring; the digest (28 / 32 / 48 / 64 bytes, big-endian words) goes to
+// out + row * digest_bytes: fixed-stride Binary values (a NULL row's bytes are never read: validity says so)
+__device__ inline uint32_t rotr32(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+__device__ inline uint64_t rotr64(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
+__constant__ uint32_t SHA256_K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3,
+    0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+    0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13,
+    0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+    0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+    0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+__constant__ uint64_t SHA512_K[80] = {
+    0x428a2f98d728ae22ull, 0x7137449123ef65cdull, 0xb5c0fbcfec4d3b2full, 0xe9b5dba58189dbbcull, 0x3956c25bf348b538ull, 0x59f111f1b605d019ull,
+    0x923f82a4af194f9bull, 0xab1c5ed5da6d8118ull, 0xd807aa98a3030242ull, 0x12835b0145706fbeull, 0x243185be4ee4b28cull, 0x550c7dc3d5ffb4e2ull,
+    0x72be5d74f27b896full, 0x80deb1fe3b1696b1ull, 0x9bdc06a725c71235ull, 0xc19bf174cf692694ull, 0xe49b69c19ef14ad2ull, 0xefbe4786384f25e3ull,
+    0x0fc19dc68b8cd5b5ull, 0x240ca1cc77ac9c65ull, 0x2de92c6f592b0275ull, 0x4a7484aa6ea6e483ull, 0x5cb0a9dcbd41fbd4ull, 0x76f988da831153b5ull,
+    0x983e5152ee66dfabull, 0xa831c66d2db43210ull, 0xb00327c898fb213full, 0xbf597fc7beef0ee4ull, 0xc6e00bf33da88fc2ull, 0xd5a79147930aa725ull,
+    0x06ca6351e003826full, 0x142929670a0e6e70ull, 0x27b70a8546d22ffcull, 0x2e1b21385c26c926ull, 0x4d2c6dfc5ac42aedull, 0x53380d139d95b3dfull,
+    0x650a73548baf63deull, 0x766a0abb3c77b2a8ull, 0x81c2c92e47edaee6ull, 0x92722c851482353bull, 0xa2bfe8a14cf10364ull, 0xa81a664bbc423001ull,
+    0xc24b8b70d0f89791ull, 0xc76c51a30654be30ull, 0xd192e819d6ef5218ull, 0xd69906245565a910ull, 0xf40e35855771202aull, 0x106aa07032bbd1b8ull,
+    0x19a4c116b8d2d0c8ull, 0x1e376c085141ab53ull, 0x2748774cdf8eeb99ull, 0x34b0bcb5e19b48a8ull, 0x391c0cb3c5c95a63ull, 0x4ed8aa4ae3418acbull,
+    0x5b9cca4f7763e373ull, 0x682e6ff3d6b2b8a3ull, 0x748f82ee5defb2fcull, 0x78a5636f43172f60ull, 0x84c87814a1f0ab72ull, 0x8cc702081a6439ecull,
+    0x90befffa23631e28ull, 0xa4506cebde82bde9ull, 0xbef9a3f7b2c67915ull, 0xc67178f2e372532bull, 0xca273eceea26619cull, 0xd186b8c721c0c207ull,
+    0xeada7dd6cde0eb1eull, 0xf57d4f7fee6ed178ull, 0x06f067aa72176fbaull, 0x0a637dc5a2c898a6ull, 0x113f9804bef90daeull, 0x1b710b35131c471bull,
+    0x28db77f523047d84ull, 0x32caab7b40c72493ull, 0x3c9ebe0a15c9bebcull, 0x431d67c49c100d4cull, 0x4cc5d4becb3e42b6ull, 0x597f299cfc657e2aull,
+    0x5fcb6fab3ad6faecull, 0x6c44198c4a475817ull};
+
+// byte `i` of the padded message: the string, 0x80, zeros, the bit length as a big-endian integer in the last `len_bytes` bytes
+__device__ inline uint32_t sha_msg_byte(const uint8_t* s, uint64_t len, uint64_t total, int len_bytes, uint64_t i) {
+    if (i < len) return s[i];
+    if (i == len) return 0x80u;
+    if (i + (uint64_t)len_bytes < total) return 0u;
+    const uint64_t k = total - 1 - i;                       // 0 = least significant byte of the length field
+    return k < 8 ? (uint32_t)(((len * 8) >> (8 * k)) & 0xFF) : 0u;
+}
+
+__global__ void __launch_bounds__(BLOCK)
+sha256_kernel(int bits, ColumnRef c, int64_t n, uint8_t* out) {
+    const int digest = bits / 8;
+    for (int64_t row = (int64_t)blockIdx.x * BLOCK + threadIdx.x; row < n; row += (int64_t)gridDim.x * BLOCK) {
+        if (!bit_at(c.validity, row)) continue;
+        const uint8_t* s = reinterpret_cast<const uint8_t*>(c.data) + c.offsets[row];
+        const uint64_t len = (uint64_t)(c.offsets[row + 1] - c.offsets[row]);
+        const uint64_t total = ((len + 1 + 8 + 63) / 64) * 64;
+        uint32_t h[8];
+        if (bits == 224) { h[0] = 0xc1059ed8; h[1] = 0x367cd507; h[2] = 0x3070dd17; h[3] = 0xf70e5939; h[4] = 0xffc00b31; h[5] = 0x68581511; h[6] = 0x64f98fa7; h[7] = 0xbefa4fa4; }
+        else { h[0] = 0x6a09e667; h[1] = 0xbb67ae85; h[2] = 0x3c6ef372; h[3] = 0xa54ff53a; h[4] = 0x510e527f; h[5] = 0x9b05688c; h[6] = 0x1f83d9ab; h[7] = 0x5be0cd19; }
+        for (uint64_t b0 = 0; b0 < total; b0 += 64) {
+            uint32_t w[16];
+            for (int t = 0; t < 16; ++t) {
+                uint32_t x = 0;
+                for (int k = 0; k < 4; ++k) x = (x << 8) | sha_msg_byte(s, len, total, 8, b0 + 4 * t + k);
+                w[t] = x;
+            }
+            uint32_t a = h[0], b = h[1], cc = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+            for (int t = 0; t < 64; ++t) {
+                if (t >= 16) {
+                    const uint32_t w15 = w[(t - 15) & 15], w2 = w[(t - 2) & 15];
+                    const uint32_t s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3), s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
+                    w[t & 15] = w[t & 15] + s0 + w[(t - 7) & 15] + s1;
+                }
+                const uint32_t S1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25), ch = (e & f) ^ (~e & g);
+                const uint32_t t1 = hh + S1 + ch + SHA256_K[t] + w[t & 15];
+                const uint32_t S0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22), mj = (a & b) ^ (a & cc) ^ (b & cc);
+                const uint32_t t2 = S0 + mj;
+                hh = g; g = f; f = e; e = d + t1; d = cc; cc = b; b = a; a = t1 + t2;
+            }
+            h[0] += a; h[1] += b; h[2] += cc; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+        }
+        uint8_t* o = out + row * digest;
+        for (int k = 0; k < digest; ++k) o[k] = (uint8_t)(h[k >> 2] >> (8 * (3 - (k & 3))));
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK)
+sha512_kernel(int bits, ColumnRef c, int64_t n, uint8_t* out) {
+    const int digest = bits / 8;
+    for (int64_t row = (int64_t)blockIdx.x * BLOCK + threadIdx.x; row < n; row += (int64_t)gridDim.x * BLOCK) {
+        if (!bit_at(c.validity, row)) continue;
+        const uint8_t* s = reinterpret_cast<const uint8_t*>(c.data) + c.offsets[row];
+        const uint64_t len = (uint64_t)(c.offsets[row + 1] - c.offsets[row]);
+        const uint64_t total = ((len + 1 + 16 + 127) / 128) * 128;
+        uint64_t h[8];
+        if (bits == 384) {
+            h[0] = 0xcbbb9d5dc1059ed8ull; h[1] = 0x629a292a367cd507ull; h[2] = 0x9159015a3070dd17ull; h[3] = 0x152fecd8f70e5939ull;
+            h[4] = 0x67332667ffc00b31ull; h[5] = 0x8eb44a8768581511ull; h[6] = 0xdb0c2e0d64f98fa7ull; h[7] = 0x47b5481dbefa4fa4ull;
+        } else {
+            h[0] = 0x6a09e667f3bcc908ull; h[1] = 0xbb67ae8584caa73bull; h[2] = 0x3c6ef372fe94f82bull; h[3] = 0xa54ff53a5f1d36f1ull;
+            h[4] = 0x510e527fade682d1ull; h[5] = 0x9b05688c2b3e6c1full; h[6] = 0x1f83d9abfb41bd6bull; h[7] = 0x5be0cd19137e2179ull;
+        }
+        for (uint64_t b0 = 0; b0 < total; b0 += 128) {
+            uint64_t w[16];
+            for (int t = 0; t < 16; ++t) {
+                uint64_t x = 0;
+                for (int k = 0; k < 8; ++k) x = (x << 8) | sha_msg_byte(s, len, total, 16, b0 + 8 * t + k);
+                w[t] = x;
+            }
+            uint64_t a = h[0], b = h[1], cc = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+            for (int t = 0; t < 80; ++t) {
+                if (t >= 16) {
+                    const uint64_t w15 = w[(t - 15) & 15], w2 = w[(t - 2) & 15];
+                    const uint64_t s0 = rotr64(w15, 1) ^ rotr64(w15, 8) ^ (w15 >> 7), s1 = rotr64(w2, 19) ^ rotr64(w2, 61) ^ (w2 >> 6);
+                    w[t & 15] = w[t & 15] + s0 + w[(t - 7) & 15] + s1;
+                }
+                const uint64_t S1 = rotr64(e, 14) ^ rotr64(e, 18) ^ rotr64(e, 41), ch = (e & f) ^ (~e & g);
+                const uint64_t t1 = hh + S1 + ch + SHA512_K[t] + w[t & 15];
+                const uint64_t S0 = rotr64(a, 28) ^ rotr64(a, 34) ^ rotr64(a, 39), mj = (a & b) ^ (a & cc) ^ (b & cc);
+                const uint64_t t2 = S0 + mj;
+                hh = g; g = f; f = e; e = d + t1; d = cc; cc = b; b = a; a = t1 + t2;
+            }
+            h[0] += a; h[1] += b; h[2] += cc; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+        }
+        uint8_t* o = out + row * digest;
+        for (int k = 0; k < digest; ++k) o[k] = (uint8_t)(h[k >> 3] >> (8 * (7 - (k & 7))));
+    }
+}
+
+// offsets of n fixed-length values
+__global__ void __launch_bounds__(BLOCK)
+fixed_offsets_kernel(int32_t stride, int64_t n, int32_t* offsets) {
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i <= n; i += (int64_t)gridDim.x * BLOCK) offsets[i] = (int32_t)(i * stride);
+}
+
 // rank[perm[i]] = i  (the position of every row in a sort order: MIN / MAX over Utf8 become MIN / MAX over Int64 ranks)
 __global__ void __launch_bounds__(BLOCK)
 invert_perm_kernel(const uint32_t* perm, int64_t n, int64_t* rank) {
@@ -176,6 +300,14 @@ hipError_t launch_str_select_lengths(const LaunchCfg& cfg, const StrSelectArgs& 
 hipError_t launch_str_select_write(const LaunchCfg& cfg, const StrSelectArgs& A, int64_t n, const int32_t* out_offsets, uint8_t* out) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(str_select_write_kernel, dim3(grid_of(cfg, n)), dim3(BLOCK), 0, cfg.stream, A, n, out_offsets, out);
+    return hipGetLastError();
+}
+hipError_t launch_sha2(const LaunchCfg& cfg, int bits, const ColumnRef& c, int64_t n, int32_t* out_offsets, uint8_t* out) {
+    if (bits != 224 && bits != 256 && bits != 384 && bits != 512) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fixed_offsets_kernel, dim3(grid_of(cfg, n + 1)), dim3(BLOCK), 0, cfg.stream, bits / 8, n, out_offsets);
+    if (n == 0) return hipGetLastError();
+    if (bits <= 256) hipLaunchKernelGGL(sha256_kernel, dim3(grid_of(cfg, n)), dim3(BLOCK), 0, cfg.stream, bits, c, n, out);
+    else hipLaunchKernelGGL(sha512_kernel, dim3(grid_of(cfg, n)), dim3(BLOCK), 0, cfg.stream, bits, c, n, out);
     return hipGetLastError();
 }
 hipError_t launch_invert_perm(const LaunchCfg& cfg, const uint32_t* perm, int64_t n, int64_t* rank) {

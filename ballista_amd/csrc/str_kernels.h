@@ -29,6 +29,9 @@ struct StrSelectArgs {
 hipError_t launch_str_select_lengths(const LaunchCfg& cfg, const StrSelectArgs& A, int64_t n, uint32_t* lengths, uint64_t* validity);
 hipError_t launch_str_select_write(const LaunchCfg& cfg, const StrSelectArgs& A, int64_t n, const int32_t* out_offsets, uint8_t* out);
 
+// sha224 / sha256 / sha384 / sha512 of every string: n digests of bits / 8 bytes at out + row * (bits / 8), offsets written too
+hipError_t launch_sha2(const LaunchCfg& cfg, int bits, const ColumnRef& c, int64_t n, int32_t* out_offsets, uint8_t* out);
+
 // MIN / MAX over Utf8 through sort ranks
 hipError_t launch_invert_perm(const LaunchCfg& cfg, const uint32_t* perm, int64_t n, int64_t* rank);
 hipError_t launch_rank_to_row(const LaunchCfg& cfg, const int64_t* rank, const uint64_t* validity, const uint32_t* perm, int64_t n, uint32_t* idx);

@@ -23,6 +23,7 @@ enum DType : int32_t {
     DT_INT8 = 9, DT_INT16 = 10, DT_UINT16 = 11, DT_UINT32 = 12, DT_FLOAT32 = 13, DT_DATE64 = 14,
     DT_TIMESTAMP_S = 15, DT_TIMESTAMP_MS = 16, DT_TIMESTAMP_US = 17, DT_TIMESTAMP_NS = 18,
     DT_LAST = 18,
+    DT_BINARY = 20,          // boundary only (schemas): variable-length bytes in the layout of Utf8 (host/core.hpp Field::binary)
     DT_LARGE_UTF8 = 19       // boundary only (schemas): a Utf8 device column whose Arrow form has 64-bit offsets (host/core.hpp Field::large)
 };
 

@@ -26,6 +26,7 @@ FLOAT64, DATE32, BOOLEAN, UTF8 = "Float64", "Date32", "Boolean", "Utf8"
 INT8, INT16, UINT16, UINT32, FLOAT32, DATE64 = "Int8", "Int16", "UInt16", "UInt32", "Float32", "Date64"
 TIMESTAMP_S, TIMESTAMP_MS = "Timestamp(Second)", "Timestamp(Millisecond)"
 TIMESTAMP_US, TIMESTAMP_NS = "Timestamp(Microsecond)", "Timestamp(Nanosecond)"
+BINARY = "Binary"              # schemas only: variable-length bytes (the sha* digests) in the buffer layout of Utf8
 LARGE_UTF8 = "LargeUtf8"       # schemas only (Arrow / IPC form of a Utf8 device column with 64-bit offsets)
 ALL_TYPES = (INT32, INT64, UINT8, UINT64, FLOAT64, DATE32, BOOLEAN, UTF8, INT8, INT16, UINT16, UINT32, FLOAT32, DATE64,
              TIMESTAMP_S, TIMESTAMP_MS, TIMESTAMP_US, TIMESTAMP_NS)
@@ -39,7 +40,9 @@ MATH_FUNCTIONS = ("sqrt", "abs", "floor", "ceil", "round", "trunc", "signum",
                   "exp", "ln", "log2", "log10", "sin", "cos", "tan", "asin", "acos", "atan")
 # Utf8 -> Utf8 (rust/core/src/serde/logical_plan/from_proto.rs:914-918) and Utf8 -> Int32 (:910)
 STRING_FUNCTIONS = ("lower", "upper", "trim", "ltrim", "rtrim")
-SCALAR_FUNCTIONS = MATH_FUNCTIONS + STRING_FUNCTIONS + ("octet_length",)
+# Utf8 -> Binary digests (from_proto.rs:924-927)
+SHA_FUNCTIONS = ("sha224", "sha256", "sha384", "sha512")
+SCALAR_FUNCTIONS = MATH_FUNCTIONS + STRING_FUNCTIONS + SHA_FUNCTIONS + ("octet_length",)
 
 
 class PhysicalExpr:
@@ -227,7 +230,7 @@ def expr_type(e: PhysicalExpr, schema: dict) -> str:
     if isinstance(e, NegativeExpr):
         return expr_type(e.expr, schema)
     if isinstance(e, ScalarFunctionExpr):
-        return UTF8 if e.fun in STRING_FUNCTIONS else INT32 if e.fun == "octet_length" else FLOAT64
+        return UTF8 if e.fun in STRING_FUNCTIONS else BINARY if e.fun in SHA_FUNCTIONS else INT32 if e.fun == "octet_length" else FLOAT64
     raise TypeError(f"not a PhysicalExpr: {e!r}")
 
 

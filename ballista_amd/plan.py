@@ -22,7 +22,7 @@ DTYPE_ID = {E.INT32: 1, E.INT64: 2, E.UINT8: 3, E.UINT64: 4, E.FLOAT64: 5, E.DAT
             "Int8": 9, "Int16": 10, "UInt16": 11, "UInt32": 12, "Float32": 13, "Date64": 14, "Timestamp(Second)": 15,
             "Timestamp(Millisecond)": 16, "Timestamp(Microsecond)": 17, "Timestamp(Nanosecond)": 18,
             # schemas only: a Utf8 column whose Arrow / IPC form has 64-bit offsets (on the device it is Utf8)
-            "LargeUtf8": 19}
+            "LargeUtf8": 19, "Binary": 20}
 DTYPE_NAME = {v: k for k, v in DTYPE_ID.items()}
 NP_DTYPE = {E.INT32: np.int32, E.INT64: np.int64, E.UINT8: np.uint8, E.UINT64: np.uint64,
             E.FLOAT64: np.float64, E.DATE32: np.int32, E.INT8: np.int8, E.INT16: np.int16, E.UINT16: np.uint16,

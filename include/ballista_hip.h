@@ -101,7 +101,9 @@ typedef enum {
     BHIP_INT8 = 9, BHIP_INT16 = 10, BHIP_UINT16 = 11, BHIP_UINT32 = 12, BHIP_FLOAT32 = 13, BHIP_DATE64 = 14,
     BHIP_TIMESTAMP_S = 15, BHIP_TIMESTAMP_MS = 16, BHIP_TIMESTAMP_US = 17, BHIP_TIMESTAMP_NS = 18,
     /* schemas only: a Utf8 column whose Arrow / IPC form is LargeUtf8 (64-bit offsets); on the device it is BHIP_UTF8 */
-    BHIP_LARGE_UTF8 = 19
+    BHIP_LARGE_UTF8 = 19,
+    /* schemas only: variable-length bytes (the digests of sha224 .. sha512) in the buffer layout of BHIP_UTF8 */
+    BHIP_BINARY = 20
 } bhip_dtype;
 
 typedef struct bhip_ctx bhip_ctx;        /* one GPU: allocator, stream pool */

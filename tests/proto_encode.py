@@ -59,7 +59,7 @@ def f_packed(field, vals):
 
 # ArrowType oneof field numbers (ballista.proto:755-790); EmptyMessage payloads
 ARROW_TYPE_FIELD = {"Boolean": 2, "UInt8": 3, "Int8": 4, "UInt16": 5, "Int16": 6, "UInt32": 7, "Int32": 8, "UInt64": 9, "Int64": 10,
-                    "Float32": 12, "Float64": 13, "Utf8": 14, "LargeUtf8": 32, "Binary": 15, "Date32": 17, "Date64": 18}
+                    "Float32": 12, "Float64": 13, "Utf8": 14, "LargeUtf8": 32, "Binary": 15, "Float16": 11, "Date32": 17, "Date64": 18}
 
 
 def arrow_type(t: str) -> bytes:

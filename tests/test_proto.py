@@ -173,12 +173,12 @@ def test_leaf_kinds_and_their_descriptions():
 def test_types_of_the_whole_serde_surface():
     """ArrowType variants of ballista.proto:755-790 the library carries"""
     names = ["Boolean", "UInt8", "Int8", "UInt16", "Int16", "UInt32", "Int32", "UInt64", "Int64", "Float32", "Float64", "Utf8", "Date32", "Date64",
-             "Timestamp(Second)", "Timestamp(Millisecond)", "Timestamp(Microsecond)", "Timestamp(Nanosecond)", "LargeUtf8"]
+             "Timestamp(Second)", "Timestamp(Millisecond)", "Timestamp(Microsecond)", "Timestamp(Nanosecond)", "LargeUtf8", "Binary"]
     fields = [(f"c{i}", t, i % 2 == 0) for i, t in enumerate(names)]
     p = ba.ExecutionPlan.from_proto(None, pe.unresolved_shuffle([1], fields, 1))
     assert p.schema() == fields
-    with pytest.raises(ba.NotImplementedOnGpu, match="Binary"):
-        ba.ExecutionPlan.from_proto(None, pe.unresolved_shuffle([1], [("x", "Binary", True)], 1))
+    with pytest.raises(ba.NotImplementedOnGpu, match="Float16"):
+        ba.ExecutionPlan.from_proto(None, pe.unresolved_shuffle([1], [("x", "Float16", True)], 1))
 
 
 def test_malformed_and_unsupported_plans_are_errors_not_crashes(nodes_tpch):

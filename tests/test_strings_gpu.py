@@ -124,3 +124,34 @@ def test_string_functions_through_the_wire_plan(ctx):
     assert decoded.display() == direct.display()
     got = helpers.concat([helpers.from_device(x) for x in decoded.collect()])
     helpers.assert_rows_equal(got, plan_eval.collect(direct), ordered=True)
+
+
+@pytest.mark.parametrize("n", [1, 777])
+def test_sha2_digests(ctx, tmp_path, n):
+    """sha224 / sha256 / sha384 / sha512 (from_proto.rs:924-927) against hashlib: messages of every padding class (0, 55, 56, 63, 64,
+    111, 112, 119, 120, 128 bytes and longer), NULLs, non-ASCII bytes; the result is a Binary column at the boundary"""
+    import hashlib
+    import pyarrow as pa
+    rng = np.random.default_rng(n)
+    lens = [0, 1, 55, 56, 57, 63, 64, 65, 111, 112, 113, 119, 120, 127, 128, 129, 300]
+    vals = [("é" * 200 + "x" * 200)[:lens[i % len(lens)]] if i % 2 else "abc" * (lens[i % len(lens)] // 3 + 1) for i in range(n)]
+    vals = [v[:lens[i % len(lens)]] for i, v in enumerate(vals)]
+    b = OrderedDict([("s", OCol("Utf8", vals, (rng.random(n) > 0.15) if n > 1 else None)), ("k", OCol("Int32", np.arange(n, dtype=np.int32)))])
+    m = helpers.memory_exec(ctx, [[b]])
+    fns = ["sha224", "sha256", "sha384", "sha512"]
+    plan = ba.ProjectionExec([(fn(f, col("s")), f) for f in fns] + [(col("k"), "k")], m)
+    assert [t for _, t, _ in plan.schema()] == ["Binary"] * 4 + ["Int32"]
+    got = pa.Table.from_batches([x.to_pyarrow() for x in plan.collect()])
+    ok = b["s"].is_valid()
+    for f in fns:
+        assert got.schema.field(f).type == pa.binary()
+        want = [getattr(hashlib, f)(v.encode()).digest() if k else None for v, k in zip(vals, ok)]
+        assert got[f].to_pylist() == want, f
+    # the digests travel through a stage file as Binary
+    path = str(tmp_path / "digests.arrow")
+    plan.execute(0).write_ipc(path)
+    back = pa.ipc.open_file(path).read_all()
+    assert back.schema.field("sha256").type == pa.binary() and back.equals(got)
+    # and a filter can compare them (byte order, as Utf8 columns compare)
+    flt = ba.FilterExec(E.IsNotNullExpr(col("sha256")), ba.IpcFileExec([path], ctx))
+    assert sum(x.num_rows for x in flt.collect()) == int(np.sum(ok))
