@@ -98,7 +98,13 @@ struct Thrift {
 enum { PQ_BOOLEAN = 0, PQ_INT32 = 1, PQ_INT64 = 2, PQ_INT96 = 3, PQ_FLOAT = 4, PQ_DOUBLE = 5, PQ_BYTE_ARRAY = 6, PQ_FIXED = 7 };
 enum { ENC_PLAIN = 0, ENC_PLAIN_DICT = 2, ENC_RLE = 3, ENC_BIT_PACKED = 4, ENC_RLE_DICT = 8 };
 
-struct PqColumn { std::string name; int phys = -1, converted = -1, repetition = 0, dtype = 0; bool logical_date = false, logical_string = false; };
+struct PqColumn {
+    std::string name;
+    int phys = -1, converted = -1, repetition = 0;
+    int dtype = 0;          // the type the pages decode to (INT32 pages annotated INT_8 .. UINT_16 decode as Int32 ...)
+    int out_dtype = 0;      // ... and are narrowed to this column type afterwards (launch_narrow_i32); else == dtype
+    bool logical_date = false, logical_string = false;
+};
 struct PqChunk { int codec = 0; int64_t num_values = 0, data_off = 0, dict_off = -1, compressed = 0; };
 struct PqRowGroup { int64_t num_rows = 0; std::vector<PqChunk> cols; };
 struct PqFile { std::string path; std::vector<PqColumn> cols; std::vector<PqRowGroup> groups; int64_t num_rows = 0; };
@@ -211,7 +217,11 @@ PqFile read_footer(const std::string& path) {
                 if (c.logical_date || c.converted == 6) c.dtype = DT_DATE32;
                 else if (c.converted == -1 || c.converted == 17) c.dtype = DT_INT32;       // none / INT_32
                 else if (c.converted == 13) c.dtype = DT_UINT32;                           // UINT_32: the same four bytes
-                break;                                                                     // (INT_8/16, UINT_8/16 would need a narrowing pass: declined)
+                else if (c.converted == 15 || c.converted == 16 || c.converted == 11 || c.converted == 12) {
+                    c.dtype = DT_INT32;                                                    // INT_8 / INT_16 / UINT_8 / UINT_16: four-byte pages, narrowed after the decode
+                    c.out_dtype = c.converted == 15 ? DT_INT8 : c.converted == 16 ? DT_INT16 : c.converted == 11 ? DT_UINT8 : DT_UINT16;
+                }
+                break;
             case PQ_INT64:
                 if (c.converted == -1 || c.converted == 18) c.dtype = DT_INT64;           // none / INT_64
                 else if (c.converted == 14) c.dtype = DT_UINT64;                          // UINT_64
@@ -223,6 +233,7 @@ PqFile read_footer(const std::string& path) {
             case PQ_BYTE_ARRAY: c.dtype = DT_UTF8; break;
             default: break;
         }
+        if (!c.out_dtype) c.out_dtype = c.dtype;
     }
     return F;
 }
@@ -643,11 +654,11 @@ public:
             if (i >= first.cols.size()) fail(BHIP_EINVAL, "Parquet projection index " + std::to_string(i) + " is out of range");
             const PqColumn& c = first.cols[i];
             if (!c.dtype) fail(BHIP_ENOTIMPL, "Parquet: column '" + c.name + "' has a type outside the GPU path (physical " + std::to_string(c.phys) + ")");
-            s->fields.push_back(Field{c.name, c.dtype, c.repetition == 1});
+            s->fields.push_back(Field{c.name, c.out_dtype, c.repetition == 1});
         }
         for (auto& f : files_)
             for (uint32_t i : proj_)
-                if (i >= f.cols.size() || f.cols[i].name != first.cols[i].name || f.cols[i].dtype != first.cols[i].dtype)
+                if (i >= f.cols.size() || f.cols[i].name != first.cols[i].name || f.cols[i].out_dtype != first.cols[i].out_dtype)
                     fail(BHIP_EINVAL, "Parquet: " + f.path + " does not have the schema of " + first.path);
         schema_ = s;
         // files are dealt out in chunks, as ParquetExec::try_from_files splits them over max_concurrency partitions
@@ -688,7 +699,15 @@ public:
                     b->n_rows = g.num_rows;
                     for (uint32_t ci : self->proj_) {
                         if (ci >= g.cols.size()) fail(BHIP_EEXEC, "Parquet: row group without column " + std::to_string(ci));
-                        b->cols.push_back(decode_chunk(ex, in, F.cols[ci], g.cols[ci], g.num_rows));
+                        Column col = decode_chunk(ex, in, F.cols[ci], g.cols[ci], g.num_rows);
+                        if (F.cols[ci].out_dtype != F.cols[ci].dtype) {                   // Int32 values of an INT_8 .. UINT_16 column
+                            Column narrow = col;
+                            narrow.dtype = F.cols[ci].out_dtype;
+                            narrow.data = make_buffer(ex, (size_t)col.length * dtype_width(narrow.dtype) + 8);
+                            TIMED_LAUNCH_N(ex, "narrow_i32", col.length, launch_narrow_i32(ex.cfg(), col.data->as<int32_t>(), col.length, dtype_width(narrow.dtype), narrow.data->ptr()));
+                            col = narrow;
+                        }
+                        b->cols.push_back(col);
                     }
                     out.push_back(b);
                 }

@@ -378,6 +378,20 @@ hipError_t launch_take_fixed(const LaunchCfg& cfg, const void* src, int width, c
     return hipGetLastError();
 }
 
+// four-byte integers -> their low 1 or 2 bytes (Parquet INT32 pages of INT_8 / INT_16 / UINT_8 / UINT_16 columns)
+__global__ void __launch_bounds__(BLOCK)
+narrow_i32_kernel(const int32_t* src, int64_t n, int width, void* dst) {
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+        if (width == 1) static_cast<uint8_t*>(dst)[i] = (uint8_t)src[i];
+        else static_cast<uint16_t*>(dst)[i] = (uint16_t)src[i];
+    }
+}
+hipError_t launch_narrow_i32(const LaunchCfg& cfg, const int32_t* src, int64_t n, int width, void* dst) {
+    if (n == 0) return hipSuccess;
+    if (width != 1 && width != 2) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(narrow_i32_kernel, dim3(grid_for(cfg, n)), dim3(BLOCK), 0, cfg.stream, src, n, width, dst);
+    return hipGetLastError();
+}
 hipError_t launch_compose_indices(const LaunchCfg& cfg, const uint32_t* inner, const uint32_t* idx, int64_t n, uint32_t* out) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(compose_indices_kernel, dim3(grid_for(cfg, n)), dim3(BLOCK), 0, cfg.stream, inner, idx, n, out);

@@ -35,6 +35,7 @@ hipError_t launch_take_fixed(const LaunchCfg& cfg, const void* src, int width, c
 hipError_t launch_take_bitmap(const LaunchCfg& cfg, const uint64_t* src, const uint32_t* idx, int64_t n, uint64_t* dst);
 hipError_t launch_take_utf8_lengths(const LaunchCfg& cfg, const int32_t* offsets, const uint32_t* idx, int64_t n,
                                     uint32_t* lengths);
+hipError_t launch_narrow_i32(const LaunchCfg& cfg, const int32_t* src, int64_t n, int width, void* dst);
 hipError_t launch_compose_indices(const LaunchCfg& cfg, const uint32_t* inner, const uint32_t* idx, int64_t n, uint32_t* out);
 hipError_t launch_take_utf8_copy(const LaunchCfg& cfg, const int32_t* src_off, const uint8_t* src, int64_t src_bytes, const uint32_t* idx,
                                  int64_t n, const int32_t* dst_off, uint8_t* dst);

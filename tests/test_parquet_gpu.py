@@ -147,17 +147,19 @@ def test_float32_uint32_and_timestamp_columns(ctx, tmp_path, use_dictionary):
                   "u32": pa.array(rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)),
                   "tms": pa.array(rng.integers(0, 2 ** 41, n), pa.int64()).cast(pa.timestamp("ms")),
                   "tus": pa.array(rng.integers(0, 2 ** 51, n), mask=mask, type=pa.int64()).cast(pa.timestamp("us")),
-                  "few": pa.array(rng.integers(0, 5, n).astype(np.float32))})
+                  "few": pa.array(rng.integers(0, 5, n).astype(np.float32)),
+                  "i8": pa.array(rng.integers(-128, 128, n).astype(np.int8), mask=mask), "u8": pa.array(rng.integers(0, 256, n).astype(np.uint8)),
+                  "i16": pa.array(rng.integers(-2 ** 15, 2 ** 15, n).astype(np.int16)), "u16": pa.array(rng.integers(0, 2 ** 16, n).astype(np.uint16), mask=mask)})
     p = str(tmp_path / "more_types.parquet")
     pq.write_table(t, p, use_dictionary=use_dictionary, row_group_size=7000, data_page_size=4096)
     plan, got = read_back(ctx, [p])
-    assert [ty for _, ty, _ in plan.schema()] == ["Float32", "UInt32", "Timestamp(Millisecond)", "Timestamp(Microsecond)", "Float32"]
+    assert [ty for _, ty, _ in plan.schema()] == ["Float32", "UInt32", "Timestamp(Millisecond)", "Timestamp(Microsecond)", "Float32", "Int8", "UInt8", "Int16", "UInt16"]
     same(got, t)
 
 
 def test_what_is_outside_the_path_is_refused(ctx, tmp_path):
-    t = pa.table({"x": pa.array(np.arange(1000, dtype=np.int8))})          # INT32 pages annotated INT_8: would need a narrowing pass
-    p = str(tmp_path / "i8.parquet")
+    t = pa.table({"x": pa.array(np.arange(1000, dtype=np.float16))})
+    p = str(tmp_path / "f16.parquet")
     pq.write_table(t, p)
     with pytest.raises(ba.NotImplementedOnGpu, match="type outside the GPU path"):
         ba.ParquetExec([p], ctx)
