@@ -169,8 +169,12 @@ int HashJoinExec::narrow_key_width() const {
 
 // A child of a join, executed so that the columns this join only passes on (everything but its keys) may arrive as views: the
 // child is a HashJoinExec, or a projection of plain columns over one (the shape of TPC-H's join chains).  Anything else: execute().
-static StreamPtr open_join_child(const PlanPtr& child, int partition, const Exec& ex, const std::vector<std::string>& key_names) {
+static bool join_views_disabled() {
     static const bool no_views = [] { const char* v = getenv("BHIP_NO_JOIN_VIEWS"); return v && atoi(v) != 0; }();
+    return no_views;
+}
+static StreamPtr open_join_child(const PlanPtr& child, int partition, const Exec& ex, const std::vector<std::string>& key_names) {
+    const bool no_views = join_views_disabled();
     auto is_key = [&](const std::string& n) { return std::find(key_names.begin(), key_names.end(), n) != key_names.end(); };
     if (no_views) return child->execute(partition, ex);
     if (auto hj = dynamic_cast<const HashJoinExec*>(child.get())) {
@@ -728,7 +732,19 @@ StreamPtr HashJoinExec::execute_needed(int partition, const Exec& ex, const std:
                 key_schema->fields.push_back(out_schema->fields[j]);
                 key_src.push_back(chain.src_of[j]);
             }
-            auto ss = chain.src->execute(partition, ex);
+            // a join below (no filter in between): only the columns read here, and everything but the keys may arrive as views
+            StreamPtr ss;
+            auto src_hj = dynamic_cast<const HashJoinExec*>(chain.src.get());
+            if (src_hj && !chain.pred && !join_views_disabled()) {
+                const size_t n_src = chain.src->schema()->fields.size();
+                std::vector<bool> need(n_src, false), defer(n_src, true);
+                for (size_t k = 0; k < self->right_cols_.size(); ++k)
+                    if (needed[n_lcols + k]) need[rmap[k]] = true;
+                for (int ci : key_src) { need[ci] = true; defer[ci] = false; }
+                ss = src_hj->execute_needed(partition, ex, need, defer);
+            } else {
+                ss = chain.src->execute(partition, ex);
+            }
             while (BatchPtr b = ss->next()) {
                 if (b->n_rows == 0) continue;
                 ProbeFilter F;

@@ -92,7 +92,7 @@ def test_two_four_byte_keys(ctx, jt, unique, nulls, filtered):
 
 @pytest.mark.parametrize("jt_top", JOIN_TYPES)
 @pytest.mark.parametrize("jt_mid", JOIN_TYPES)
-@pytest.mark.parametrize("shape", ["probe_chain", "build_chain"])
+@pytest.mark.parametrize("shape", ["probe_chain", "probe_direct", "build_chain"])
 def test_payload_columns_pass_through_joins_as_views(ctx, jt_top, jt_mid, shape):
     """three joins in a row with column projections between them (the shape of TPC-H Q3 / Q5): a column a join only passes on
     travels as (source column, row indices) and is gathered once, by the last join — through Inner / Left / Right joins (NULL
@@ -112,6 +112,9 @@ def test_payload_columns_pass_through_joins_as_views(ctx, jt_top, jt_mid, shape)
         j2 = proj(["aname", "bflag", "cx", "cs", "c_dk"], ba.HashJoinExec(j1, C, [("bk", "c_bk")], jt_mid))    # (a b) |x| c: j1 is the BUILD side
         top = ba.HashJoinExec(D, j2, [("dk", "c_dk")], jt_top)                                          # d |x| (a b c): j2 is the PROBE side
         keys = ["dk", "c_dk", "cx", "cs", "aname"]
+    elif shape == "probe_direct":
+        top = ba.HashJoinExec(D, ba.HashJoinExec(j1, C, [("bk", "c_bk")], jt_mid), [("dk", "c_dk")], jt_top)    # Q5's supplier join: no projection between
+        keys = ["dk", "c_dk", "cx", "cs", "aname", "bk"]
     else:
         j2 = proj(["c_dk", "aname", "cx", "bflag"], ba.HashJoinExec(j1, C, [("bk", "c_bk")], jt_mid))
         top = ba.HashJoinExec(j2, D, [("c_dk", "dk")], jt_top)                                          # (a b c) |x| d: j2 is the BUILD side
