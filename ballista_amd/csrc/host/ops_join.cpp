@@ -228,8 +228,10 @@ std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) co
         while (BatchPtr b = s->next())
             if (b->n_rows > 0) parts.push_back(b);
     }
-    if (parts.size() > 1)
-        for (auto& b : parts) b = materialize_batch(ex, b);       // concat works on ordinary columns
+    // concat works on ordinary columns; and a small build side (Q5: the five nations of a region) is gathered here, once, so that
+    // all its columns travel on as views over ONE index vector (a view in, a view out: one more index vector to compose per join above)
+    if (parts.size() > 1 || (parts.size() == 1 && parts[0]->n_rows <= 65536))
+        for (auto& b : parts) b = materialize_batch(ex, b);
     if (parts.empty()) {
         auto e = std::make_shared<Batch>();
         e->schema = left_->schema();

@@ -47,8 +47,22 @@ struct AggLds {
 // issued from inside the loop.)
 // NACC_: accumulator registers per group.  8 for everything that scans; 16 only for tiny inputs (the Final aggregate over a few
 // partial-state rows per rank: Q1 carries 11 accumulators), where one launch instead of the hash path's dozen is what counts
+__device__ inline uint64_t readfirstlane_u64(uint64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+// (a real call: inlined, the end-of-kernel reduction is GMAX x NACC copies of six shuffle steps around the combine's switch)
+__device__ __noinline__ uint64_t wave_reduce_call(uint64_t v, int kind) { return wave_reduce(v, kind); }
+
+// workgroups per CU the register allocator plans for.  The accumulators are 2 x GMAX x NACC VGPRs (+ a valid count each with
+// NULLS): 128 of them get the whole SIMD's file (AGPRs included), 64 a cap of 256, fewer one of 168 — no variant spills
+constexpr int lowcard_min_blocks(int gmax, int nacc, bool nulls) {
+    const int w = gmax * nacc;
+    return w >= 64 ? 1 : (w >= 32 || (nulls && w >= 16)) ? 2 : 3;
+}
+
 template <int R, bool NULLS, int GMAX, bool PREFETCH, int NACC_ = AGG_NACC>
-__global__ void __launch_bounds__(BLOCK, (NACC_ > AGG_NACC ? 1 : (GMAX >= 8 ? 2 : 3)))   // >= 2-3 workgroups per CU: caps VGPRs at 256 / 168
+__global__ void __launch_bounds__(BLOCK, lowcard_min_blocks(GMAX, NACC_, NULLS))
 scan_agg_lowcard_kernel(const ScanParams* __restrict__ Pp, const AggLowCardArgs<GMAX> A) {
     const ScanParams& P = *Pp;
     constexpr int TILE = BLOCK * R;
@@ -68,14 +82,16 @@ scan_agg_lowcard_kernel(const ScanParams* __restrict__ Pp, const AggLowCardArgs<
     uint32_t nvalid[NULLS ? GMAX : 1][NULLS ? NACC : 1];
     uint32_t rows[GMAX];
 #pragma unroll
-    for (int g = 0; g < GMAX; ++g) {
-        rows[g] = 0;
+    for (int a = 0; a < NACC; ++a) {
+        const uint64_t id = (a < n_acc) ? acc_identity(P.acc[a].kind) : 0;
 #pragma unroll
-        for (int a = 0; a < NACC; ++a) {
-            acc[g][a] = (a < n_acc) ? acc_identity(P.acc[a].kind) : 0;
-            if (NULLS) nvalid[g][a] = 0;
+        for (int g = 0; g < GMAX; ++g) {
+            acc[g][a] = id;
+            if (NULLS) nvalid[NULLS ? g : 0][NULLS ? a : 0] = 0;
         }
     }
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g) rows[g] = 0;
     if (tid == 0) { S->ng = 0; S->overflow = 0; S->winner = 0xFFFFFFFFu; }
     if (tid < GMAX) { S->keys[tid].k0 = 0; S->keys[tid].k1 = 0; }
     __syncthreads();
@@ -106,7 +122,10 @@ scan_agg_lowcard_kernel(const ScanParams* __restrict__ Pp, const AggLowCardArgs<
         int ng = S->ng;
         Key128 gk[GMAX];
 #pragma unroll
-        for (int g = 0; g < GMAX; ++g) { gk[g].k0 = S->keys[g].k0; gk[g].k1 = key64 ? 0 : S->keys[g].k1; }
+        for (int g = 0; g < GMAX; ++g) {          // the same for every lane: scalar registers
+            gk[g].k0 = readfirstlane_u64(S->keys[g].k0);
+            gk[g].k1 = key64 ? 0 : readfirstlane_u64(S->keys[g].k1);
+        }
         Key128 rk[R];
         int lg[R];
         bool pending = false;
@@ -199,12 +218,16 @@ scan_agg_lowcard_kernel(const ScanParams* __restrict__ Pp, const AggLowCardArgs<
                         }
                         if (sp.kind == ACC_COUNT_VALID || sp.kind == ACC_COUNT_VALID_B) { v = k ? 1 : 0; k = true; }
                         if (k) {
+                            // the row's group picked and written back with static indices, ONE combine between (a combine per
+                            // group is GMAX x NACC x R copies of its switch: past the unroller's budget, and the arrays go to scratch)
+                            uint64_t cur = 0;
+#pragma unroll
+                            for (int g = 0; g < GMAX; ++g) cur = (lg[r] == g) ? acc[g][a] : cur;
+                            cur = acc_combine(cur, v, sp.kind);
 #pragma unroll
                             for (int g = 0; g < GMAX; ++g) {
-                                if (lg[r] == g) {
-                                    acc[g][a] = acc_combine(acc[g][a], v, sp.kind);
-                                    if (NULLS) nvalid[NULLS ? g : 0][NULLS ? a : 0] += 1;
-                                }
+                                acc[g][a] = (lg[r] == g) ? cur : acc[g][a];
+                                if (NULLS) nvalid[NULLS ? g : 0][NULLS ? a : 0] += (lg[r] == g) ? 1u : 0u;
                             }
                         }
                     }
@@ -231,7 +254,7 @@ scan_agg_lowcard_kernel(const ScanParams* __restrict__ Pp, const AggLowCardArgs<
 #pragma unroll
         for (int a = 0; a < NACC; ++a) {
             const int kind = (a < n_acc) ? P.acc[a].kind : ACC_COUNT_ROWS;
-            const uint64_t v = wave_reduce(acc[g][a], kind);
+            const uint64_t v = wave_reduce_call(acc[g][a], kind);
             if (lane == 0) S->red[wave][g * NACC + a] = v;
         }
     __syncthreads();
@@ -447,6 +470,10 @@ static hipError_t launch_lowcard_n(const LaunchCfg& cfg, const ScanParams& P, Sc
         return hipErrorInvalidValue;
     }
     // 8 groups x 8 accumulators take 128 VGPRs: no room for prefetch registers
+    if (P.n_acc <= 4) {                            // (TPC-H Q3 / Q5 / Q6 carry one SUM): a quarter / half of the accumulator registers
+        if (gmax == 8) return launch_lowcard_t<2, NULLS, 8, false, 4>(cfg, P, dparams, partials, partial_ng, max_grid, status, grid_out);
+        if (gmax == 4) return launch_lowcard_t<AGG_DEFAULT_R, NULLS, 4, AGG_DEFAULT_PREFETCH, 4>(cfg, P, dparams, partials, partial_ng, max_grid, status, grid_out);
+    }
     if (gmax == 8) return BHIP_LC(2, 8, false);
     if (gmax == 4) return BHIP_LC(AGG_DEFAULT_R, 4, AGG_DEFAULT_PREFETCH);
     if (gmax == 1) return BHIP_LC(AGG_DEFAULT_R, 1, AGG_DEFAULT_PREFETCH);
