@@ -653,6 +653,10 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
         head->n_rows = std::min<int64_t>(head->n_rows, 32768);
         sample.push_back(head);
     }
+    // the head is read at the wider of the two register widths straight away: its group count then picks the width for the whole
+    // input (<= 4: the 4-group kernel, which prefetches; <= 8: this one; more: the hash table) — one small launch, not two
+    const bool probe8 = !sample.empty() && gmax == 4 && !wide_acc;
+    if (probe8) gmax = 8;
     std::shared_ptr<Batch> early;
     TailInfo tail;
     memset(&tail, 0, sizeof(tail));
@@ -726,7 +730,11 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
             if (gmax == -1) sample.clear();
             continue;
         }
-        if (sampling) { sample.clear(); continue; }       // the head fits this width: now the whole input
+        if (sampling) {                                   // the head fits this width: now the whole input
+            if (probe8 && st.n_groups <= 4) gmax = 4;
+            sample.clear();
+            continue;
+        }
         n_groups = st.n_groups;
         break;
     }

@@ -101,7 +101,7 @@ static Column take_column_v(const Exec& ex, const Column& c, const uint32_t* idx
 // several columns by the same index vector: the fixed-width values and all bitmaps go in ONE launch
 // (a Q1 result batch is 10 columns x 4 rows: ten launches of four threads otherwise); Utf8 columns one by one
 std::vector<Column> take_columns(const Exec& ex, const std::vector<const Column*>& cols_in, const uint32_t* idx, int64_t n,
-                                 bool may_null, bool permutation, bool keep_views) {
+                                 bool may_null, bool permutation, bool keep_views, const BufferPtr& idx_owner) {
     // ---- views in, views out (host/core.hpp Column::view_base) ------------------------------------------------------------
     bool any_view = keep_views;
     for (auto* c : cols_in) any_view = any_view || c->is_view();
@@ -135,6 +135,7 @@ std::vector<Column> take_columns(const Exec& ex, const std::vector<const Column*
                     through_null[comp.get()] = through_null[comp.get()] || c.view_may_null || may_null;
                 }
             } else if (keep_views) {
+                if (!own_idx && idx_owner && idx_owner->ptr() == (const void*)idx) own_idx = idx_owner;     // the caller's own buffer: kept, not copied
                 if (!own_idx) {
                     own_idx = make_buffer(ex, (size_t)n * 4 + 8);
                     if (n) HIP_CHECK(hipMemcpyAsync(own_idx->ptr(), idx, (size_t)n * 4, hipMemcpyDeviceToDevice, ex.stream));

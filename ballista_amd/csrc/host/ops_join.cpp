@@ -533,7 +533,9 @@ StreamPtr HashJoinExec::execute_needed(int partition, const Exec& ex, const std:
 
         // output batch from index pairs; R: the batch the right columns are gathered from, rmap[i] = its column for right
         // output column i (nullptr: self->right_cols_).  Columns no parent reads stay placeholders.
-        auto emit = [&](const Batch* R, const std::vector<int>* rmap, const uint32_t* lidx, const uint32_t* ridx, int64_t n_out) {
+        // (lbuf / rbuf: the buffers that own lidx / ridx, when the caller has them — view columns keep them instead of a copy)
+        auto emit = [&](const Batch* R, const std::vector<int>* rmap, const uint32_t* lidx, const uint32_t* ridx, int64_t n_out,
+                        const BufferPtr& lbuf = nullptr, const BufferPtr& rbuf = nullptr) {
             auto b = std::make_shared<Batch>();
             b->schema = self->schema_;
             b->ctx = ex.ctx;
@@ -549,7 +551,7 @@ StreamPtr HashJoinExec::execute_needed(int partition, const Exec& ex, const std:
             for (int v = 0; v < 2; ++v) {
                 if (lc[v].empty()) continue;
                 if (lidx) {
-                    auto got = take_columns(ex, lc[v], lidx, n_out, right_outer, false, v == 1);
+                    auto got = take_columns(ex, lc[v], lidx, n_out, right_outer, false, v == 1, lbuf);
                     for (size_t k = 0; k < got.size(); ++k) b->cols[lpos[v][k]] = std::move(got[k]);
                 } else {
                     for (size_t k = 0; k < lc[v].size(); ++k) b->cols[lpos[v][k]] = null_column(ex, lc[v][k]->dtype, n_out);
@@ -564,7 +566,7 @@ StreamPtr HashJoinExec::execute_needed(int partition, const Exec& ex, const std:
             }
             for (int v = 0; v < 2; ++v) {
                 if (rc[v].empty()) continue;
-                auto got = take_columns(ex, rc[v], ridx, n_out, left_outer, false, v == 1);
+                auto got = take_columns(ex, rc[v], ridx, n_out, left_outer, false, v == 1, rbuf);
                 for (size_t k = 0; k < got.size(); ++k) b->cols[rpos[v][k]] = std::move(got[k]);
             }
             out.push_back(b);
@@ -652,16 +654,18 @@ StreamPtr HashJoinExec::execute_needed(int partition, const Exec& ex, const std:
             HIP_CHECK(exclusive_scan_u32_u64(ex.stream, tile_counts, n_tiles, tile_off, false, total, scan_tmp));
             const uint64_t n_out = read_device(ex, total);
             if (n_out == 0) return;
-            uint32_t* ridx = tmp.get<uint32_t>((size_t)n_out);
-            uint32_t* lidx = need_left ? tmp.get<uint32_t>((size_t)n_out) : nullptr;
+            BufferPtr rbuf = make_buffer(ex, (size_t)n_out * 4 + 8), lbuf = need_left ? make_buffer(ex, (size_t)n_out * 4 + 8) : nullptr;
+            uint32_t* ridx = rbuf->as<uint32_t>();
+            uint32_t* lidx = need_left ? lbuf->as<uint32_t>() : nullptr;
             if (need_left) TIMED_LAUNCH_N(ex, "join_compact_staged", n, launch_join_compact_staged(cfg, staging, tile_off, n_out, n_tiles, lidx, staging_rows, ridx));
             else TIMED_LAUNCH_N(ex, "select_indices", n, launch_select_indices(cfg, bitmap, tile_off, n, ridx));
             if (remap) {
-                uint32_t* orig = tmp.get<uint32_t>((size_t)n_out);
-                TIMED_LAUNCH_N(ex, "take_fixed", n_out, launch_take_fixed(cfg, remap, 4, ridx, (int64_t)n_out, orig));
-                ridx = orig;
+                BufferPtr orig = make_buffer(ex, (size_t)n_out * 4 + 8);
+                TIMED_LAUNCH_N(ex, "take_fixed", n_out, launch_take_fixed(cfg, remap, 4, ridx, (int64_t)n_out, orig->as<uint32_t>()));
+                rbuf = orig;
+                ridx = orig->as<uint32_t>();
             }
-            emit(outsrc, rmap, lidx, ridx, (int64_t)n_out);
+            emit(outsrc, rmap, lidx, ridx, (int64_t)n_out, lbuf, rbuf);
         };
         ProbeFilter no_filter;
         memset(&no_filter, 0, sizeof(no_filter));

@@ -322,7 +322,7 @@ BatchPtr project_batch(const Exec& ex, const Batch& in, const std::vector<std::p
 Column take_batch_column(const Exec& ex, const Column& c, const uint32_t* idx, int64_t n);
 // columns gathered by one index vector; may_null: the indices may hold 0xFFFFFFFF (outer joins) -> validity always built
 std::vector<Column> take_columns(const Exec& ex, const std::vector<const Column*>& cols, const uint32_t* idx, int64_t n,
-                                 bool may_null, bool permutation = false, bool keep_views = false);
+                                 bool may_null, bool permutation = false, bool keep_views = false, const BufferPtr& idx_owner = nullptr);
 // view columns (core.hpp Column::view_base) as ordinary columns
 Column materialize_column(const Exec& ex, const Column& c);
 BatchPtr materialize_batch(const Exec& ex, const BatchPtr& b);

@@ -6,14 +6,18 @@ R=$PWD; export TMPDIR=/tmp; cd /tmp
 Q=${QUERY:-q1}
 ARGS="--query $Q --steps ${STEPS:-5} --warmup 2 --no-cpu-baseline ${EXTRA_ARGS}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${Q}_stats -- python3 $R/bench.py $ARGS > $R/gpurun_out/prof_${Q}_stats.log 2>&1
+if [ -z "$STATS_ONLY" ]; then          # STATS_ONLY=1: the kernel table and the step timeline, no counter passes
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_${Q}_fetch -- python3 $R/bench.py $ARGS > $R/gpurun_out/prof_${Q}_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_${Q}_write -- python3 $R/bench.py $ARGS > $R/gpurun_out/prof_${Q}_write.log 2>&1
+else rm -rf $R/gpurun_out/prof_${Q}_fetch $R/gpurun_out/prof_${Q}_write; fi
 cd $R
 QUERY=$Q python3 - <<'PY'
 import csv, glob, collections, json, os, shutil
 q = os.environ["QUERY"]
 def agg(tag, ctr):
-    f = glob.glob(f"gpurun_out/{tag}/*/*counter_collection.csv")[0]
+    fl = glob.glob(f"gpurun_out/{tag}/*/*counter_collection.csv")
+    if not fl: return {}
+    f = fl[0]
     a = collections.defaultdict(float); d = collections.defaultdict(set)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == ctr:
@@ -53,7 +57,7 @@ def wavg(m):
     tot = sum(m.get(r["Name"], (0, 0))[0] * m.get(r["Name"], (0, 0))[1] for r in same)
     n = sum(m.get(r["Name"], (0, 0))[1] for r in same)
     return tot / n if n else 0.0
-json.dump({"kernel": base, "variants": [r["Name"][:120] for r in same], "dispatches": calls,
+if fs: json.dump({"kernel": base, "variants": [r["Name"][:120] for r in same], "dispatches": calls,
            "avg_ms": sum(float(r["TotalDurationNs"]) for r in same) / max(calls, 1) / 1e6,
            "fetch_size_kb_per_launch": wavg(fs), "write_size_kb_per_launch": wavg(ws),
            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; KB = 1024 B; gfx950: FETCH_SIZE x2 for wide streaming reads; "
