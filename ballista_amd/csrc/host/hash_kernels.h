@@ -112,10 +112,10 @@ struct NarrowJoinTable {
     uint32_t kmin, krange;
     uint64_t kmin64;          // first key of the window as raw key bits (32-bit keys: zero- or sign-extension does not matter, the
                               // offset is taken modulo 2^32)
-    // rank map (kernels_join.hip; keys inside a window of <= 2^30 values): rbits = key set, 64 keys per word;
-    // rprefix[w] = set bits before word w; rank -> build row through rperm (null: the build side is sorted by key, rank = row)
-    const uint64_t* rbits;
-    const uint32_t* rprefix;
+    // rank map (kernels_join.hip; keys inside a window of <= 2^30 values): rpack[g] = the key set of granule g (32 key values,
+    // low half) | the number of build keys before the granule (high half): ONE 8-byte read gives a probe row its membership bit and
+    // its rank; rank -> build row through rperm (null: the build side is sorted by key, rank = row)
+    const uint64_t* rpack;
     const uint32_t* rperm;
     // two-column join whose build side is unique on the first column: second key of every build row (null: one-column join)
     const uint32_t* resid_build;
@@ -123,12 +123,11 @@ struct NarrowJoinTable {
 // one pass over the build keys (kernels_join.hip): stats[0] / [1] = min / max of (key ^ sign bit) as unsigned (seed ~0 / 0),
 // stats[2] != 0 when the keys are not strictly increasing (or some are NULL)
 hipError_t launch_join_key_stats(const LaunchCfg& cfg, const void* keys, int key_width, const uint64_t* sel, uint32_t n, uint64_t* stats);
-// rank map build: key-set bits (zeroed by the caller), popcounts per word (scanned by the caller into rprefix), perm
+// rank map build: key-set bits (zeroed by the caller; 64 keys per word = two granules), then launch_rank_pack (util_kernels.h), perm
 hipError_t launch_rank_bits(const LaunchCfg& cfg, const void* keys, int key_width, const uint64_t* sel, uint32_t n, uint64_t kmin, bool sorted,
                             uint64_t* bits, uint32_t* dup_flag);
-hipError_t launch_rank_popcount(const LaunchCfg& cfg, const uint64_t* bits, int64_t n_words, uint32_t* counts);
 hipError_t launch_rank_perm(const LaunchCfg& cfg, const void* keys, int key_width, const uint64_t* sel, uint32_t n, uint64_t kmin,
-                            const uint64_t* bits, const uint32_t* prefix, uint32_t* perm);
+                            const uint64_t* rpack, uint32_t* perm);
 // the key-set bitmap in front of the CAS table (round-1 design; kept as the A/B partner of the rank map, BHIP_JOIN_TABLE=1)
 hipError_t launch_join_key_present64(const LaunchCfg& cfg, const uint64_t* keys, const uint64_t* sel, uint32_t n, uint64_t kmin,
                                      uint32_t* present);

@@ -24,7 +24,7 @@ struct JoinBuildSide {
     bool unique = false;            // no two build rows share a key: probe rows have at most one partner
     bool narrow = false;            // ONE integer key, unique: NarrowJoinTable instead of JoinTable
     int narrow_width = 0;           // its key bytes (4: Int32 / Date32, 8: Int64 / UInt64)
-    BufferPtr slots, present, rbits, rprefix, rperm;
+    BufferPtr slots, present, rpack, rperm;
     NarrowJoinTable ntable;
     Column key_holder;              // two-column join: the key column built for it (packed pair, or the first key with both validities)
     bool resid = false;             // two-column join by the first key; the second is compared on every match (ntable.resid_build)
@@ -285,30 +285,27 @@ std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) co
         const bool window_ok = any_key && range <= (1ull << 30) && range / 4096 <= (uint64_t)n + 256;
         if (window_ok && !force_table) {
             // ---- rank map ----------------------------------------------------------------------------------------------
-            const int64_t n_words = (int64_t)(range >> 6) + 1;
-            bs->rbits = make_buffer(ex, (size_t)n_words * 8 + 8);
-            bs->rprefix = make_buffer(ex, (size_t)n_words * 4 + 8);
-            HIP_CHECK(hipMemsetAsync(bs->rbits->ptr(), 0, (size_t)n_words * 8, ex.stream));
+            const int64_t n_words = (int64_t)(range >> 6) + 1, n_gran = 2 * n_words;
+            uint64_t* bits = tmp.get<uint64_t>((size_t)n_words + 1);
+            bs->rpack = make_buffer(ex, (size_t)n_gran * 8 + 8);
+            HIP_CHECK(hipMemsetAsync(bits, 0, (size_t)n_words * 8, ex.stream));
             TIMED_LAUNCH_N(ex, sorted ? "rank_bits_sorted" : "rank_bits_any", n,
-                           launch_rank_bits(ex.cfg(), kc.data->ptr(), nkw, ksel, (uint32_t)n, kmin, sorted, bs->rbits->as<uint64_t>(), bs->dup->as<uint32_t>()));
-            uint32_t* counts = tmp.get<uint32_t>((size_t)n_words + 1);
-            void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes(n_words));
+                           launch_rank_bits(ex.cfg(), kc.data->ptr(), nkw, ksel, (uint32_t)n, kmin, sorted, bits, bs->dup->as<uint32_t>()));
+            void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes(n_gran));
             uint64_t* total = tmp.get<uint64_t>(1);
-            TIMED_LAUNCH_N(ex, "rank_popcount", n_words, launch_rank_popcount(ex.cfg(), bs->rbits->as<uint64_t>(), n_words, counts));
-            HIP_CHECK(exclusive_scan_u32_i32(ex.stream, counts, n_words, bs->rprefix->as<int32_t>(), false, total, scan_tmp));
+            TIMED_LAUNCH_N(ex, "rank_pack", n_gran, launch_rank_pack(ex.stream, reinterpret_cast<const uint32_t*>(bits), n_gran, bs->rpack->as<uint64_t>(), total, scan_tmp));
             bool dup = false;
             if (!sorted) {
                 dup = read_device(ex, bs->dup->as<uint32_t>()) != 0;           // duplicates would collide in perm[]
                 if (!dup) {
                     bs->rperm = make_buffer(ex, (size_t)n * 4 + 8);
-                    TIMED_LAUNCH_N(ex, "rank_perm", n, launch_rank_perm(ex.cfg(), kc.data->ptr(), nkw, ksel, (uint32_t)n, kmin, bs->rbits->as<uint64_t>(),
-                                                                       bs->rprefix->as<uint32_t>(), bs->rperm->as<uint32_t>()));
+                    TIMED_LAUNCH_N(ex, "rank_perm", n, launch_rank_perm(ex.cfg(), kc.data->ptr(), nkw, ksel, (uint32_t)n, kmin, bs->rpack->as<uint64_t>(),
+                                                                       bs->rperm->as<uint32_t>()));
                 }
             }
             if (!dup) {
                 stream_wait(ex);                 // other tasks (other streams) read the map: complete before it is published
-                bs->ntable.rbits = bs->rbits->as<uint64_t>();
-                bs->ntable.rprefix = bs->rprefix->as<uint32_t>();
+                bs->ntable.rpack = bs->rpack->as<uint64_t>();
                 bs->ntable.rperm = bs->rperm ? bs->rperm->as<uint32_t>() : nullptr;
                 bs->ntable.krange = (uint32_t)range;
                 bs->narrow = bs->unique = true;
@@ -322,8 +319,7 @@ std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) co
                 }
                 return true;
             }
-            bs->rbits.reset();
-            bs->rprefix.reset();
+            bs->rpack.reset();
         } else {
             // ---- CAS table (sparse keys), with the key set as a bitmap in front of it when the window allows -------------
             const size_t slot_bytes = nkw == 4 ? 8 : 16;

@@ -130,24 +130,18 @@ rank_bits_any_kernel(const void* __restrict__ keys_v, const uint64_t* __restrict
     }
 }
 
-__global__ void __launch_bounds__(BLOCK)
-rank_popcount_kernel(const uint64_t* __restrict__ bits, int64_t n_words, uint32_t* __restrict__ counts) {
-    for (int64_t w = (int64_t)blockIdx.x * BLOCK + threadIdx.x; w < n_words; w += (int64_t)gridDim.x * BLOCK)
-        counts[w] = (uint32_t)__popcll(bits[w]);
-}
-
 // unsorted build side: perm[rank of key] = build row
 template <int KW>
 __global__ void __launch_bounds__(BLOCK)
 rank_perm_kernel(const void* __restrict__ keys_v, const uint64_t* __restrict__ sel, uint32_t n, uint64_t kmin,
-                 const uint64_t* __restrict__ bits, const uint32_t* __restrict__ prefix, uint32_t* __restrict__ perm) {
+                 const uint64_t* __restrict__ rpack, uint32_t* __restrict__ perm) {
     using K = typename KeyT<KW>::type;
     const K* __restrict__ keys = static_cast<const K*>(keys_v);
     for (uint32_t row = blockIdx.x * BLOCK + threadIdx.x; row < n; row += gridDim.x * BLOCK) {
         if (!jbit_at(sel, row)) continue;
         const uint64_t d = key_offset<KW>(keys[row], kmin);
-        const uint64_t w = bits[d >> 6];
-        perm[prefix[d >> 6] + (uint32_t)__popcll(w & ((1ull << (d & 63)) - 1ull))] = row;
+        const uint64_t w = rpack[d >> 5];
+        perm[(uint32_t)(w >> 32) + (uint32_t)__popc((uint32_t)w & ((1u << (d & 31)) - 1u))] = row;
     }
 }
 
@@ -181,8 +175,8 @@ __device__ inline uint32_t table_lookup(const NarrowJoinTable& T, typename KeyT<
 // per-wave LDS scratch of the lookup compaction: up to FP_CHUNK packed items
 template <int FP_CHUNK>
 struct WaveScratchT {
-    uint64_t a[FP_CHUNK];        // rank map: word index; table: the key
-    uint32_t b[FP_CHUNK];        // rank map: popcount of the lower bits; then: the result (build row)
+    uint64_t a[FP_CHUNK];        // rank map: the rank; table: the key
+    uint32_t b[FP_CHUNK];        // the result (build row)
     uint32_t c[FP_CHUNK];        // residual key (second key column of a two-column join) of the probe row
 };
 
@@ -192,9 +186,8 @@ struct WaveScratchT {
 // as vector instructions on them (rocprofv3 SQ_INSTS_SALU 293 M vs SQ_INSTS_VALU 275 M per launch, profiles/r02_probe_variants_q3_sf100.txt).
 // RESID: a second 4-byte key column on both sides (ON a = c AND b = d with the build side unique on `a` alone): the lookup goes by
 // the first key, a match stands only if the second keys are equal too (T.resid_build[build row] vs the probe row's value).
-// FAST: the common configuration fixed at compile time — rank map, no NULL keys on the probe side, not a left join — so that the
-// per-row-slot tests of those run-time options (wave-uniform branches around every load) disappear from the loop
-template <int KW, int NF, int FP_ROWS, bool RESID, bool FAST>
+// (The common configuration — rank map, no NULL keys on the probe side, not a left join — has a kernel of its own below.)
+template <int KW, int NF, int FP_ROWS, bool RESID>
 __global__ void __launch_bounds__(BLOCK)
 join_filter_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void* __restrict__ rkeys_v, const uint64_t* __restrict__ rsel,
                          uint32_t n_right, int right_outer, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts,
@@ -214,9 +207,8 @@ join_filter_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const voi
     const uint32_t last_row = n_right - 1;
     const uint32_t wave_id = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (BLOCK / 64);
-    const bool ranked = FAST || T.rbits != nullptr;
-    const bool key_set = FAST || ranked || T.present != nullptr;
-    if (FAST) { rsel = nullptr; matched = nullptr; }
+    const bool ranked = T.rpack != nullptr;
+    const bool key_set = ranked || T.present != nullptr;
 
     // the streamed inputs of one pass; the NEXT pass's are loaded before this pass walks its dependent reads.
     // Rows are 32-bit (a batch holds < 2^32 - 16 rows and a pass starts at a multiple of 256: base + 255 does not wrap).
@@ -240,12 +232,15 @@ join_filter_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const voi
 #pragma unroll 1
         for (int c = 0; c < SEL_TILE / FP_CHUNK; ++c) {
             const uint32_t base = tile_base + (uint32_t)c * FP_CHUNK;
-            {
+            // The next pass's streamed loads are issued AFTER this pass's key-set word loads: loads return in issue order, so a wait
+            // for the words (an L2 round trip) would otherwise also wait for the streamed loads issued before them (an HBM round trip)
+            auto prefetch = [&]() {
                 const bool last = c == SEL_TILE / FP_CHUNK - 1;
                 // (after the wave's last tile the prefetch re-reads the final rows: harmless, and no branch around the loads)
                 const uint32_t nt = t + n_waves < n_tiles ? t + n_waves : n_tiles - 1;
                 load(last ? nt * SEL_TILE : base + FP_CHUNK, nxt);
-            }
+            };
+            if (!key_set) prefetch();
             bool pass[FP_ROWS], live[FP_ROWS];
             uint32_t m[FP_ROWS], d[FP_ROWS];
             uint64_t word[FP_ROWS];
@@ -259,7 +254,7 @@ join_filter_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const voi
                 pass[k] = p;
                 m[k] = 0xFFFFFFFFu;
                 live[k] = p;
-                if (!FAST && rsel != nullptr) {                            // NULL keys never match (wave-uniform test of the pointer)
+                if (rsel != nullptr) {                            // NULL keys never match (wave-uniform test of the pointer)
                     const uint32_t rc = row < last_row ? row : last_row;
                     live[k] = live[k] && ((rsel[rc >> 6] >> (rc & 63)) & 1ull);
                 }
@@ -271,11 +266,14 @@ join_filter_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const voi
                     const uint64_t off = key_offset<KW>(cur.key[k], T.kmin64);
                     live[k] = live[k] && off <= T.krange;
                     d[k] = live[k] ? (uint32_t)off : 0u;                                  // the window holds <= 2^30 values
-                    if (ranked) word[k] = T.rbits[d[k] >> 6];
-                    else word[k] = (uint64_t)T.present[d[k] >> 5] << (d[k] & 32);         // the 32-bit word at its place in the 64-bit one
+                    if (ranked) word[k] = T.rpack[d[k] >> 5];                             // key set of the granule | keys before it << 32
+                    else word[k] = (uint64_t)T.present[d[k] >> 5];
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                prefetch();
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int k = 0; k < FP_ROWS; ++k) live[k] = live[k] && ((word[k] >> (d[k] & 63)) & 1ull);
+                for (int k = 0; k < FP_ROWS; ++k) live[k] = live[k] && (((uint32_t)word[k] >> (d[k] & 31)) & 1u);
             }
             // ---- pack the surviving row slots into consecutive lanes, one round of dependent reads for all of them ---------
             uint64_t lw[FP_ROWS];
@@ -288,7 +286,7 @@ join_filter_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const voi
                 for (int k = 0; k < FP_ROWS; ++k) {
                     idx[k] = before[k] + (uint32_t)__popcll(lw[k] & lane_lt);
                     if (live[k]) {
-                        if (ranked) { S.a[idx[k]] = d[k] >> 6; S.b[idx[k]] = (uint32_t)__popcll(word[k] & ((1ull << (d[k] & 63)) - 1ull)); }
+                        if (ranked) S.a[idx[k]] = (word[k] >> 32) + (uint32_t)__popc((uint32_t)word[k] & ((1u << (d[k] & 31)) - 1u));   // the rank
                         else S.a[idx[k]] = (uint64_t)cur.key[k];
                         if (RESID) S.c[idx[k]] = cur.g[RESID ? k : 0];
                     }
@@ -298,7 +296,7 @@ join_filter_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const voi
                 for (uint32_t j = lane; j < total; j += 64) {
                     uint32_t r;
                     if (ranked) {
-                        r = T.rprefix[S.a[j]] + S.b[j];
+                        r = (uint32_t)S.a[j];
                         if (T.rperm) r = T.rperm[r];                      // (unsorted build side; a uniform test once per lookup round)
                     } else {
                         r = table_lookup<KW>(T, (K)S.a[j]);
@@ -330,6 +328,125 @@ join_filter_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const voi
                 }
                 tile_cnt += (uint32_t)__popcll(wd);
             }
+            cur = nxt;
+        }
+        if (lane == 0) tile_counts[t] = tile_cnt;
+    }
+}
+
+// The common configuration — rank map, no NULL keys on the probe side, not a left join — without the lookup round: the packed
+// word of the rank map (NarrowJoinTable::rpack) holds the membership bit AND the rank, so a row is decided by one dependent
+// 8-byte read and 32-bit arithmetic; no ballot / LDS compaction of the surviving rows, no second read.  The general kernel above
+// issues ~235 vector and ~236 scalar instructions per 256-row pass of a wave, which is what bounds it: at four cycles per wave64
+// vector instruction that is one row per cycle and CU — the 570 rows/ns it measures on 600 M rows.
+// RESID: the second key column of every match is compared in place (T.resid_build[build row]: a second dependent read for the
+// rows that passed the first).  An unsorted build side adds the rank -> row read (T.rperm).
+template <int KW, int NF, int FP_ROWS, bool RESID, bool PERM>
+__global__ void __launch_bounds__(BLOCK)
+join_rank_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void* __restrict__ rkeys_v, uint32_t n_right, int right_outer,
+                       uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts, uint32_t* __restrict__ staging,
+                       const uint32_t* __restrict__ resid_probe, uint32_t* __restrict__ staging_rows) {
+    using K = typename KeyT<KW>::type;
+    constexpr int NFR = NF > 0 ? NF : 1;
+    constexpr int FP_CHUNK = 64 * FP_ROWS;
+    static_assert(SEL_TILE % FP_CHUNK == 0, "a tile is a whole number of passes");
+    static_assert(FP_ROWS <= 64, "one bitmap word per row slot, written by the first FP_ROWS lanes");
+    const K* __restrict__ rkeys = static_cast<const K*>(rkeys_v);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t lane_lt = (1ull << lane) - 1ull;
+    const uint32_t n_tiles = (uint32_t)(((uint64_t)n_right + SEL_TILE - 1) / SEL_TILE);
+    const uint32_t last_row = n_right - 1;
+    const uint32_t wave_id = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * (BLOCK / 64);
+    const uint64_t* __restrict__ rpack = T.rpack;
+    const bool staged = staging != nullptr;            // (staging and staging_rows come together: host/ops_join.cpp process_fused)
+
+    struct Regs { K key[FP_ROWS]; int32_t f[NFR][FP_ROWS]; uint32_t g[RESID ? FP_ROWS : 1]; };
+    auto load = [&](uint32_t base, Regs& r) {
+#pragma unroll
+        for (int k = 0; k < FP_ROWS; ++k) {
+            const uint32_t row = base + 64u * k + lane;
+            const uint32_t rc = row < last_row ? row : last_row;
+            r.key[k] = rkeys[rc];
+            if (RESID) r.g[RESID ? k : 0] = resid_probe[rc];
+#pragma unroll
+            for (int j = 0; j < NF; ++j) r.f[j][k] = F.col[j < F.n ? j : 0][rc];
+        }
+    };
+    Regs cur, nxt;
+    if (wave_id < n_tiles) load(wave_id * SEL_TILE, cur);
+    for (uint32_t t = wave_id; t < n_tiles; t += n_waves) {
+        const uint32_t tile_base = t * SEL_TILE;
+        uint32_t* __restrict__ st_m = staging + tile_base;            // (null + offset when not staged: never dereferenced)
+        uint32_t* __restrict__ st_r = staging_rows + tile_base;
+        uint32_t tile_cnt = 0;
+#pragma unroll 1
+        for (int c = 0; c < SEL_TILE / FP_CHUNK; ++c) {
+            const uint32_t base = tile_base + (uint32_t)c * FP_CHUNK;
+            // The next pass's streamed loads go out BEHIND this pass's last dependent load and nothing of this pass waits on a
+            // load issued after them: loads return in issue order, so the streamed rows stay in flight until the next pass
+            // picks them up.
+            auto prefetch = [&]() {
+                __builtin_amdgcn_sched_barrier(0);
+                const bool last = c == SEL_TILE / FP_CHUNK - 1;
+                // (after the wave's last tile the prefetch re-reads the final rows: harmless, and no branch around the loads)
+                const uint32_t nt = t + n_waves < n_tiles ? t + n_waves : n_tiles - 1;
+                load(last ? nt * SEL_TILE : base + FP_CHUNK, nxt);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            bool pass[FP_ROWS], live[FP_ROWS];
+            uint32_t d[FP_ROWS], m[FP_ROWS];
+            uint64_t pk[FP_ROWS];
+#pragma unroll
+            for (int k = 0; k < FP_ROWS; ++k) {
+                const uint32_t row = base + 64u * k + lane;
+                bool p = row < n_right;
+#pragma unroll
+                for (int j = 0; j < NF; ++j)
+                    if (j < F.n) p = p && cur.f[j][k] >= F.lo[j] && cur.f[j][k] <= F.hi[j];
+                pass[k] = p;
+                const uint64_t off = key_offset<KW>(cur.key[k], T.kmin64);
+                live[k] = p && off <= T.krange;
+                d[k] = live[k] ? (uint32_t)off : 0u;                                      // the window holds <= 2^30 values
+                pk[k] = rpack[d[k] >> 5];                                                 // unconditional: granule 0 for the others
+            }
+            if (!PERM && !RESID) prefetch();
+#pragma unroll
+            for (int k = 0; k < FP_ROWS; ++k) {
+                const uint32_t bits = (uint32_t)pk[k], sh = d[k] & 31u;
+                live[k] = live[k] && ((bits >> sh) & 1u);
+                m[k] = (uint32_t)(pk[k] >> 32) + (uint32_t)__popc(bits & ((1u << sh) - 1u));
+            }
+            if (PERM) {
+#pragma unroll
+                for (int k = 0; k < FP_ROWS; ++k) m[k] = T.rperm[live[k] ? m[k] : 0u];
+                if (!RESID) prefetch();
+            }
+            if (RESID) {
+                uint32_t second[FP_ROWS];
+#pragma unroll
+                for (int k = 0; k < FP_ROWS; ++k) second[k] = T.resid_build[live[k] ? m[k] : 0u];
+                prefetch();
+#pragma unroll
+                for (int k = 0; k < FP_ROWS; ++k) live[k] = live[k] && second[k] == cur.g[RESID ? k : 0];
+            }
+            uint64_t my_word = 0;
+#pragma unroll
+            for (int k = 0; k < FP_ROWS; ++k) {
+                const bool emit = pass[k] && (right_outer || live[k]);
+                const uint64_t wd = __ballot(emit);
+                my_word = lane == (uint32_t)k ? wd : my_word;
+                if (staged) {                                                             // wave-uniform
+                    if (emit) {
+                        const uint32_t at = (tile_cnt + (uint32_t)__popcll(wd & lane_lt)) & (SEL_TILE - 1);   // (< 1024 anyway)
+                        st_m[at] = live[k] ? m[k] : 0xFFFFFFFFu;
+                        st_r[at] = base + 64u * k + lane;
+                    }
+                }
+                tile_cnt += (uint32_t)__popcll(wd);
+            }
+            // the pass's FP_ROWS selection words in one store (bitmap words past the last row's word exist: whole tiles)
+            if (lane < FP_ROWS) bitmap[(base >> 6) + lane] = my_word;
             cur = nxt;
         }
         if (lane == 0) tile_counts[t] = tile_cnt;
@@ -434,18 +551,12 @@ hipError_t launch_rank_bits(const LaunchCfg& cfg, const void* keys, int key_widt
     return hipGetLastError();
 }
 
-hipError_t launch_rank_popcount(const LaunchCfg& cfg, const uint64_t* bits, int64_t n_words, uint32_t* counts) {
-    if (n_words == 0) return hipSuccess;
-    hipLaunchKernelGGL(rank_popcount_kernel, dim3(rows_grid(cfg, (size_t)n_words)), dim3(BLOCK), 0, cfg.stream, bits, n_words, counts);
-    return hipGetLastError();
-}
-
 hipError_t launch_rank_perm(const LaunchCfg& cfg, const void* keys, int key_width, const uint64_t* sel, uint32_t n, uint64_t kmin,
-                            const uint64_t* bits, const uint32_t* prefix, uint32_t* perm) {
+                            const uint64_t* rpack, uint32_t* perm) {
     if (n == 0) return hipSuccess;
     const int grid = rows_grid(cfg, n);
-    if (key_width == 4) hipLaunchKernelGGL(rank_perm_kernel<4>, dim3(grid), dim3(BLOCK), 0, cfg.stream, keys, sel, n, kmin, bits, prefix, perm);
-    else hipLaunchKernelGGL(rank_perm_kernel<8>, dim3(grid), dim3(BLOCK), 0, cfg.stream, keys, sel, n, kmin, bits, prefix, perm);
+    if (key_width == 4) hipLaunchKernelGGL(rank_perm_kernel<4>, dim3(grid), dim3(BLOCK), 0, cfg.stream, keys, sel, n, kmin, rpack, perm);
+    else hipLaunchKernelGGL(rank_perm_kernel<8>, dim3(grid), dim3(BLOCK), 0, cfg.stream, keys, sel, n, kmin, rpack, perm);
     return hipGetLastError();
 }
 
@@ -460,14 +571,24 @@ hipError_t launch_join_filter_probe(const LaunchCfg& cfg, const NarrowJoinTable&
     const int64_t need = (n_tiles + BLOCK / 64 - 1) / (BLOCK / 64);
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;
-    const bool fast = T.rbits != nullptr && rsel == nullptr && matched == nullptr;
-#define BHIP_PROBE_L(KW_, NF_, RESID_, FAST_)                                                                                         \
-    hipLaunchKernelGGL((join_filter_probe_kernel<KW_, NF_, 4, RESID_, FAST_>), dim3((unsigned)grid), dim3(BLOCK), 0, cfg.stream, T, F, rkeys,  \
-                       rsel, n_right, right_outer ? 1 : 0, bitmap, tile_counts, staging, matched, resid_probe, staging_rows)
+    // the rank map without NULL probe keys and without a left join: the one-read kernel
+    const bool direct = T.rpack != nullptr && rsel == nullptr && matched == nullptr && (staging != nullptr) == (staging_rows != nullptr);
+#define BHIP_PROBE_L(KW_, NF_, RESID_)                                                                                                \
+    do {                                                                                                                              \
+        if (direct && T.rperm)                                                                                                        \
+            hipLaunchKernelGGL((join_rank_probe_kernel<KW_, NF_, 4, RESID_, true>), dim3((unsigned)grid), dim3(BLOCK), 0, cfg.stream, T, F, rkeys,  \
+                               n_right, right_outer ? 1 : 0, bitmap, tile_counts, staging, resid_probe, staging_rows);                \
+        else if (direct)                                                                                                              \
+            hipLaunchKernelGGL((join_rank_probe_kernel<KW_, NF_, 4, RESID_, false>), dim3((unsigned)grid), dim3(BLOCK), 0, cfg.stream, T, F, rkeys, \
+                               n_right, right_outer ? 1 : 0, bitmap, tile_counts, staging, resid_probe, staging_rows);                \
+        else                                                                                                                          \
+            hipLaunchKernelGGL((join_filter_probe_kernel<KW_, NF_, 4, RESID_>), dim3((unsigned)grid), dim3(BLOCK), 0, cfg.stream, T, F, rkeys, \
+                               rsel, n_right, right_outer ? 1 : 0, bitmap, tile_counts, staging, matched, resid_probe, staging_rows); \
+    } while (0)
 #define BHIP_PROBE(KW_, NF_)                                                                                                          \
     do {                                                                                                                              \
-        if (resid_probe) { if (fast) BHIP_PROBE_L(KW_, NF_, true, true); else BHIP_PROBE_L(KW_, NF_, true, false); }                  \
-        else { if (fast) BHIP_PROBE_L(KW_, NF_, false, true); else BHIP_PROBE_L(KW_, NF_, false, false); }                            \
+        if (resid_probe) BHIP_PROBE_L(KW_, NF_, true);                                                                                \
+        else BHIP_PROBE_L(KW_, NF_, false);                                                                                           \
     } while (0)
     if (key_width == 4) {
         if (F.n == 0) BHIP_PROBE(4, 0);

@@ -174,6 +174,89 @@ hipError_t exclusive_scan_u32_u32(hipStream_t st, const uint32_t* in, int64_t n,
 }
 
 // =============================================================================================
+// rank map of the narrow join (kernels_join.hip): bits32[g] = the build keys of granule g (32 consecutive key values, one bit
+// each)  ->  pack[g] = bits32[g] | (number of build keys before granule g) << 32.  The same three phases as the scan above with
+// the popcount taken on the fly and the packed word written by the last one: a probe reads ONE 8-byte word per row and has both
+// the membership bit and the rank.
+// =============================================================================================
+__global__ void __launch_bounds__(SCAN_BLOCK)
+rank_pack_sums_kernel(const uint32_t* __restrict__ bits32, int64_t n, uint64_t* __restrict__ chunk_sums) {
+    __shared__ uint64_t s_wave[4];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK;
+    uint64_t v = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        const int64_t j = base + i * SCAN_BLOCK + threadIdx.x;
+        if (j < n) v += (uint32_t)__popc(bits32[j]);
+    }
+    uint64_t tot;
+    block_exclusive_scan(v, s_wave, &tot);
+    if (threadIdx.x == 0) chunk_sums[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(SCAN_BLOCK)
+rank_pack_apply_kernel(const uint32_t* __restrict__ bits32, int64_t n, const uint64_t* __restrict__ chunk_offsets, uint64_t* __restrict__ pack) {
+    __shared__ uint64_t s_wave[4];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK;
+    uint32_t x[SCAN_ITEMS];
+    uint64_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        const int64_t j = base + (int64_t)threadIdx.x * SCAN_ITEMS + i;
+        x[i] = j < n ? bits32[j] : 0;
+        sum += (uint32_t)__popc(x[i]);
+    }
+    uint64_t run = chunk_offsets[blockIdx.x] + block_exclusive_scan(sum, s_wave, nullptr);
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        const int64_t j = base + (int64_t)threadIdx.x * SCAN_ITEMS + i;
+        if (j < n) pack[j] = (uint64_t)x[i] | (run << 32);
+        run += (uint32_t)__popc(x[i]);
+    }
+}
+
+// small maps (<= SCAN_ONE_LAUNCH_MAX granules: a dimension table's keys) in one launch of one workgroup
+__global__ void __launch_bounds__(SCAN_BLOCK)
+rank_pack_one_kernel(const uint32_t* __restrict__ bits32, int64_t n, uint64_t* __restrict__ pack, uint64_t* total_out) {
+    __shared__ uint64_t s_wave[4];
+    uint64_t carry = 0;
+    for (int64_t base = 0; base < n; base += SCAN_CHUNK) {
+        uint32_t x[SCAN_ITEMS];
+        uint64_t sum = 0;
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; ++i) {
+            const int64_t j = base + (int64_t)threadIdx.x * SCAN_ITEMS + i;
+            x[i] = j < n ? bits32[j] : 0;
+            sum += (uint32_t)__popc(x[i]);
+        }
+        uint64_t tot;
+        uint64_t run = carry + block_exclusive_scan(sum, s_wave, &tot);
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; ++i) {
+            const int64_t j = base + (int64_t)threadIdx.x * SCAN_ITEMS + i;
+            if (j < n) pack[j] = (uint64_t)x[i] | (run << 32);
+            run += (uint32_t)__popc(x[i]);
+        }
+        carry += tot;
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = carry;
+}
+
+hipError_t launch_rank_pack(hipStream_t st, const uint32_t* bits32, int64_t n, uint64_t* pack, uint64_t* total_out, void* temp) {
+    if (n <= 0) return total_out ? hipMemsetAsync(total_out, 0, sizeof(uint64_t), st) : hipSuccess;
+    if (n <= SCAN_ONE_LAUNCH_MAX) {
+        hipLaunchKernelGGL(rank_pack_one_kernel, dim3(1), dim3(SCAN_BLOCK), 0, st, bits32, n, pack, total_out);
+        return hipGetLastError();
+    }
+    uint64_t* sums = reinterpret_cast<uint64_t*>(temp);
+    const int64_t n_chunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    hipLaunchKernelGGL(rank_pack_sums_kernel, dim3((unsigned)n_chunks), dim3(SCAN_BLOCK), 0, st, bits32, n, sums);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, st, sums, n_chunks, total_out);
+    hipLaunchKernelGGL(rank_pack_apply_kernel, dim3((unsigned)n_chunks), dim3(SCAN_BLOCK), 0, st, bits32, n, (const uint64_t*)sums, pack);
+    return hipGetLastError();
+}
+
+// =============================================================================================
 // selection bitmap -> ascending row indices (FilterExec keeps row order)
 // =============================================================================================
 // One wave per 1024-row tile, no LDS, no barrier: lanes 0..15 load the tile's 16 words, a shuffle prefix sum of

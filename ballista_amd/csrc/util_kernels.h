@@ -9,6 +9,8 @@ namespace bhip {
 
 // ---- prefix sums ------------------------------------------------------------------------
 size_t exclusive_scan_temp_bytes(int64_t n);
+// rank map of the narrow join: pack[g] = bits32[g] | (set bits before granule g) << 32; temp: exclusive_scan_temp_bytes(n)
+hipError_t launch_rank_pack(hipStream_t st, const uint32_t* bits32, int64_t n, uint64_t* pack, uint64_t* total_out, void* temp);
 // out[i] = sum in[0..i) ; write_total: also out[n] = grand total ; total_out (device u64) optional
 hipError_t exclusive_scan_u32_u64(hipStream_t st, const uint32_t* in, int64_t n, uint64_t* out, bool write_total,
                                   uint64_t* total_out, void* temp);
