@@ -571,12 +571,16 @@ hipError_t launch_join_filter_probe(const LaunchCfg& cfg, const NarrowJoinTable&
     const int64_t need = (n_tiles + BLOCK / 64 - 1) / (BLOCK / 64);
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;
+    static const int probe_rows = [] { const char* v = getenv("BHIP_PROBE_ROWS"); return v ? atoi(v) : 8; }();      // 8 rows per lane and pass (4-byte keys): profiles/r02_probe_variants_q3_sf100.txt
     // the rank map without NULL probe keys and without a left join: the one-read kernel
     const bool direct = T.rpack != nullptr && rsel == nullptr && matched == nullptr && (staging != nullptr) == (staging_rows != nullptr);
 #define BHIP_PROBE_L(KW_, NF_, RESID_)                                                                                                \
     do {                                                                                                                              \
         if (direct && T.rperm)                                                                                                        \
             hipLaunchKernelGGL((join_rank_probe_kernel<KW_, NF_, 4, RESID_, true>), dim3((unsigned)grid), dim3(BLOCK), 0, cfg.stream, T, F, rkeys,  \
+                               n_right, right_outer ? 1 : 0, bitmap, tile_counts, staging, resid_probe, staging_rows);                \
+        else if (direct && probe_rows == 8 && KW_ == 4)                                                                               \
+            hipLaunchKernelGGL((join_rank_probe_kernel<4, NF_, 8, RESID_, false>), dim3((unsigned)grid), dim3(BLOCK), 0, cfg.stream, T, F, rkeys, \
                                n_right, right_outer ? 1 : 0, bitmap, tile_counts, staging, resid_probe, staging_rows);                \
         else if (direct)                                                                                                              \
             hipLaunchKernelGGL((join_rank_probe_kernel<KW_, NF_, 4, RESID_, false>), dim3((unsigned)grid), dim3(BLOCK), 0, cfg.stream, T, F, rkeys, \
