@@ -287,7 +287,8 @@ std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) co
             // ---- rank map ----------------------------------------------------------------------------------------------
             const int64_t n_words = (int64_t)(range >> 6) + 1, n_gran = 2 * n_words;
             uint64_t* bits = tmp.get<uint64_t>((size_t)n_words + 1);
-            bs->rpack = make_buffer(ex, (size_t)n_gran * 8 + 8);
+            bs->rpack = make_buffer(ex, (size_t)n_gran * 8 + 16);
+            HIP_CHECK(hipMemsetAsync(bs->rpack->as<uint64_t>() + n_gran, 0, 8, ex.stream));        // NarrowJoinTable::rzero
             HIP_CHECK(hipMemsetAsync(bits, 0, (size_t)n_words * 8, ex.stream));
             TIMED_LAUNCH_N(ex, sorted ? "rank_bits_sorted" : "rank_bits_any", n,
                            launch_rank_bits(ex.cfg(), kc.data->ptr(), nkw, ksel, (uint32_t)n, kmin, sorted, bits, bs->dup->as<uint32_t>()));
@@ -306,6 +307,7 @@ std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) co
             if (!dup) {
                 stream_wait(ex);                 // other tasks (other streams) read the map: complete before it is published
                 bs->ntable.rpack = bs->rpack->as<uint64_t>();
+                bs->ntable.rzero = (uint32_t)n_gran;
                 bs->ntable.rperm = bs->rperm ? bs->rperm->as<uint32_t>() : nullptr;
                 bs->ntable.krange = (uint32_t)range;
                 bs->narrow = bs->unique = true;

@@ -19,6 +19,7 @@
 // dependent reads, so a pass pays ONE round trip for all of them instead of one per row slot.
 // Algorithmic bytes per probe row: predicate columns + key column once, + 1 bit; per emitted row 4 B partner twice.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "host/hash_kernels.h"
 #include "launch_common.h"
 
@@ -341,80 +342,98 @@ join_filter_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const voi
 // vector instruction that is one row per cycle and CU — the 570 rows/ns it measures on 600 M rows.
 // RESID: the second key column of every match is compared in place (T.resid_build[build row]: a second dependent read for the
 // rows that passed the first).  An unsorted build side adds the rank -> row read (T.rperm).
+// Instruction issue is what bounds this kernel (rocprofv3: SQ_ACTIVE_INST_ANY x resident waves = 90 % of the SIMD cycles, 10 % of a
+// wave's cycles waiting on memory), so everything wave-uniform is kept scalar: the wave's tile index goes through readfirstlane,
+// interior tiles (all but a batch's last) run a variant without row-bound tests and address clamps, the streamed loads and the
+// staging stores address `scalar base + lane offset`.
 template <int KW, int NF, int FP_ROWS, bool RESID, bool PERM>
 __global__ void __launch_bounds__(BLOCK)
-join_rank_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void* __restrict__ rkeys_v, uint32_t n_right, int right_outer,
+join_rank_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void* __restrict__ rkeys_v, uint32_t n_right,
                        uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts, uint32_t* __restrict__ staging,
                        const uint32_t* __restrict__ resid_probe, uint32_t* __restrict__ staging_rows) {
     using K = typename KeyT<KW>::type;
     constexpr int NFR = NF > 0 ? NF : 1;
     constexpr int FP_CHUNK = 64 * FP_ROWS;
+    constexpr int PASSES = SEL_TILE / FP_CHUNK;
     static_assert(SEL_TILE % FP_CHUNK == 0, "a tile is a whole number of passes");
     static_assert(FP_ROWS <= 64, "one bitmap word per row slot, written by the first FP_ROWS lanes");
     const K* __restrict__ rkeys = static_cast<const K*>(rkeys_v);
     const uint32_t lane = threadIdx.x & 63;
-    const uint64_t lane_lt = (1ull << lane) - 1ull;
     const uint32_t n_tiles = (uint32_t)(((uint64_t)n_right + SEL_TILE - 1) / SEL_TILE);
+    const uint32_t full_tiles = n_right / SEL_TILE;                  // tiles before this one hold SEL_TILE rows each
     const uint32_t last_row = n_right - 1;
-    const uint32_t wave_id = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    const uint32_t wave_id = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)));
     const uint32_t n_waves = gridDim.x * (BLOCK / 64);
     const uint64_t* __restrict__ rpack = T.rpack;
     const bool staged = staging != nullptr;            // (staging and staging_rows come together: host/ops_join.cpp process_fused)
 
     struct Regs { K key[FP_ROWS]; int32_t f[NFR][FP_ROWS]; uint32_t g[RESID ? FP_ROWS : 1]; };
-    auto load = [&](uint32_t base, Regs& r) {
+    // rows [base, base + FP_CHUNK) of the streamed columns; EDGE: the chunk may reach past the last row (index clamped)
+    auto load = [&](uint32_t base, Regs& r, auto edge) {
+        constexpr bool EDGE = decltype(edge)::value;
 #pragma unroll
         for (int k = 0; k < FP_ROWS; ++k) {
-            const uint32_t row = base + 64u * k + lane;
-            const uint32_t rc = row < last_row ? row : last_row;
-            r.key[k] = rkeys[rc];
-            if (RESID) r.g[RESID ? k : 0] = resid_probe[rc];
+            if (EDGE) {
+                const uint32_t row = base + 64u * k + lane;
+                const uint32_t rc = row < last_row ? row : last_row;
+                r.key[k] = rkeys[rc];
+                if (RESID) r.g[RESID ? k : 0] = resid_probe[rc];
 #pragma unroll
-            for (int j = 0; j < NF; ++j) r.f[j][k] = F.col[j < F.n ? j : 0][rc];
+                for (int j = 0; j < NF; ++j) r.f[j][k] = F.col[j < F.n ? j : 0][rc];
+            } else {
+                r.key[k] = (rkeys + base)[64u * k + lane];
+                if (RESID) r.g[RESID ? k : 0] = (resid_probe + base)[64u * k + lane];
+#pragma unroll
+                for (int j = 0; j < NF; ++j) r.f[j][k] = (F.col[j < F.n ? j : 0] + base)[64u * k + lane];
+            }
         }
     };
+    auto load_any = [&](uint32_t base, Regs& r) {
+        if (base / SEL_TILE < full_tiles) load(base, r, std::false_type{});       // wave-uniform
+        else load(base, r, std::true_type{});
+    };
     Regs cur, nxt;
-    if (wave_id < n_tiles) load(wave_id * SEL_TILE, cur);
+    if (wave_id < n_tiles) load_any(wave_id * SEL_TILE, cur);
     for (uint32_t t = wave_id; t < n_tiles; t += n_waves) {
         const uint32_t tile_base = t * SEL_TILE;
         uint32_t* __restrict__ st_m = staging + tile_base;            // (null + offset when not staged: never dereferenced)
         uint32_t* __restrict__ st_r = staging_rows + tile_base;
         uint32_t tile_cnt = 0;
-#pragma unroll 1
-        for (int c = 0; c < SEL_TILE / FP_CHUNK; ++c) {
+        auto pass_body = [&](int c, auto edge) {
+            constexpr bool EDGE = decltype(edge)::value;
             const uint32_t base = tile_base + (uint32_t)c * FP_CHUNK;
             // The next pass's streamed loads go out BEHIND this pass's last dependent load and nothing of this pass waits on a
             // load issued after them: loads return in issue order, so the streamed rows stay in flight until the next pass
             // picks them up.
             auto prefetch = [&]() {
                 __builtin_amdgcn_sched_barrier(0);
-                const bool last = c == SEL_TILE / FP_CHUNK - 1;
+                const bool last = c == PASSES - 1;
                 // (after the wave's last tile the prefetch re-reads the final rows: harmless, and no branch around the loads)
                 const uint32_t nt = t + n_waves < n_tiles ? t + n_waves : n_tiles - 1;
-                load(last ? nt * SEL_TILE : base + FP_CHUNK, nxt);
+                load_any(last ? nt * SEL_TILE : base + FP_CHUNK, nxt);
                 __builtin_amdgcn_sched_barrier(0);
             };
-            bool pass[FP_ROWS], live[FP_ROWS];
+            bool live[FP_ROWS];
             uint32_t d[FP_ROWS], m[FP_ROWS];
             uint64_t pk[FP_ROWS];
 #pragma unroll
             for (int k = 0; k < FP_ROWS; ++k) {
-                const uint32_t row = base + 64u * k + lane;
-                bool p = row < n_right;
+                bool p = EDGE ? (base + 64u * k + lane) < n_right : true;
 #pragma unroll
                 for (int j = 0; j < NF; ++j)
                     if (j < F.n) p = p && cur.f[j][k] >= F.lo[j] && cur.f[j][k] <= F.hi[j];
-                pass[k] = p;
                 const uint64_t off = key_offset<KW>(cur.key[k], T.kmin64);
-                live[k] = p && off <= T.krange;
-                d[k] = live[k] ? (uint32_t)off : 0u;                                      // the window holds <= 2^30 values
-                pk[k] = rpack[d[k] >> 5];                                                 // unconditional: granule 0 for the others
+                d[k] = (uint32_t)off;                                                     // (the window holds <= 2^30 values)
+                // a row the filter dropped, or whose key lies outside the window, reads the all-zero granule behind the map: the
+                // bit test below is then the whole decision — ONE compare, whose lane mask is the ballot (a ballot of an AND of
+                // conditions costs two more vector instructions per row slot)
+                pk[k] = rpack[(p && off <= T.krange) ? d[k] >> 5 : T.rzero];
             }
             if (!PERM && !RESID) prefetch();
 #pragma unroll
             for (int k = 0; k < FP_ROWS; ++k) {
                 const uint32_t bits = (uint32_t)pk[k], sh = d[k] & 31u;
-                live[k] = live[k] && ((bits >> sh) & 1u);
+                live[k] = ((bits >> sh) & 1u) != 0u;
                 m[k] = (uint32_t)(pk[k] >> 32) + (uint32_t)__popc(bits & ((1u << sh) - 1u));
             }
             if (PERM) {
@@ -433,21 +452,29 @@ join_rank_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void*
             uint64_t my_word = 0;
 #pragma unroll
             for (int k = 0; k < FP_ROWS; ++k) {
-                const bool emit = pass[k] && (right_outer || live[k]);
-                const uint64_t wd = __ballot(emit);
+                const bool emit = live[k];                                                // (inner join: a right join takes the general kernel)
+                const uint64_t wd = __builtin_amdgcn_ballot_w64(emit);
                 my_word = lane == (uint32_t)k ? wd : my_word;
                 if (staged) {                                                             // wave-uniform
                     if (emit) {
-                        const uint32_t at = (tile_cnt + (uint32_t)__popcll(wd & lane_lt)) & (SEL_TILE - 1);   // (< 1024 anyway)
-                        st_m[at] = live[k] ? m[k] : 0xFFFFFFFFu;
+                        // tile_cnt + (emitting lanes below this one): two mbcnt instructions, the count riding along as their addend
+                        const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(wd >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wd, tile_cnt)) & (SEL_TILE - 1);
+                        st_m[at] = m[k];
                         st_r[at] = base + 64u * k + lane;
                     }
                 }
                 tile_cnt += (uint32_t)__popcll(wd);
             }
             // the pass's FP_ROWS selection words in one store (bitmap words past the last row's word exist: whole tiles)
-            if (lane < FP_ROWS) bitmap[(base >> 6) + lane] = my_word;
+            if (lane < FP_ROWS) (bitmap + (base >> 6))[lane] = my_word;
             cur = nxt;
+        };
+        if (t < full_tiles) {                                                             // wave-uniform
+#pragma unroll 1
+            for (int c = 0; c < PASSES; ++c) pass_body(c, std::false_type{});
+        } else {
+#pragma unroll 1
+            for (int c = 0; c < PASSES; ++c) pass_body(c, std::true_type{});
         }
         if (lane == 0) tile_counts[t] = tile_cnt;
     }
@@ -573,18 +600,18 @@ hipError_t launch_join_filter_probe(const LaunchCfg& cfg, const NarrowJoinTable&
     if (grid < 1) grid = 1;
     static const int probe_rows = [] { const char* v = getenv("BHIP_PROBE_ROWS"); return v ? atoi(v) : 8; }();      // 8 rows per lane and pass (4-byte keys): profiles/r02_probe_variants_q3_sf100.txt
     // the rank map without NULL probe keys and without a left join: the one-read kernel
-    const bool direct = T.rpack != nullptr && rsel == nullptr && matched == nullptr && (staging != nullptr) == (staging_rows != nullptr);
+    const bool direct = T.rpack != nullptr && rsel == nullptr && matched == nullptr && !right_outer && (staging != nullptr) == (staging_rows != nullptr);
 #define BHIP_PROBE_L(KW_, NF_, RESID_)                                                                                                \
     do {                                                                                                                              \
         if (direct && T.rperm)                                                                                                        \
             hipLaunchKernelGGL((join_rank_probe_kernel<KW_, NF_, 4, RESID_, true>), dim3((unsigned)grid), dim3(BLOCK), 0, cfg.stream, T, F, rkeys,  \
-                               n_right, right_outer ? 1 : 0, bitmap, tile_counts, staging, resid_probe, staging_rows);                \
+                               n_right, bitmap, tile_counts, staging, resid_probe, staging_rows);                \
         else if (direct && probe_rows == 8 && KW_ == 4)                                                                               \
             hipLaunchKernelGGL((join_rank_probe_kernel<4, NF_, 8, RESID_, false>), dim3((unsigned)grid), dim3(BLOCK), 0, cfg.stream, T, F, rkeys, \
-                               n_right, right_outer ? 1 : 0, bitmap, tile_counts, staging, resid_probe, staging_rows);                \
+                               n_right, bitmap, tile_counts, staging, resid_probe, staging_rows);                \
         else if (direct)                                                                                                              \
             hipLaunchKernelGGL((join_rank_probe_kernel<KW_, NF_, 4, RESID_, false>), dim3((unsigned)grid), dim3(BLOCK), 0, cfg.stream, T, F, rkeys, \
-                               n_right, right_outer ? 1 : 0, bitmap, tile_counts, staging, resid_probe, staging_rows);                \
+                               n_right, bitmap, tile_counts, staging, resid_probe, staging_rows);                \
         else                                                                                                                          \
             hipLaunchKernelGGL((join_filter_probe_kernel<KW_, NF_, 4, RESID_>), dim3((unsigned)grid), dim3(BLOCK), 0, cfg.stream, T, F, rkeys, \
                                rsel, n_right, right_outer ? 1 : 0, bitmap, tile_counts, staging, matched, resid_probe, staging_rows); \
