@@ -15,6 +15,7 @@ run BHIP_JOIN_TABLE=1 "$J"
 run BHIP_JOIN_RADIX=1 "$J"
 run BHIP_NO_NARROW_JOIN=1 "$J"
 run BHIP_NO_FUSED_PROBE=1 "$J"
+run BHIP_PROBE_ROWS=4 "tests/test_join_paths_gpu.py"
 run BHIP_NO_RUN_AGG=1 "$A"
 run BHIP_AGG_ATOMIC=1 "$A"
 run BHIP_NO_FINAL_ELISION=1 "$A"
