@@ -648,9 +648,9 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
     for (auto& b : inputs) total_in += b->n_rows;
     // (not for the wide-load path: its plans have at most two 32-bit key parts — flags, short codes — and its launches are the
     // ones the bench's roofline line and the rocprofv3 averages are about)
-    // (a mid-sized input — up to 4 Mi rows: one of these launches is ~0.05 ms whatever it reads — is not sampled; with at most four
+    // (a mid-sized input — up to 1 Mi rows: one of these launches is ~0.05 ms whatever it reads — is not sampled; with at most four
     // accumulators it starts at 8 groups, whose kernel then holds as many accumulator registers as the 4-group one with eight)
-    const bool mid_sized = total_in < (1 << 22);
+    const bool mid_sized = total_in < (1 << 20);
     if (hint == 0 && gmax == 4 && mid_sized && !wide_acc && n_acc <= 4 && !use_lean) gmax = 8;
     if (hint == 0 && gmax > 0 && !group_.empty() && !use_lean && (!mid_sized || (gmax == 4 && total_in >= (1 << 17)))) {
         auto head = std::make_shared<Batch>(*inputs[0]);

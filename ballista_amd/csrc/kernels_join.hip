@@ -111,34 +111,36 @@ join_key_stats_kernel(const void* __restrict__ keys_v, const uint64_t* __restric
     }
 }
 
-// sorted, unique build keys: lanes whose keys fall into the same 64-bit word are neighbours; the last lane of each run writes
-// the combined bits — with a plain store when the run lies strictly inside the wave (then no other wave holds a key of that
-// word), with an atomicOr when it touches the wave's first or last lane
+// sorted, unique build keys: lanes whose keys fall into the same 32-bit piece of the bitmap are neighbours; the last lane of each
+// run writes the combined bits — with a plain store when the run lies strictly inside the wave (then no other wave holds a key
+// of that piece), with an atomicOr when it touches the wave's first or last lane.  (32-bit pieces: the segmented scan moves two
+// 32-bit values per step instead of two 64-bit ones, and the kernel is bound by those instructions.)
 template <int KW>
 __global__ void __launch_bounds__(BLOCK)
-rank_bits_sorted_kernel(const void* __restrict__ keys_v, uint32_t n, uint64_t kmin, unsigned long long* __restrict__ bits) {
+rank_bits_sorted_kernel(const void* __restrict__ keys_v, uint32_t n, uint64_t kmin, unsigned long long* __restrict__ bits64) {
     using K = typename KeyT<KW>::type;
     const K* __restrict__ keys = static_cast<const K*>(keys_v);
+    uint32_t* __restrict__ bits = reinterpret_cast<uint32_t*>(bits64);        // little-endian: piece 2w / 2w + 1 = low / high half of word w
     const int lane = threadIdx.x & 63;
     const uint32_t n_round = (n + 63u) & ~63u;
     for (uint32_t row = blockIdx.x * BLOCK + threadIdx.x; row < n_round; row += gridDim.x * BLOCK) {
         const bool in = row < n;
         const uint64_t d = in ? key_offset<KW>(keys[row], kmin) : 0;
-        const uint64_t wi = in ? (d >> 6) : ~0ull;
-        uint64_t m = in ? (1ull << (d & 63)) : 0ull;
+        const uint32_t wi = in ? (uint32_t)(d >> 5) : 0xFFFFFFFFu;              // (the window holds <= 2^30 values)
+        uint32_t m = in ? (1u << (d & 31)) : 0u;
         // inclusive segmented OR over runs of equal wi (runs are contiguous: the keys increase)
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
-            const uint64_t pm = __shfl_up((unsigned long long)m, off, 64);
-            const uint64_t pw = __shfl_up((unsigned long long)wi, off, 64);
+            const uint32_t pm = __shfl_up(m, off, 64);
+            const uint32_t pw = __shfl_up(wi, off, 64);
             if (lane >= off && pw == wi) m |= pm;
         }
-        const uint64_t next_wi = __shfl_down((unsigned long long)wi, 1, 64);
-        const uint64_t first_wi = __shfl((unsigned long long)wi, 0, 64);     // outside the branch: every lane takes part in a shuffle
+        const uint32_t next_wi = __shfl_down(wi, 1, 64);
+        const uint32_t first_wi = __shfl(wi, 0, 64);     // outside the branch: every lane takes part in a shuffle
         const bool last_of_run = in && (lane == 63 || next_wi != wi);
         if (last_of_run) {
             const bool touches_edge = lane == 63 || first_wi == wi || row + 1 >= n;
-            if (touches_edge) atomicOr(&bits[wi], (unsigned long long)m);
+            if (touches_edge) atomicOr(&bits[wi], m);
             else bits[wi] = m;
         }
     }
