@@ -58,7 +58,7 @@ __device__ __noinline__ uint64_t wave_reduce_call(uint64_t v, int kind) { return
 // NULLS): 128 of them get the whole SIMD's file (AGPRs included), 64 a cap of 256, fewer one of 168 — no variant spills
 constexpr int lowcard_min_blocks(int gmax, int nacc, bool nulls) {
     const int w = gmax * nacc;
-    return w >= 64 ? 1 : (w >= 32 || (nulls && w >= 16)) ? 2 : 3;
+    return w >= 64 ? 1 : (w >= 32 || (nulls && w >= 8)) ? 2 : 3;
 }
 
 template <int R, bool NULLS, int GMAX, bool PREFETCH, int NACC_ = AGG_NACC>

@@ -43,6 +43,16 @@ __device__ inline uint32_t table_upsert(uint32_t* owner, uint64_t mask, const ui
     }
 }
 
+// T.fsum_of_acc[a] without indexing the by-value argument dynamically (that copies the array to scratch: a global-memory read per
+// accumulator and row): the 16 bytes as two scalars, shifted
+__device__ inline uint32_t fsum_index(const HashAggTable& T, int a) {
+    static_assert(VM_MAX_ACC == 16, "two 8-byte halves");
+    uint64_t w0, w1;
+    __builtin_memcpy(&w0, T.fsum_of_acc, 8);
+    __builtin_memcpy(&w1, T.fsum_of_acc + 8, 8);
+    return (uint32_t)(((a < 8 ? w0 : w1) >> (8 * (a & 7))) & 0xFFu);
+}
+
 template <int R, bool NULLS>
 __global__ void __launch_bounds__(BLOCK)
 scan_agg_hash_kernel(const ScanParams P, const HashAggTable T, uint32_t row_base, ScanStatus* status) {
@@ -86,8 +96,9 @@ scan_agg_hash_kernel(const ScanParams P, const HashAggTable T, uint32_t row_base
                     if (NULLS) k = L.vvalid[sp.slot * TILE + idx];
                 }
                 if (sp.kind == ACC_COUNT_VALID || sp.kind == ACC_COUNT_VALID_B) { v = k ? 1 : 0; k = true; }
-                if (T.n_fsum && T.fsum_of_acc[a] != 0xFF) {       // summed later, in row order: record the addend (NULL adds +0.0)
-                    T.fvals[(size_t)T.fsum_of_acc[a] * T.total_rows + grow] = k ? u2d(v) : 0.0;
+                const uint32_t fs = fsum_index(T, a);
+                if (T.n_fsum && fs != 0xFF) {       // summed later, in row order: record the addend (NULL adds +0.0)
+                    T.fvals[(size_t)fs * T.total_rows + grow] = k ? u2d(v) : 0.0;
                     if (NULLS && k) atomicAdd(reinterpret_cast<unsigned long long*>(&T.nvalid[(size_t)slot * T.n_acc + a]), 1ull);
                     continue;
                 }

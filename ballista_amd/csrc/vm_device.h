@@ -80,41 +80,77 @@ struct LoadRegs {
     uint8_t ok[NULLS ? LOAD_GROUP : 1][NULLS ? R : 1];   // without NULLS every loaded value is known
 };
 
+// Two passes over the group's (load, row) pairs: FIRST every global load, raw and unconditional (row index clamped to the last
+// row; narrow values zero-extended, which needs no data), THEN the conversions (sign extension, float -> double, the Boolean's
+// bit, the validity bit).  With the conversion next to its load — one loop — every load was followed by `s_waitcnt vmcnt(0)`:
+// R x n_loads exposed round trips per tile, ~30 us per 1024-row tile in the kernels that load blocking (rocprofv3: 87 % of the
+// wave cycles of scan_agg_hash_kernel waiting on memory, 26 vector loads per tile).
 template <int R, bool NULLS>
 __device__ inline void vm_load_issue_a(const ScanParams& P, int64_t tile_base, int g0, LoadRegs<R, NULLS>& g) {
     const VmProgram& G = P.prog;
     const int tid = threadIdx.x;
+    const int64_t last_row = P.n_rows - 1;                       // (a tile is only loaded when the batch has rows)
+    // (raw bits go straight into g.x / g.ok and are converted in place: no second set of registers)
+    // TWO load shapes only (more cases and the compiler's chain of flag-guarded blocks makes it wait before loads that write a
+    // register some other case may have written): an 8-byte value as one dwordx2; everything narrower as the ALIGNED 4-byte word
+    // that holds it (1- / 2- / 4-byte values, the Boolean's byte), a Utf8 row as its two 4-byte offsets.  (An aligned word that
+    // holds a valid byte lies inside the buffer's allocation granule.)
 #pragma unroll
     for (int j = 0; j < LOAD_GROUP; ++j) {
         if (g0 + j < G.n_loads) {
             const VmLoad ld = G.loads[g0 + j];
             const ColumnRef& c = P.cols[ld.col];
+            const int w = dt_width(ld.dtype);                                           // wave-uniform; 0: Boolean / Utf8
+            const bool utf8 = ld.dtype == DT_UTF8;
+            const BHIP_GLOBAL uint8_t* base = utf8 ? (const BHIP_GLOBAL uint8_t*)gptr<int32_t>(c.offsets) : gptr<uint8_t>(c.data);
+            const int shift = utf8 ? 2 : (w == 2 ? 1 : w == 4 ? 2 : 0);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int64_t row0 = tile_base + r * BLOCK + tid;
+                const int64_t row = row0 < last_row ? row0 : last_row;
+                uint32_t a, b = 0;
+                if (w == 8) {
+                    const uint64_t v2 = gptr<uint64_t>(c.data)[row];
+                    a = (uint32_t)v2; b = (uint32_t)(v2 >> 32);
+                } else {
+                    const int64_t byte = ld.dtype == DT_BOOLEAN ? (row >> 3) : (row << shift);
+                    const BHIP_GLOBAL uint32_t* word = (const BHIP_GLOBAL uint32_t*)(base + (byte & ~(int64_t)3));
+                    a = word[0];
+                    if (utf8) b = word[1];
+                }
+                g.x[j][r] = (uint64_t)a | ((uint64_t)b << 32);
+                if (NULLS) g.ok[NULLS ? j : 0][NULLS ? r : 0] = c.validity ? gptr<uint8_t>(c.validity)[row >> 3] : (uint8_t)0xFF;     // the byte that holds the row's bit
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < LOAD_GROUP; ++j) {
+        if (g0 + j < G.n_loads) {
+            const VmLoad ld = G.loads[g0 + j];
+            const int w = dt_width(ld.dtype);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int64_t row = tile_base + r * BLOCK + tid;
-                uint64_t v = 0;
-                uint8_t k = 0;
-                if (row < P.n_rows) {
-                    switch (ld.dtype) {
-                        case DT_INT32:
-                        case DT_DATE32: v = (uint64_t)(int64_t)gptr<int32_t>(c.data)[row]; break;
-                        case DT_UINT8: v = gptr<uint8_t>(c.data)[row]; break;
-                        case DT_INT8: v = (uint64_t)(int64_t)gptr<int8_t>(c.data)[row]; break;
-                        case DT_INT16: v = (uint64_t)(int64_t)gptr<int16_t>(c.data)[row]; break;
-                        case DT_UINT16: v = gptr<uint16_t>(c.data)[row]; break;
-                        case DT_UINT32: v = gptr<uint32_t>(c.data)[row]; break;
-                        case DT_FLOAT32: v = d2u((double)gptr<float>(c.data)[row]); break;
-                        case DT_BOOLEAN: v = (gptr<uint8_t>(c.data)[row >> 3] >> (row & 7)) & 1u; break;
-                        case DT_UTF8: {   // stage A of a short-string pack: offset in the low, length in the high half
-                            const int32_t o0 = gptr<int32_t>(c.offsets)[row], o1 = gptr<int32_t>(c.offsets)[row + 1];
-                            v = (uint64_t)(uint32_t)o0 | ((uint64_t)(uint32_t)(o1 - o0) << 32);
-                        } break;
-                        default: v = gptr<uint64_t>(c.data)[row]; break;     // every 8-byte type
-                    }
-                    k = NULLS ? (uint8_t)column_valid_bit(c, row) : 1;
+                const int64_t rowc = row < last_row ? row : last_row;
+                const uint32_t lo = (uint32_t)g.x[j][r], b = (uint32_t)(g.x[j][r] >> 32);
+                // the value's bits inside its aligned word
+                const uint32_t a = w == 1 ? (lo >> (8 * (rowc & 3))) & 0xFFu
+                                 : w == 2 ? (lo >> (16 * (rowc & 1))) & 0xFFFFu
+                                 : ld.dtype == DT_BOOLEAN ? (lo >> (8 * ((rowc >> 3) & 3) + (rowc & 7))) & 1u
+                                 : lo;
+                uint64_t v;
+                switch (ld.dtype) {
+                    case DT_INT32:
+                    case DT_DATE32: v = (uint64_t)(int64_t)(int32_t)a; break;
+                    case DT_INT8: v = (uint64_t)(int64_t)(int8_t)a; break;
+                    case DT_INT16: v = (uint64_t)(int64_t)(int16_t)a; break;
+                    case DT_FLOAT32: v = d2u((double)__uint_as_float(a)); break;
+                    case DT_UTF8: v = (uint64_t)a | ((uint64_t)(b - a) << 32); break;   // stage A of a short-string pack: offset | length << 32
+                    default: v = (uint64_t)a | ((uint64_t)b << 32); break;               // Boolean, unsigned narrow types (b = 0), every 8-byte type
                 }
-                g.x[j][r] = v;
-                if (NULLS) g.ok[NULLS ? j : 0][NULLS ? r : 0] = k;
+                const bool in = row < P.n_rows;
+                g.x[j][r] = in ? v : 0;
+                if (NULLS) g.ok[NULLS ? j : 0][NULLS ? r : 0] = in ? (uint8_t)((g.ok[NULLS ? j : 0][NULLS ? r : 0] >> (row & 7)) & 1u) : (uint8_t)0;
             }
         }
     }
