@@ -8,6 +8,12 @@
 
 #include "../util_kernels.h"
 
+// Kernel arguments in device memory (a ROCm runtime option; unset, the argument block of every launch lives in host memory the GPU
+// reads across the bus: ~2-3 us more per launch, and the expression VM's kernels — which read their program out of a by-value
+// argument, scalar load by scalar load — wait on those reads).  Measured on the bench: Q3 4.69 -> 4.52 ms, Q5 3.05 -> 2.98 ms,
+// Q1 5.07 -> 4.99 ms.  Set when the library is loaded, before the process's first HIP call, unless the user has decided otherwise.
+__attribute__((constructor)) static void bhip_runtime_defaults() { setenv("HIP_FORCE_DEV_KERNARG", "1", 0); }
+
 namespace bhip {
 
 static thread_local std::string t_last_error;

@@ -34,6 +34,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("BHIP_KERNEL_TIMING", "1")
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")     # (the library's own default, ballista_amd/csrc/host/core.cpp: set before torch initialises HIP)
 
 SF = 100.0
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
