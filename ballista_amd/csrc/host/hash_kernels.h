@@ -49,6 +49,7 @@ struct DetSum {
     uint32_t* tile_nseg;      // [n_tiles]
     uint32_t* runs;           // [capacity] runs per slot
     uint64_t* acc;            // the table's accumulators [capacity][n_acc]
+    uint64_t* rows;           // the table's row counts [capacity]: every run adds its length (one atomic per run, not per row)
     // spill
     uint64_t* spill_key;      // (slot << 32) | first row
     uint32_t* spill_seg;      // index of the run in the staging area

@@ -304,6 +304,7 @@ GroupRec* hash_aggregate(const Exec& ex, Temp& tmp, const ScanParams& P0, const 
         D.tile_nseg = tmp.get<uint32_t>(n_tiles);
         D.runs = tmp.get<uint32_t>(cap);
         D.acc = T.acc;
+        D.rows = T.rows;
         D.spill_key = tmp.get<uint64_t>(stage_n);
         D.spill_seg = tmp.get<uint32_t>(stage_n);
         D.spill_count = tmp.get<uint32_t>(2);

@@ -32,7 +32,7 @@ det_segments_kernel(const DetSum D, int k0, int first_pass) {
         const uint64_t tile_base = (uint64_t)t * DS_TILE;
         uint32_t n_out = 0;
         // the run that is still open at the end of the previous chunk (wave-uniform)
-        uint32_t c_slot = NONE, c_first = 0;
+        uint32_t c_slot = NONE, c_first = 0, c_last = 0;
         double c_sum[NK];
 #pragma unroll
         for (int k = 0; k < NK; ++k) c_sum[k] = 0.0;
@@ -44,6 +44,7 @@ det_segments_kernel(const DetSum D, int k0, int first_pass) {
                     D.seg_slot[at] = c_slot;
                     D.seg_first[at] = c_first;
                     atomicAdd(&D.runs[c_slot], 1u);
+                    atomicAdd(reinterpret_cast<unsigned long long*>(&D.rows[c_slot]), (unsigned long long)(c_last - c_first + 1u));
                 }
 #pragma unroll
                 for (int k = 0; k < NK; ++k) D.seg_sum[(size_t)(k0 + k) * stage_n + at] = c_sum[k];
@@ -95,6 +96,7 @@ det_segments_kernel(const DetSum D, int k0, int first_pass) {
                     D.seg_slot[at] = slot;
                     D.seg_first[at] = first_row;
                     atomicAdd(&D.runs[slot], 1u);
+                    atomicAdd(reinterpret_cast<unsigned long long*>(&D.rows[slot]), (unsigned long long)((uint32_t)row - first_row + 1u));
                 }
 #pragma unroll
                 for (int k = 0; k < NK; ++k) D.seg_sum[(size_t)(k0 + k) * stage_n + at] = v[k];
@@ -103,6 +105,7 @@ det_segments_kernel(const DetSum D, int k0, int first_pass) {
             // lane 63's run is the new carry
             c_slot = __shfl(slot, 63, 64);
             c_first = __shfl(first_row, 63, 64);
+            c_last = (uint32_t)(tile_base + 64ull * c + 63);
 #pragma unroll
             for (int k = 0; k < NK; ++k) c_sum[k] = __shfl(v[k], 63, 64);
         }

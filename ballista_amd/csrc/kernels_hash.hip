@@ -85,7 +85,8 @@ scan_agg_hash_kernel(const ScanParams P, const HashAggTable T, uint32_t row_base
                 slot = table_upsert(T.owner, T.mask, T.keys128, key, grow);
                 if (T.n_fsum) T.rowslot[grow] = slot;
             }
-            atomicAdd(reinterpret_cast<unsigned long long*>(&T.rows[slot]), 1ull);
+            // (with fixed-order sums the row counts come from the segment kernel: one atomic per run of rows, kernels_dagg.hip)
+            if (!T.n_fsum) atomicAdd(reinterpret_cast<unsigned long long*>(&T.rows[slot]), 1ull);
             for (int a = 0; a < P.n_acc; ++a) {
                 const AccSpec sp = P.acc[a];
                 uint64_t v = 1;
