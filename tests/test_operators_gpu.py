@@ -3,6 +3,8 @@ random batches with NULLs, ragged sizes, empty inputs and the reference's .tbl f
 Bit-exact for integers / strings / per-row Float64 expression values (separately rounded ops);
 row order: preserved where the reference preserves it (Filter, Projection, Limit), else compared
 as multisets (Join, Repartition) or by sort keys (Sort)."""
+from collections import OrderedDict
+
 import numpy as np
 import pytest
 
@@ -602,3 +604,31 @@ def test_like_general_patterns(ctx, pattern):
     m = helpers.memory_exec(ctx, [[b]])
     for op in ("Like", "NotLike"):
         run_both(ba.FilterExec(E.BinaryExpr(col("s"), op, lit(pattern)), m), ordered=True)
+
+
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 63, 64, 65, 1023, 1024, 1025, 5000])
+@pytest.mark.parametrize("density", [0.0, 0.02, 0.5, 1.0])
+def test_filter_selection_sizes_and_densities(ctx, n, density):
+    """select_indices takes 16 rows per lane and writes one set bit per step: row counts around its pieces (16), words (64) and
+    tiles (1024), from nothing selected to everything"""
+    rng = np.random.default_rng(n)
+    keep = rng.random(n) < density
+    b = OrderedDict([("k", OCol("Int32", np.where(keep, 1, 0).astype(np.int32))), ("v", OCol("Int64", np.arange(n, dtype=np.int64))),
+                     ("s", OCol("Utf8", [f"s{i % 11}" for i in range(n)]))])
+    plan = ba.FilterExec(E.coerce(col("k").eq(lit(1)), {"k": "Int32"}), helpers.memory_exec(ctx, [[b]]))
+    helpers.assert_rows_equal(helpers.concat(helpers.collect_product(plan)), plan_eval.collect(plan), ordered=True)
+
+
+@pytest.mark.parametrize("clustered", [True, False])
+def test_hash_aggregate_counts_rows_of_filtered_runs(ctx, clustered):
+    """many groups (the hash path), Float64 sums (fixed order: the segment kernel counts a group's rows run by run) and a
+    predicate that drops rows in the middle of runs: COUNT / AVG need every kept row counted exactly once"""
+    rng = np.random.default_rng(21)
+    n, ng = 60000, 9000
+    g = np.sort(rng.integers(0, ng, n)) if clustered else rng.integers(0, ng, n)
+    b = OrderedDict([("g", OCol("Int32", g.astype(np.int32))), ("x", OCol("Float64", np.round(rng.random(n) * 100, 2))),
+                     ("keep", OCol("Int32", (rng.random(n) > 0.3).astype(np.int32)))])
+    m = helpers.memory_exec(ctx, [[helpers.slice_batch(b, 0, 25000), helpers.slice_batch(b, 25000, n)]])
+    flt = ba.FilterExec(E.coerce(col("keep").eq(lit(1)), {"keep": "Int32"}), m)
+    agg = ba.HashAggregateExec(ba.plan.PARTIAL, [(col("g"), "g")], [E.Sum(col("x"), "s"), E.Count(col("x"), "c"), E.Avg(col("x"), "a")], flt)
+    helpers.assert_rows_equal(helpers.concat(helpers.collect_product(agg)), plan_eval.collect(agg), ordered=False, float_rtol=1e-12, key_cols=["g"])

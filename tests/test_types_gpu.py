@@ -271,3 +271,19 @@ def test_large_utf8_at_the_boundary(ctx, tmp_path):
     assert [ty for _, ty, _ in agg.schema()][:2] == ["LargeUtf8", "LargeUtf8"]
     out = pa.Table.from_batches([b.to_pyarrow() for b in agg.collect()])
     assert out.schema.field("s").type == pa.large_string() and out.num_rows == len(words) + 1
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 7, 15, 16, 17, 63, 65, 255, 257, 1023, 1025])
+def test_narrow_columns_of_odd_lengths_through_the_vm(ctx, n):
+    """1- / 2- / 4-byte values and Booleans are read as the aligned 4-byte word that holds them (vm_device.h): lengths that end
+    inside such a word, with and without NULLs, through a projection (the VM) and a filter (VM predicate: the Boolean column)"""
+    types = ["Int8", "UInt8", "Int16", "UInt16", "Int32", "UInt32", "Float32", "Date32", "Boolean", "Int64"]
+    for nulls in (False, True):
+        b = batch_of(types, n, seed=100 + n, nulls=nulls, small=True)
+        m = helpers.memory_exec(ctx, [[b]])
+        schema = {f"c{i}": t for i, t in enumerate(types)}
+        exprs = [(E.coerce(col("c0") + col("c2"), schema), "a"), (E.coerce(col("c1") + col("c3"), schema), "b"),
+                 (E.coerce(col("c4") + col("c5"), schema), "c"), (E.coerce(col("c6") * lit(2.0, "Float64"), schema), "d"),
+                 (col("c7"), "e"), (E.NotExpr(col("c8")), "f"), (col("c9"), "g")]
+        run_both(ba.ProjectionExec(exprs, m), ordered=True)
+        run_both(ba.FilterExec(col("c8"), m), ordered=True)
