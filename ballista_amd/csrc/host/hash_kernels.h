@@ -32,7 +32,9 @@ struct MergeAccKinds { uint8_t kind[VM_MAX_ACC]; };
 //             tree), a run that continues into the next 64-row chunk carries its sum along; every run end leaves a record
 //             (slot, first row, sums) in the tile's staging area and bumps the slot's run count (an integer atomic);
 //   apply     a slot with ONE run takes its sums with a plain store; the runs of the others go to a spill list;
-//   spill     sorted by (slot, first row) and combined left to right, one thread per slot.
+//   spill     per group a linked list of its runs: a few runs are ordered by first row in registers and combined left to right
+//             by the thread of the earliest run; only when some group has more than DET_LIST_MAX runs is the whole list sorted
+//             by (slot, first row) and combined one thread per slot.
 // Input clustered by group (lineitem by order key: Q3) spills only the runs that straddle a tile; unclustered input spills
 // everything and pays a sort — still the same sums, run to run and whatever the grid.
 struct DetSum {
@@ -53,10 +55,17 @@ struct DetSum {
     // spill
     uint64_t* spill_key;      // (slot << 32) | first row
     uint32_t* spill_seg;      // index of the run in the staging area
-    uint32_t* spill_count;
+    uint32_t* spill_count;    // [0] entries of the spill list; [1] != 0: some group has more runs than the list walk holds
+    uint32_t* spill_next;     // per spill entry: the group's previous entry (a linked list per group, in arrival order), NONE ends it
+    uint32_t* spill_head;     // [capacity] last entry of the group's list, NONE = none
 };
 hipError_t launch_det_segments(const LaunchCfg& cfg, const DetSum& D);
 hipError_t launch_det_apply(const LaunchCfg& cfg, const DetSum& D);
+// groups with a handful of runs (a clustered input's runs straddling a tile): every group's runs are found through its list,
+// ordered by first row in registers and added up left to right — no sort, no host round trip; groups with more than
+// DET_LIST_MAX runs raise spill_count[1] and are left to the sorted combine below
+constexpr int DET_LIST_MAX = 16;
+hipError_t launch_det_spill_lists(const LaunchCfg& cfg, const DetSum& D);
 // sorted_key / sorted_seg: the spill list after a stable sort by key
 hipError_t launch_det_spill_combine(const LaunchCfg& cfg, const DetSum& D, const uint64_t* sorted_key, const uint32_t* sorted_seg, uint32_t n_spill);
 

@@ -291,6 +291,9 @@ GroupRec* hash_aggregate(const Exec& ex, Temp& tmp, const ScanParams& P0, const 
         TIMED_LAUNCH_N(ex, "scan_agg_hash", b->n_rows, launch_scan_agg_hash(cfg, P, T, row_base, status));
         row_base += (uint32_t)b->n_rows;
     }
+    // [0] the group count (the scan below), [1] the spill list's entry count | "lists too long" << 32: read in one piece
+    uint64_t* tail = tmp.get<uint64_t>(2);
+    HIP_CHECK(hipMemsetAsync(tail, 0, 16, ex.stream));
     if (T.n_fsum) {
         const size_t n_tiles = ((size_t)total_rows + 1023) / 1024, stage_n = n_tiles * 1024;
         D.rowslot = T.rowslot;
@@ -307,27 +310,35 @@ GroupRec* hash_aggregate(const Exec& ex, Temp& tmp, const ScanParams& P0, const 
         D.rows = T.rows;
         D.spill_key = tmp.get<uint64_t>(stage_n);
         D.spill_seg = tmp.get<uint32_t>(stage_n);
-        D.spill_count = tmp.get<uint32_t>(2);
+        D.spill_count = reinterpret_cast<uint32_t*>(tail + 1);
+        D.spill_next = tmp.get<uint32_t>(stage_n);
+        D.spill_head = tmp.get<uint32_t>(cap);
         HIP_CHECK(hipMemsetAsync(D.runs, 0, cap * 4, ex.stream));
+        HIP_CHECK(hipMemsetAsync(D.spill_head, 0xFF, cap * 4, ex.stream));
         HIP_CHECK(hipMemsetAsync(D.spill_count, 0, 8, ex.stream));
         TIMED_LAUNCH_N(ex, "det_segments", total_rows, launch_det_segments(cfg, D));
         TIMED_LAUNCH_N(ex, "det_apply", total_rows, launch_det_apply(cfg, D));
-        const uint32_t n_spill = read_device(ex, D.spill_count);
-        if (n_spill) {
-            // runs of groups that have several: ordered by (slot, first row), then added up left to right
-            BufferPtr kb = std::make_shared<Buffer>(ex.ctx, D.spill_key, (size_t)n_spill * 8), pb2 = std::make_shared<Buffer>(ex.ctx, D.spill_seg, (size_t)n_spill * 4);
-            radix_sort_pairs(ex, kb, pb2, (int64_t)n_spill);
-            TIMED_LAUNCH_N(ex, "det_spill_combine", n_spill, launch_det_spill_combine(cfg, D, kb->as<uint64_t>(), pb2->as<uint32_t>(), n_spill));
-        }
+        // groups with several runs: combined through their lists right here; the entry count and the "lists too long" flag are
+        // read together with the group count below (ONE host wait for the whole tail of the aggregate)
+        TIMED_LAUNCH_N(ex, "det_spill_lists", total_rows, launch_det_spill_lists(cfg, D));
     }
     // used slots -> dense records (slot order: deterministic for a given input)
     uint32_t* flags = tmp.get<uint32_t>(cap);
     uint64_t* dense = tmp.get<uint64_t>(cap + 1);
-    uint64_t* total = tmp.get<uint64_t>(1);
+    uint64_t* total = tail;
     void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes((int64_t)cap));
     TIMED_LAUNCH_N(ex, "hash_agg_flags", cap, launch_hash_agg_flags(cfg, T, flags));
     HIP_CHECK(exclusive_scan_u32_u64(ex.stream, flags, (int64_t)cap, dense, false, total, scan_tmp));
-    const uint64_t ng = read_device(ex, total);
+    struct Tail { uint64_t n_groups; uint32_t n_spill, lists_too_long; };
+    const Tail tl = read_device(ex, reinterpret_cast<const Tail*>(tail));
+    const uint64_t ng = tl.n_groups;
+    if (T.n_fsum && tl.lists_too_long) {
+        // some group has many runs (unclustered input): the whole list ordered by (slot, first row), then added up left to right
+        const uint32_t n_spill = tl.n_spill;
+        BufferPtr kb = std::make_shared<Buffer>(ex.ctx, D.spill_key, (size_t)n_spill * 8), pb2 = std::make_shared<Buffer>(ex.ctx, D.spill_seg, (size_t)n_spill * 4);
+        radix_sort_pairs(ex, kb, pb2, (int64_t)n_spill);
+        TIMED_LAUNCH_N(ex, "det_spill_combine", n_spill, launch_det_spill_combine(cfg, D, kb->as<uint64_t>(), pb2->as<uint32_t>(), n_spill));
+    }
     check_scan_status(ex, status);                   // after the one wait above: the stream is idle, this read is immediate
     GroupRec* table = tmp.get<GroupRec>(ng ? ng : 1);
     if (ng) TIMED_LAUNCH_N(ex, "hash_agg_compact", cap, launch_hash_agg_compact(cfg, T, dense, nullable, table));

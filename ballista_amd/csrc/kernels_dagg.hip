@@ -134,7 +134,58 @@ det_apply_kernel(const DetSum D) {
                 const uint32_t pos = atomicAdd(D.spill_count, 1u);
                 D.spill_key[pos] = ((uint64_t)slot << 32) | D.seg_first[at];
                 D.spill_seg[pos] = (uint32_t)at;
+                D.spill_next[pos] = atomicExch(&D.spill_head[slot], pos);
             }
+        }
+    }
+}
+
+// One thread per spill entry walks its group's list (at most DET_LIST_MAX entries: first row + run index of each).  The entry with
+// the SMALLEST first row orders the list by first row (insertion into a sorted prefix: the arrays stay in registers, every index
+// is static) and adds the runs' sums left to right; the others have nothing to do.  The result does not depend on the order in
+// which the entries were linked.  A longer list raises the flag for the sorted combine.
+__global__ void __launch_bounds__(BLOCK)
+det_spill_lists_kernel(const DetSum D) {
+    const uint32_t n_spill = D.spill_count[0];
+    const uint32_t n_tiles = (uint32_t)((D.total_rows + DS_TILE - 1) / DS_TILE);
+    const size_t stage_n = (size_t)n_tiles * DS_TILE;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n_spill; i += gridDim.x * BLOCK) {
+        const uint32_t slot = (uint32_t)(D.spill_key[i] >> 32), mine = (uint32_t)D.spill_key[i];
+        uint32_t first[DET_LIST_MAX], seg[DET_LIST_MAX];
+#pragma unroll
+        for (int q = 0; q < DET_LIST_MAX; ++q) { first[q] = NONE; seg[q] = 0; }
+        uint32_t e = D.spill_head[slot];
+        int n = 0;
+        bool leader = true;
+        while (e != NONE && n <= DET_LIST_MAX) {
+            const uint32_t f = (uint32_t)D.spill_key[e], sg = D.spill_seg[e];
+            leader = leader && f >= mine;
+            if (n < DET_LIST_MAX) {
+                // insert (f, sg) into the sorted prefix: everything greater moves one place up
+                uint32_t cf = f, cs = sg;
+#pragma unroll
+                for (int q = 0; q < DET_LIST_MAX; ++q) {
+                    const bool sw = cf < first[q];
+                    const uint32_t tf = first[q], ts = seg[q];
+                    first[q] = sw ? cf : tf; seg[q] = sw ? cs : ts;
+                    cf = sw ? tf : cf; cs = sw ? ts : cs;
+                }
+            }
+            ++n;
+            e = D.spill_next[e];
+        }
+        if (n > DET_LIST_MAX) { D.spill_count[1] = 1u; continue; }           // too many runs for the walk: the sorted combine takes over
+        if (!leader) continue;
+        for (int k = 0; k < D.n_fsum; ++k) {
+            double total = 0.0;
+#pragma unroll
+            for (int q = 0; q < DET_LIST_MAX; ++q) {
+                if (q < n) {
+                    const double v = D.seg_sum[(size_t)k * stage_n + seg[q]];
+                    total = q == 0 ? v : total + v;
+                }
+            }
+            D.acc[(size_t)slot * D.n_acc + D.acc_of_fsum[k]] = (uint64_t)__double_as_longlong(total);
         }
     }
 }
@@ -186,6 +237,13 @@ hipError_t launch_det_segments(const LaunchCfg& cfg, const DetSum& D) {
 hipError_t launch_det_apply(const LaunchCfg& cfg, const DetSum& D) {
     if (D.total_rows == 0) return hipSuccess;
     hipLaunchKernelGGL(det_apply_kernel, dim3(tile_grid(cfg, D.total_rows)), dim3(BLOCK), 0, cfg.stream, D);
+    return hipGetLastError();
+}
+
+hipError_t launch_det_spill_lists(const LaunchCfg& cfg, const DetSum& D) {
+    if (D.total_rows == 0) return hipSuccess;
+    // the number of entries is on the device: a modest grid, grid-stride over the list
+    hipLaunchKernelGGL(det_spill_lists_kernel, dim3((unsigned)cfg.device_cus * 2), dim3(BLOCK), 0, cfg.stream, D);
     return hipGetLastError();
 }
 

@@ -619,12 +619,14 @@ def test_filter_selection_sizes_and_densities(ctx, n, density):
     helpers.assert_rows_equal(helpers.concat(helpers.collect_product(plan)), plan_eval.collect(plan), ordered=True)
 
 
+@pytest.mark.parametrize("ng", [9000, 150])
 @pytest.mark.parametrize("clustered", [True, False])
-def test_hash_aggregate_counts_rows_of_filtered_runs(ctx, clustered):
+def test_hash_aggregate_counts_rows_of_filtered_runs(ctx, clustered, ng):
     """many groups (the hash path), Float64 sums (fixed order: the segment kernel counts a group's rows run by run) and a
-    predicate that drops rows in the middle of runs: COUNT / AVG need every kept row counted exactly once"""
+    predicate that drops rows in the middle of runs: COUNT / AVG need every kept row counted exactly once.  9000 groups: a few
+    runs per group, combined through the per-group lists; 150 unclustered groups: hundreds of runs each, the sorted combine"""
     rng = np.random.default_rng(21)
-    n, ng = 60000, 9000
+    n = 60000
     g = np.sort(rng.integers(0, ng, n)) if clustered else rng.integers(0, ng, n)
     b = OrderedDict([("g", OCol("Int32", g.astype(np.int32))), ("x", OCol("Float64", np.round(rng.random(n) * 100, 2))),
                      ("keep", OCol("Int32", (rng.random(n) > 0.3).astype(np.int32)))])
