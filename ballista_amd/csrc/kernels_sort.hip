@@ -11,6 +11,7 @@
 // any sorting network.  HBM traffic per pass: read keys+ids twice, write once (12 B x 3 per row);
 // passes whose byte is the same in every key are skipped (one OR-reduction per key tells).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "sort_kernels.h"
 #include "util_kernels.h"
 #include "vm_device.h"
@@ -21,14 +22,25 @@ constexpr int SORT_BLOCK = 256;
 constexpr int SORT_ITEMS = 16;                       // sub-tiles per chunk
 constexpr int SORT_CHUNK = SORT_BLOCK * SORT_ITEMS;  // 4096 rows per workgroup
 
+// ITEMS sub-tiles of 256 rows per workgroup: 16 for large inputs; 4 for up to 2 Mi rows, where a pass is latency-bound (three
+// barriers and a dependent load per sub-tile) and 4x the workgroups hide it (tools/exp_sort.py, two keys: 200 K rows 0.45 -> 0.33 ms,
+// 1.13 M rows 0.60 -> 0.52 ms, 4 M rows 1.08 -> 1.17 ms)
+constexpr int SORT_ITEMS_SMALL = 4;
+static int sort_items_for(int64_t n) {
+    static const int forced = [] { const char* v = getenv("BHIP_SORT_ITEMS"); return v ? atoi(v) : 0; }();       // 4 | 16: A/B
+    if (forced == SORT_ITEMS_SMALL || forced == SORT_ITEMS) return forced;
+    return n <= (1ll << 21) ? SORT_ITEMS_SMALL : SORT_ITEMS;
+}
+
+template <int ITEMS>
 __global__ void __launch_bounds__(SORT_BLOCK)
 radix_hist_kernel(const uint64_t* keys, int64_t n, int shift, uint32_t* hist, int n_blocks) {
     __shared__ uint32_t s_hist[256];
     s_hist[threadIdx.x] = 0;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * SORT_CHUNK;
+    const int64_t base = (int64_t)blockIdx.x * (SORT_BLOCK * ITEMS);
 #pragma unroll
-    for (int i = 0; i < SORT_ITEMS; ++i) {
+    for (int i = 0; i < ITEMS; ++i) {
         const int64_t j = base + i * SORT_BLOCK + threadIdx.x;
         if (j < n) atomicAdd(&s_hist[(keys[j] >> shift) & 0xFF], 1u);
     }
@@ -36,6 +48,7 @@ radix_hist_kernel(const uint64_t* keys, int64_t n, int shift, uint32_t* hist, in
     hist[(size_t)threadIdx.x * n_blocks + blockIdx.x] = s_hist[threadIdx.x];   // digit-major
 }
 
+template <int ITEMS>
 __global__ void __launch_bounds__(SORT_BLOCK)
 radix_scatter_kernel(const uint64_t* keys, const uint32_t* vals, int64_t n, int shift, const uint32_t* offsets,
                      int n_blocks, uint64_t* keys_out, uint32_t* vals_out) {
@@ -43,8 +56,8 @@ radix_scatter_kernel(const uint64_t* keys, const uint32_t* vals, int64_t n, int 
     __shared__ uint32_t s_wave[4][256];         // per-wave digit counts of the current sub-tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     s_base[tid] = offsets[(size_t)tid * n_blocks + blockIdx.x];
-    const int64_t base = (int64_t)blockIdx.x * SORT_CHUNK;
-    for (int i = 0; i < SORT_ITEMS; ++i) {
+    const int64_t base = (int64_t)blockIdx.x * (SORT_BLOCK * ITEMS);
+    for (int i = 0; i < ITEMS; ++i) {
         for (int w = 0; w < 4; ++w) s_wave[w][tid] = 0;
         __syncthreads();
         const int64_t j = base + i * SORT_BLOCK + tid;
@@ -201,7 +214,8 @@ key_diff_kernel(const uint64_t* keys, int64_t n, uint64_t* out) {
 }
 
 size_t radix_sort_temp_bytes(int64_t n) {
-    const int64_t n_blocks = (n + SORT_CHUNK - 1) / SORT_CHUNK;
+    const int64_t chunk = (int64_t)SORT_BLOCK * sort_items_for(n);
+    const int64_t n_blocks = (n + chunk - 1) / chunk;
     const size_t hist = (size_t)256 * (n_blocks > 0 ? n_blocks : 1) * 4;
     return 2 * hist + exclusive_scan_temp_bytes(256 * n_blocks) + 64;
 }
@@ -250,16 +264,23 @@ hipError_t small_sort_pairs(const LaunchCfg& cfg, uint64_t* keys, uint32_t* vals
 hipError_t radix_pass(const LaunchCfg& cfg, const uint64_t* keys, const uint32_t* vals, int64_t n, int byte,
                       uint64_t* keys_out, uint32_t* vals_out, void* temp) {
     if (n == 0) return hipSuccess;
-    const int n_blocks = (int)((n + SORT_CHUNK - 1) / SORT_CHUNK);
+    const bool small = sort_items_for(n) == SORT_ITEMS_SMALL;
+    const int64_t chunk = (int64_t)SORT_BLOCK * sort_items_for(n);
+    const int n_blocks = (int)((n + chunk - 1) / chunk);
     const size_t hist_elems = (size_t)256 * n_blocks;
     uint32_t* hist = reinterpret_cast<uint32_t*>(temp);
     uint32_t* offsets = hist + hist_elems;
     void* scan_tmp = offsets + hist_elems + 4;
-    hipLaunchKernelGGL(radix_hist_kernel, dim3(n_blocks), dim3(SORT_BLOCK), 0, cfg.stream, keys, n, byte * 8, hist, n_blocks);
+    if (small) hipLaunchKernelGGL(radix_hist_kernel<SORT_ITEMS_SMALL>, dim3(n_blocks), dim3(SORT_BLOCK), 0, cfg.stream, keys, n, byte * 8, hist, n_blocks);
+    else hipLaunchKernelGGL(radix_hist_kernel<SORT_ITEMS>, dim3(n_blocks), dim3(SORT_BLOCK), 0, cfg.stream, keys, n, byte * 8, hist, n_blocks);
     hipError_t e = exclusive_scan_u32_u32(cfg.stream, hist, (int64_t)hist_elems, offsets, false, nullptr, scan_tmp);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(radix_scatter_kernel, dim3(n_blocks), dim3(SORT_BLOCK), 0, cfg.stream, keys, vals, n, byte * 8,
-                       offsets, n_blocks, keys_out, vals_out);
+    if (small)
+        hipLaunchKernelGGL(radix_scatter_kernel<SORT_ITEMS_SMALL>, dim3(n_blocks), dim3(SORT_BLOCK), 0, cfg.stream, keys, vals, n, byte * 8,
+                           offsets, n_blocks, keys_out, vals_out);
+    else
+        hipLaunchKernelGGL(radix_scatter_kernel<SORT_ITEMS>, dim3(n_blocks), dim3(SORT_BLOCK), 0, cfg.stream, keys, vals, n, byte * 8,
+                           offsets, n_blocks, keys_out, vals_out);
     return hipGetLastError();
 }
 
