@@ -241,3 +241,26 @@ def test_parents_that_read_only_some_join_columns(ctx, jt):
     agg = ba.HashAggregateExec(ba.plan.PARTIAL, [(col("ls"), "ls")], [E.Sum(col("ry"), "s"), E.Count(lit(1, E.UINT8), "n")], j)
     fin = ba.HashAggregateExec(ba.plan.FINAL, [(col("ls"), "ls")], [E.Sum(col("ry"), "s"), E.Count(lit(1, E.UINT8), "n")], ba.MergeExec(agg))
     check(fin, ["ls"])
+
+
+@pytest.mark.parametrize("sorted_build", [True, False])
+@pytest.mark.parametrize("n_ranges", [2, 3])
+def test_probe_side_filter_of_several_ranges(ctx, n_ranges, sorted_build):
+    """the probe kernel compiled for JOIN_FILTER_MAX range columns (an AND of two or three Int32 / Date32 ranges under the join),
+    over a build side in key order (rank = row) and one that is not (rank -> row through the permutation)"""
+    rng = np.random.default_rng(31 + n_ranges)
+    nl, nr = 700, 9000
+    lk = rng.permutation(3000)[:nl].astype(np.int32)
+    if sorted_build:
+        lk = np.sort(lk)
+    left = OrderedDict([("lk", OCol("Int32", lk)), ("lx", OCol("Float64", rng.random(nl)))])
+    right = OrderedDict([("rk", OCol("Int32", rng.integers(-20, 3100, nr).astype(np.int32))), ("ra", OCol("Int32", rng.integers(0, 100, nr).astype(np.int32))),
+                         ("rb", OCol("Date32", rng.integers(9000, 9400, nr).astype(np.int32))), ("rc", OCol("Int32", rng.integers(-50, 50, nr).astype(np.int32))),
+                         ("ry", OCol("Int64", rng.integers(0, 10 ** 6, nr)))])
+    schema = {"rk": "Int32", "ra": "Int32", "rb": "Date32", "rc": "Int32", "ry": "Int64"}
+    pred = (col("ra") >= lit(10)).and_(col("ra") < lit(80)).and_(col("rb") > E.date32("1994-12-01"))
+    if n_ranges == 3:
+        pred = pred.and_(col("rc") <= lit(20))
+    rm = helpers.memory_exec(ctx, [[helpers.slice_batch(right, 0, 4100), helpers.slice_batch(right, 4100, nr)]])
+    plan = ba.HashJoinExec(helpers.memory_exec(ctx, [[left]]), ba.FilterExec(E.coerce(pred, schema), rm), [("lk", "rk")], ba.plan.INNER)
+    check(plan, ["lk", "rk", "ry", "lx"])
