@@ -644,7 +644,10 @@ StreamPtr HashJoinExec::execute_needed(int partition, const Exec& ex, const std:
             // the selection bitmap (a semi-join — no build column read — has nothing else to compact and takes the bitmap route)
             uint32_t* staging_rows = need_left ? tmp.get<uint32_t>((size_t)n_tiles * SEL_TILE) : nullptr;
             // algorithmic bytes: the predicate columns and the key column once, one selection bit per row
-            TIMED_LAUNCH_B(ex, "join_filter_probe", n, (uint64_t)n * (uint64_t)(bs->narrow_width + 4 * F.n) + (uint64_t)n / 8,
+            // (named after the kernel the launcher picks — kernels_join.hip launch_join_filter_probe: rank map, no NULL probe keys,
+            // an inner join -> join_rank_probe_kernel — so that bench.py's roofline line and the rocprofv3 summaries agree)
+            const bool direct = bs->ntable.rpack != nullptr && !kc.validity && !left_outer && !right_outer;
+            TIMED_LAUNCH_B(ex, direct ? "join_rank_probe" : "join_filter_probe", n, (uint64_t)n * (uint64_t)(bs->narrow_width + 4 * F.n) + (uint64_t)n / 8,
                            launch_join_filter_probe(cfg, bs->ntable, F, kc.data->ptr(), bs->narrow_width,
                                                     kc.validity ? kc.validity->as<uint64_t>() : nullptr, (uint32_t)n, right_outer, bitmap,
                                                     tile_counts, staging, left_outer ? matched->as<uint32_t>() : nullptr,

@@ -8,6 +8,8 @@ decoded before `plan.execute`): join build sides, hash tables and path choices a
 as in a task that has just decoded its plan (rust/executor/src/flight_service.rs:87-121).
 
   python bench.py --gpus N --steps K --warmup W [--query q1]
+      (two more untimed passes run before the W warmup steps, as part of the setup: they bring the library's caching allocator
+      to its steady state, so that no timed step calls hipMalloc whatever W is; `setup_passes` in the output line)
       N > 1: one process per GPU.  When WORLD_SIZE is not set this process only spawns
       `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child (before anything touches the
       GPU) and relays its output and exit code.
@@ -207,19 +209,28 @@ def main():
         group.barrier()
         ctx.synchronize()
 
+    step_times = os.environ.get("BHIP_BENCH_STEP_TIMES", "0") not in ("", "0")
+
     def timed(step, steps, warmup):
         result = None
-        W.prepare(steps + warmup)
-        for _ in range(warmup):
+        # two untimed passes before the warmup proper: the caching allocator reaches its steady state (the first pass of a
+        # process allocates ~70 device buffers with hipMalloc, the second a few more; from the third on a step allocates none)
+        W.prepare(steps + warmup + 2)
+        for _ in range(warmup + 2):
             result = step()
         ctx.synchronize()
         ctx.kernel_stats(reset=True)
         ctx.kernel_time(reset=True)
         barrier()
         t0 = time.perf_counter()
+        marks = []
         for _ in range(steps):
             result = step()
+            if step_times:                                       # diagnosis only (BHIP_BENCH_STEP_TIMES=1): wall time of every step
+                marks.append(time.perf_counter())
         barrier()
+        if step_times and rank == 0:
+            print("step ms:", [round((b - a) * 1e3, 3) for a, b in zip([t0] + marks[:-1], marks)], file=sys.stderr)
         elapsed = group.max_over_ranks(time.perf_counter() - t0)
         return elapsed, result, ctx.kernel_stats(reset=True)
 
@@ -248,7 +259,7 @@ def main():
         algo_job = W.algorithmic_bytes(key_bytes)
         out = {
             "metric": f"tpch_{args.query}_sf{args.sf:g}_rows_per_sec", "value": rows_job * args.steps / elapsed, "unit": "rows/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "setup_passes": 2, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": W.describe(), "lineitem_rows": rows_job, "rows_per_gpu": rows_launch,
