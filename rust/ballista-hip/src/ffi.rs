@@ -113,6 +113,15 @@ extern "C" {
     pub fn bhip_plan_collect(plan: *mut bhip_plan, cap: i32, out: *mut *mut bhip_batch, n_out: *mut i32) -> bhip_status;
     pub fn bhip_plan_release(plan: *mut bhip_plan);
 
+    /// utils::write_stream_to_disk (rust/core/src/utils.rs:49-84) on the device side: drains `stream` into an Arrow IPC file and
+    /// reports PartitionStats; the stream is consumed
+    pub fn bhip_stream_write_ipc(
+        stream: *mut bhip_stream,
+        path: *const c_char,
+        num_rows: *mut u64,
+        num_batches: *mut u64,
+        num_bytes: *mut u64,
+    ) -> bhip_status;
     pub fn bhip_stream_next(stream: *mut bhip_stream, out: *mut *mut bhip_batch) -> bhip_status;
     pub fn bhip_stream_release(stream: *mut bhip_stream);
     pub fn bhip_batch_export_arrow(batch: *mut bhip_batch, out_array: *mut FFI_ArrowArray, out_schema: *mut FFI_ArrowSchema) -> bhip_status;

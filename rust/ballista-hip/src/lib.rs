@@ -205,6 +205,35 @@ impl GpuExec {
     }
 }
 
+/// What `write_stream_to_disk` reports for a stage partition (rust/core/src/utils.rs:49-84, `PartitionStats`).
+#[derive(Debug, Clone, Copy, Default)]
+pub struct StageFileStats {
+    pub num_rows: u64,
+    pub num_batches: u64,
+    pub num_bytes: u64,
+}
+
+impl GpuExec {
+    /// One stage partition straight into its Arrow IPC file: the executor's
+    /// `plan.execute(partition)` + `utils::write_stream_to_disk(&mut stream, path)` (rust/executor/src/flight_service.rs:104-150)
+    /// as one library call — the batches go from HBM to the file writer without becoming host `RecordBatch`es in between.
+    pub async fn execute_to_file(&self, partition: usize, path: &str) -> Result<StageFileStats> {
+        let plan = self.gpu_plan()?;
+        let cpath = std::ffi::CString::new(path).map_err(|e| DataFusionError::Execution(format!("{:?}", e)))?;
+        tokio::task::spawn_blocking(move || -> Result<StageFileStats> {
+            let mut raw = std::ptr::null_mut();
+            check(unsafe { ffi::bhip_plan_execute(plan.0, partition as i32, &mut raw) })?;
+            let mut st = StageFileStats::default();
+            let status = unsafe { ffi::bhip_stream_write_ipc(raw, cpath.as_ptr(), &mut st.num_rows, &mut st.num_batches, &mut st.num_bytes) };
+            unsafe { ffi::bhip_stream_release(raw) };
+            check(status)?;
+            Ok(st)
+        })
+        .await
+        .map_err(|e| DataFusionError::Execution(format!("{:?}", e)))?
+    }
+}
+
 #[async_trait]
 impl ExecutionPlan for GpuExec {
     fn as_any(&self) -> &dyn Any {
