@@ -747,7 +747,8 @@ bhip_status bhip_ipc_open_file(const char* path, struct ArrowArrayStream* out) {
 
 bhip_status bhip_stream_write_ipc(bhip_stream* stream, const char* path, uint64_t* num_rows, uint64_t* num_batches, uint64_t* num_bytes) {
     BHIP_I_BEGIN
-    if (!stream || !path) fail(BHIP_EINVAL, "null argument");
+    if (!stream) fail(BHIP_EINVAL, "null argument");
+    if (!path) { bhip_stream_release(stream); fail(BHIP_EINVAL, "null argument: path"); }    // consumed on every path
     ArrowArrayStream cs;
     memset(&cs, 0, sizeof(cs));
     const bhip_status st = bhip_stream_export_arrow(stream, &cs);      // consumes the stream

@@ -692,7 +692,8 @@ struct Decoder {
         }
         static const char* ops[] = {"", "CsvExec", "ParquetExec", "ShuffleReaderExec", "UnresolvedShuffleExec"};
         int parts = 1;
-        if (L.kind == BHIP_LEAF_SHUFFLE_READER) parts = 1;
+        // ShuffleReaderExec reports one output partition per location (rust/core/src/execution_plans/shuffle_reader.rs:61)
+        if (L.kind == BHIP_LEAF_SHUFFLE_READER) parts = std::max<int>(1, (int)L.locations.size());
         if (L.kind == BHIP_LEAF_UNRESOLVED_SHUFFLE) parts = (int)L.partition_count;
         return std::make_shared<UnresolvedLeafExec>(ops[L.kind], leaf_text(L, out_schema), out_schema, parts);
     }

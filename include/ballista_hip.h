@@ -360,7 +360,8 @@ bhip_status bhip_stream_drain(bhip_stream* stream, bhip_batch_sink sink, void* u
 /* ---- Arrow IPC files: the two sides of a stage boundary ------------------------------------------------------
  * bhip_stream_write_ipc = utils::write_stream_to_disk (rust/core/src/utils.rs:49-84): drains the stream into an Arrow IPC
  * FILE at `path` (what the executor serves to the next stage, rust/executor/src/flight_service.rs:104-150) and reports
- * PartitionStats.  The stream is consumed.
+ * PartitionStats.  The stream is CONSUMED on every path, success or error (a NULL `stream` aside): the caller must NOT call
+ * bhip_stream_release on it afterwards.
  * bhip_plan_ipc_files: a leaf over such files, one output partition per file — the local half of ShuffleReaderExec
  * (rust/core/src/execution_plans/shuffle_reader.rs:77-99).  Files written by arrow-rs / pyarrow are read as well
  * (metadata V4 or V5, no compression, no dictionaries; other files -> BHIP_ENOTIMPL).

@@ -224,8 +224,9 @@ impl GpuExec {
             let mut raw = std::ptr::null_mut();
             check(unsafe { ffi::bhip_plan_execute(plan.0, partition as i32, &mut raw) })?;
             let mut st = StageFileStats::default();
+            // bhip_stream_write_ipc CONSUMES the stream on every path (include/ballista_hip.h): no bhip_stream_release here —
+            // a second release would free it twice (tests/c/shim_sequence.c pins this ownership rule under the host ASan build)
             let status = unsafe { ffi::bhip_stream_write_ipc(raw, cpath.as_ptr(), &mut st.num_rows, &mut st.num_batches, &mut st.num_bytes) };
-            unsafe { ffi::bhip_stream_release(raw) };
             check(status)?;
             Ok(st)
         })
@@ -346,7 +347,9 @@ pub fn offload(plan: Arc<dyn ExecutionPlan>, gpu: &Arc<GpuContext>) -> Result<Ar
     }
     match GpuExec::try_new(plan.clone(), gpu.clone()) {
         Ok(exec) => Ok(Arc::new(exec)),
-        Err(DataFusionError::NotImplemented(why)) => {
+        // NotImplemented = the library declines the subtree; Plan = its dry run refused something the CPU operators may still
+        // accept (a coercion or operator it does not model).  Either way the CPU plan stays and reports its own errors.
+        Err(DataFusionError::NotImplemented(why)) | Err(DataFusionError::Plan(why)) => {
             log::debug!("not offloaded ({}): {:?}", why, plan);
             let children = plan.children().into_iter().map(|c| offload(c, gpu)).collect::<Result<Vec<_>>>()?;
             plan.with_new_children(children)
