@@ -70,6 +70,11 @@ class LeafDesc(C.Structure):
                 ("stage_ids", C.POINTER(C.c_uint32)), ("partition_count", C.c_uint32)]
 
 
+class TpchOpts(C.Structure):
+    _fields_ = [("key64", C.c_int32), ("with_dates", C.c_int32), ("sparse_keys", C.c_int32), ("n_columns", C.c_int32),
+                ("key_base", C.c_int64), ("columns", C.POINTER(C.c_char_p))]
+
+
 LEAF_RESOLVER = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(LeafDesc), C.POINTER(C.c_void_p))
 
 
@@ -154,6 +159,8 @@ SYMBOLS = {
     "bhip_batch_unpack": (C.c_int32, [_P, C.c_int32, C.POINTER(ColumnDesc), C.POINTER(C.c_int64), _P, _PP]),
     "bhip_tpch_lineitem": (C.c_int32, [_P, C.c_double, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32, _PP]),
     "bhip_tpch_orders": (C.c_int32, [_P, C.c_double, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32, _PP]),
+    "bhip_tpch_lineitem_opts": (C.c_int32, [_P, C.c_double, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(TpchOpts), _PP]),
+    "bhip_tpch_orders_opts": (C.c_int32, [_P, C.c_double, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(TpchOpts), _PP]),
 }
 
 _lib = None

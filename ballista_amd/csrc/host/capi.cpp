@@ -572,11 +572,20 @@ static Column gen_char_col(const Exec& ex, int64_t n) {
     return c;
 }
 
-bhip_status bhip_tpch_lineitem(bhip_ctx* ctx, double sf, uint64_t seed, uint64_t row0, uint64_t n, int32_t key64,
-                               int32_t with_dates, bhip_batch** out) {
+// columns == NULL: every column; else only the named ones, in the table's own column order
+static bool gen_wants(const bhip_tpch_opts* o, const char* name) {
+    if (!o || !o->columns || o->n_columns <= 0) return true;
+    for (int i = 0; i < o->n_columns; ++i)
+        if (o->columns[i] && !strcmp(o->columns[i], name)) return true;
+    return false;
+}
+
+bhip_status bhip_tpch_lineitem_opts(bhip_ctx* ctx, double sf, uint64_t seed, uint64_t row0, uint64_t n, const bhip_tpch_opts* opts,
+                                    bhip_batch** out) {
     BHIP_API_BEGIN
     need(ctx, "ctx"); need(out, "out");
     if (n > 0xFFFFFFF0ull) fail(BHIP_EINVAL, "at most 2^32-16 rows per batch");
+    const bool key64 = opts && opts->key64, with_dates = opts && opts->with_dates;
     const TpchCard card = tpch_card(sf);
     ctx->p->set_device();
     Exec ex{ctx->p, nullptr};
@@ -587,32 +596,38 @@ bhip_status bhip_tpch_lineitem(bhip_ctx* ctx, double sf, uint64_t seed, uint64_t
     auto add = [&](const char* name, Column c) { s->fields.push_back(Field{name, c.dtype, false}); b->cols.push_back(std::move(c)); };
     GenLineitemOut o;
     memset(&o, 0, sizeof(o));
-    Column okey = gen_col(ex, key64 ? DT_INT64 : DT_INT32, n);
-    if (key64) o.l_orderkey_i64 = okey.data->as<int64_t>(); else o.l_orderkey = okey.data->as<int32_t>();
-    add("l_orderkey", okey);
-    Column c = gen_col(ex, DT_INT32, n); o.l_suppkey = c.data->as<int32_t>(); add("l_suppkey", c);
-    c = gen_col(ex, DT_FLOAT64, n); o.l_quantity = c.data->as<double>(); add("l_quantity", c);
-    c = gen_col(ex, DT_FLOAT64, n); o.l_extendedprice = c.data->as<double>(); add("l_extendedprice", c);
-    c = gen_col(ex, DT_FLOAT64, n); o.l_discount = c.data->as<double>(); add("l_discount", c);
-    c = gen_col(ex, DT_FLOAT64, n); o.l_tax = c.data->as<double>(); add("l_tax", c);
-    c = gen_char_col(ex, n); o.flag_off = c.offsets->as<int32_t>(); o.flag_data = c.data->as<uint8_t>(); add("l_returnflag", c);
-    c = gen_char_col(ex, n); o.status_off = c.offsets->as<int32_t>(); o.status_data = c.data->as<uint8_t>(); add("l_linestatus", c);
-    c = gen_col(ex, DT_DATE32, n); o.l_shipdate = c.data->as<int32_t>(); add("l_shipdate", c);
-    if (with_dates) {
-        c = gen_col(ex, DT_DATE32, n); o.l_commitdate = c.data->as<int32_t>(); add("l_commitdate", c);
-        c = gen_col(ex, DT_DATE32, n); o.l_receiptdate = c.data->as<int32_t>(); add("l_receiptdate", c);
+    Column c;
+    if (gen_wants(opts, "l_orderkey")) {
+        c = gen_col(ex, key64 ? DT_INT64 : DT_INT32, n);
+        if (key64) o.l_orderkey_i64 = c.data->as<int64_t>(); else o.l_orderkey = c.data->as<int32_t>();
+        add("l_orderkey", c);
     }
+    if (gen_wants(opts, "l_suppkey")) { c = gen_col(ex, DT_INT32, n); o.l_suppkey = c.data->as<int32_t>(); add("l_suppkey", c); }
+    if (gen_wants(opts, "l_quantity")) { c = gen_col(ex, DT_FLOAT64, n); o.l_quantity = c.data->as<double>(); add("l_quantity", c); }
+    if (gen_wants(opts, "l_extendedprice")) { c = gen_col(ex, DT_FLOAT64, n); o.l_extendedprice = c.data->as<double>(); add("l_extendedprice", c); }
+    if (gen_wants(opts, "l_discount")) { c = gen_col(ex, DT_FLOAT64, n); o.l_discount = c.data->as<double>(); add("l_discount", c); }
+    if (gen_wants(opts, "l_tax")) { c = gen_col(ex, DT_FLOAT64, n); o.l_tax = c.data->as<double>(); add("l_tax", c); }
+    if (gen_wants(opts, "l_returnflag")) { c = gen_char_col(ex, n); o.flag_off = c.offsets->as<int32_t>(); o.flag_data = c.data->as<uint8_t>(); add("l_returnflag", c); }
+    if (gen_wants(opts, "l_linestatus")) { c = gen_char_col(ex, n); o.status_off = c.offsets->as<int32_t>(); o.status_data = c.data->as<uint8_t>(); add("l_linestatus", c); }
+    if (gen_wants(opts, "l_shipdate")) { c = gen_col(ex, DT_DATE32, n); o.l_shipdate = c.data->as<int32_t>(); add("l_shipdate", c); }
+    if (with_dates) {
+        if (gen_wants(opts, "l_commitdate")) { c = gen_col(ex, DT_DATE32, n); o.l_commitdate = c.data->as<int32_t>(); add("l_commitdate", c); }
+        if (gen_wants(opts, "l_receiptdate")) { c = gen_col(ex, DT_DATE32, n); o.l_receiptdate = c.data->as<int32_t>(); add("l_receiptdate", c); }
+    }
+    if (s->fields.empty()) fail(BHIP_EINVAL, "bhip_tpch_lineitem_opts: no such column");
     b->schema = s;
-    HIP_CHECK(launch_gen_lineitem(ex.cfg(), seed, row0, n, card.orders, card.part, card.supplier, o));
+    const GenKeyLayout keys{opts ? opts->key_base : 0, opts && opts->sparse_keys ? 1 : 0};
+    HIP_CHECK(launch_gen_lineitem(ex.cfg(), seed, row0, n, card.orders, card.part, card.supplier, o, keys));
     HIP_CHECK(hipDeviceSynchronize());
     *out = wrap_batch(b);
     BHIP_API_END
 }
 
-bhip_status bhip_tpch_orders(bhip_ctx* ctx, double sf, uint64_t seed, uint64_t row0, uint64_t n, int32_t key64, bhip_batch** out) {
+bhip_status bhip_tpch_orders_opts(bhip_ctx* ctx, double sf, uint64_t seed, uint64_t row0, uint64_t n, const bhip_tpch_opts* opts, bhip_batch** out) {
     BHIP_API_BEGIN
     need(ctx, "ctx"); need(out, "out");
     if (n > 0xFFFFFFF0ull) fail(BHIP_EINVAL, "at most 2^32-16 rows per batch");
+    const bool key64 = opts && opts->key64;
     const TpchCard card = tpch_card(sf);
     ctx->p->set_device();
     Exec ex{ctx->p, nullptr};
@@ -623,17 +638,38 @@ bhip_status bhip_tpch_orders(bhip_ctx* ctx, double sf, uint64_t seed, uint64_t r
     auto add = [&](const char* name, Column c) { s->fields.push_back(Field{name, c.dtype, false}); b->cols.push_back(std::move(c)); };
     GenOrdersOut o;
     memset(&o, 0, sizeof(o));
-    Column okey = gen_col(ex, key64 ? DT_INT64 : DT_INT32, n);
-    if (key64) o.o_orderkey_i64 = okey.data->as<int64_t>(); else o.o_orderkey = okey.data->as<int32_t>();
-    add("o_orderkey", okey);
-    Column c = gen_col(ex, DT_INT32, n); o.o_custkey = c.data->as<int32_t>(); add("o_custkey", c);
-    c = gen_col(ex, DT_DATE32, n); o.o_orderdate = c.data->as<int32_t>(); add("o_orderdate", c);
-    c = gen_col(ex, DT_INT32, n); o.o_shippriority = c.data->as<int32_t>(); add("o_shippriority", c);
+    Column c;
+    if (gen_wants(opts, "o_orderkey")) {
+        c = gen_col(ex, key64 ? DT_INT64 : DT_INT32, n);
+        if (key64) o.o_orderkey_i64 = c.data->as<int64_t>(); else o.o_orderkey = c.data->as<int32_t>();
+        add("o_orderkey", c);
+    }
+    if (gen_wants(opts, "o_custkey")) { c = gen_col(ex, DT_INT32, n); o.o_custkey = c.data->as<int32_t>(); add("o_custkey", c); }
+    if (gen_wants(opts, "o_orderdate")) { c = gen_col(ex, DT_DATE32, n); o.o_orderdate = c.data->as<int32_t>(); add("o_orderdate", c); }
+    if (gen_wants(opts, "o_shippriority")) { c = gen_col(ex, DT_INT32, n); o.o_shippriority = c.data->as<int32_t>(); add("o_shippriority", c); }
+    if (s->fields.empty()) fail(BHIP_EINVAL, "bhip_tpch_orders_opts: no such column");
     b->schema = s;
-    HIP_CHECK(launch_gen_orders(ex.cfg(), seed, row0, n, card.customer, o));
+    const GenKeyLayout keys{opts ? opts->key_base : 0, opts && opts->sparse_keys ? 1 : 0};
+    HIP_CHECK(launch_gen_orders(ex.cfg(), seed, row0, n, card.customer, o, keys));
     HIP_CHECK(hipDeviceSynchronize());
     *out = wrap_batch(b);
     BHIP_API_END
+}
+
+bhip_status bhip_tpch_lineitem(bhip_ctx* ctx, double sf, uint64_t seed, uint64_t row0, uint64_t n, int32_t key64,
+                               int32_t with_dates, bhip_batch** out) {
+    bhip_tpch_opts o;
+    memset(&o, 0, sizeof(o));
+    o.key64 = key64;
+    o.with_dates = with_dates;
+    return bhip_tpch_lineitem_opts(ctx, sf, seed, row0, n, &o, out);
+}
+
+bhip_status bhip_tpch_orders(bhip_ctx* ctx, double sf, uint64_t seed, uint64_t row0, uint64_t n, int32_t key64, bhip_batch** out) {
+    bhip_tpch_opts o;
+    memset(&o, 0, sizeof(o));
+    o.key64 = key64;
+    return bhip_tpch_orders_opts(ctx, sf, seed, row0, n, &o, out);
 }
 
 }  // extern "C"

@@ -117,12 +117,13 @@ struct NarrowJoinTable {
     uint64_t* slots;
     uint64_t mask;
     uint32_t* dup_flag;       // set when two build rows share a key: the host falls back to JoinTable
-    // optional with the CAS table: the exact set of build keys, one bit per value of [kmin64, kmin64 + krange] (null: absent)
+    // optional with the CAS table: the exact set of build keys, one bit per value of [kmin64, kmin64 + krange64] (null: absent)
     const uint32_t* present;
-    uint32_t kmin, krange;
+    uint32_t kmin;
+    uint64_t krange64;        // last offset of the window: keys in [kmin64, kmin64 + krange64] (rank map: <= 2^36; key-set bitmap: <= 2^30)
     uint64_t kmin64;          // first key of the window as raw key bits (32-bit keys: zero- or sign-extension does not matter, the
                               // offset is taken modulo 2^32)
-    // rank map (kernels_join.hip; keys inside a window of <= 2^30 values): rpack[g] = the key set of granule g (32 key values,
+    // rank map (kernels_join.hip; keys inside a window of <= 2^36 values — TPC-H SF1000 order keys reach 6 x 10^9): rpack[g] = the key set of granule g (32 key values,
     // low half) | the number of build keys before the granule (high half): ONE 8-byte read gives a probe row its membership bit and
     // its rank; rank -> build row through rperm (null: the build side is sorted by key, rank = row)
     const uint64_t* rpack;

@@ -281,8 +281,11 @@ std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) co
         const bool sorted = host_stats[2] == 0;
         bs->ntable.kmin64 = kmin;
         bs->ntable.kmin = (uint32_t)kmin;
-        // a window of at most 2^30 values that is not absurdly sparse (<= 1 KiB of map per build row)
-        const bool window_ok = any_key && range <= (1ull << 30) && range / 4096 <= (uint64_t)n + 256;
+        // a window of at most 2^36 values (granule indices and `rzero` are 32-bit; SF1000 order keys span 1.5 - 6 x 10^9 and hash
+        // partitioning does not narrow a rank's window) that is not absurdly sparse (<= 1 KiB of map per build row).
+        // BHIP_RANK_WINDOW_LOG2 lowers the bound (30 = the round-2 limit: the A/B partner, profiles/r03_rank_window_ab.txt)
+        static const int window_log2 = [] { const char* v = getenv("BHIP_RANK_WINDOW_LOG2"); const int b = v ? atoi(v) : 36; return b < 10 ? 10 : (b > 36 ? 36 : b); }();
+        const bool window_ok = any_key && range <= (1ull << window_log2) && range / 4096 <= (uint64_t)n + 256;
         if (window_ok && !force_table) {
             // ---- rank map ----------------------------------------------------------------------------------------------
             const int64_t n_words = (int64_t)(range >> 6) + 1, n_gran = 2 * n_words;
@@ -309,7 +312,7 @@ std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) co
                 bs->ntable.rpack = bs->rpack->as<uint64_t>();
                 bs->ntable.rzero = (uint32_t)n_gran;
                 bs->ntable.rperm = bs->rperm ? bs->rperm->as<uint32_t>() : nullptr;
-                bs->ntable.krange = (uint32_t)range;
+                bs->ntable.krange64 = range;
                 bs->narrow = bs->unique = true;
                 static const bool radix_ab = [] { const char* v = getenv("BHIP_JOIN_RADIX"); return v && atoi(v) != 0; }();
                 if (radix_ab && nkw == 4 && !ksel && n < (1ll << 31)) {
@@ -346,7 +349,7 @@ std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) co
                 bs->ntable.dup_flag = nullptr;
                 if (bs->present) {
                     bs->ntable.present = bs->present->as<uint32_t>();
-                    bs->ntable.krange = (uint32_t)range;
+                    bs->ntable.krange64 = range;
                 }
                 bs->narrow = bs->unique = true;
                 return true;

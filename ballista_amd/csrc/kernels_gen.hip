@@ -44,6 +44,11 @@ __device__ inline uint64_t order_of_line(uint64_t seed, uint64_t row, uint64_t n
     return (group * 7u + j) % n_orders;
 }
 
+__device__ inline int64_t order_key(uint64_t ord, GenKeyLayout L) {
+    const uint64_t k = L.sparse ? (((ord >> 3) << 5) | (ord & 7u)) : ord;
+    return L.key_base + (int64_t)(k + 1u);
+}
+
 __device__ inline int32_t order_date(uint64_t seed, uint64_t order) {
     return 8035 + (int32_t)(rnd(seed, ODATE, order) % 2406u);   // 1992-01-01 .. 1998-08-02
 }
@@ -52,7 +57,7 @@ __device__ inline int32_t order_date(uint64_t seed, uint64_t order) {
 
 __global__ void __launch_bounds__(256)
 gen_lineitem_kernel(uint64_t seed, uint64_t row0, uint64_t n, uint64_t n_orders, uint64_t n_parts, uint64_t n_supp,
-                    GenLineitemOut o) {
+                    GenLineitemOut o, GenKeyLayout keys) {
     using namespace gen;
     for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (uint64_t)gridDim.x * 256) {
         const uint64_t row = row0 + k;
@@ -63,8 +68,8 @@ gen_lineitem_kernel(uint64_t seed, uint64_t row0, uint64_t n, uint64_t n_orders,
         const uint64_t retail = 90000u + ((part / 10u) % 20001u) + 100u * (part % 1000u);   // cents
         const int32_t ship = odate + 1 + (int32_t)(rnd(seed, SHIP, row) % 121u);
         const int32_t receipt = ship + 1 + (int32_t)(rnd(seed, RECEIPT, row) % 30u);
-        if (o.l_orderkey) o.l_orderkey[k] = (int32_t)(ord + 1u);
-        if (o.l_orderkey_i64) o.l_orderkey_i64[k] = (int64_t)(ord + 1u);
+        if (o.l_orderkey) o.l_orderkey[k] = (int32_t)order_key(ord, keys);
+        if (o.l_orderkey_i64) o.l_orderkey_i64[k] = order_key(ord, keys);
         if (o.l_suppkey) o.l_suppkey[k] = (int32_t)(1u + rnd(seed, SUPP, row) % n_supp);
         if (o.l_quantity) o.l_quantity[k] = (double)qty;
         if (o.l_extendedprice) o.l_extendedprice[k] = (double)((uint64_t)qty * retail) / 100.0;
@@ -90,14 +95,14 @@ gen_lineitem_kernel(uint64_t seed, uint64_t row0, uint64_t n, uint64_t n_orders,
 }
 
 __global__ void __launch_bounds__(256)
-gen_orders_kernel(uint64_t seed, uint64_t row0, uint64_t n, uint64_t n_cust, GenOrdersOut o) {
+gen_orders_kernel(uint64_t seed, uint64_t row0, uint64_t n, uint64_t n_cust, GenOrdersOut o, GenKeyLayout keys) {
     using namespace gen;
     for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (uint64_t)gridDim.x * 256) {
         const uint64_t ord = row0 + k;
         uint64_t cust = 1u + rnd(seed, OCUST, ord) % n_cust;
         if (cust % 3u == 0) cust -= 1u;            // TPC-H: a third of the customers never order
-        if (o.o_orderkey) o.o_orderkey[k] = (int32_t)(ord + 1u);
-        if (o.o_orderkey_i64) o.o_orderkey_i64[k] = (int64_t)(ord + 1u);
+        if (o.o_orderkey) o.o_orderkey[k] = (int32_t)order_key(ord, keys);
+        if (o.o_orderkey_i64) o.o_orderkey_i64[k] = order_key(ord, keys);
         if (o.o_custkey) o.o_custkey[k] = (int32_t)cust;
         if (o.o_orderdate) o.o_orderdate[k] = order_date(seed, ord);
         if (o.o_shippriority) o.o_shippriority[k] = 0;
@@ -113,16 +118,16 @@ static int gen_grid(const LaunchCfg& cfg, uint64_t n) {
 }
 
 hipError_t launch_gen_lineitem(const LaunchCfg& cfg, uint64_t seed, uint64_t row0, uint64_t n, uint64_t n_orders,
-                               uint64_t n_parts, uint64_t n_supp, const GenLineitemOut& out) {
+                               uint64_t n_parts, uint64_t n_supp, const GenLineitemOut& out, GenKeyLayout keys) {
     hipLaunchKernelGGL(gen_lineitem_kernel, dim3(gen_grid(cfg, n)), dim3(256), 0, cfg.stream, seed, row0, n, n_orders,
-                       n_parts, n_supp, out);
+                       n_parts, n_supp, out, keys);
     return hipGetLastError();
 }
 
 hipError_t launch_gen_orders(const LaunchCfg& cfg, uint64_t seed, uint64_t row0, uint64_t n, uint64_t n_cust,
-                             const GenOrdersOut& out) {
+                             const GenOrdersOut& out, GenKeyLayout keys) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(gen_orders_kernel, dim3(gen_grid(cfg, n)), dim3(256), 0, cfg.stream, seed, row0, n, n_cust, out);
+    hipLaunchKernelGGL(gen_orders_kernel, dim3(gen_grid(cfg, n)), dim3(256), 0, cfg.stream, seed, row0, n, n_cust, out, keys);
     return hipGetLastError();
 }
 

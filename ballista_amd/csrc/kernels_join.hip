@@ -2,7 +2,7 @@
 // build side — every join of TPC-H Q3 / Q5 but Q5's two-column supplier join.
 //
 // BUILD.  `join_key_stats` reads the build keys once: min, max, "strictly increasing" (= sorted and unique).
-//   * Keys inside a window of <= 2^30 values (dense surrogate keys: o_orderkey, c_custkey, ...) get a RANK MAP instead of a hash
+//   * Keys inside a window of <= 2^36 values (dense surrogate keys: o_orderkey, c_custkey, ...) get a RANK MAP instead of a hash
 //     table: bits[] = the exact key set, one bit per value of the window; prefix[w] = set bits before 64-bit word w.  The rank of
 //     a present key (prefix + popcount of the lower bits of its word) IS its build row when the build side arrives sorted by key
 //     (a table stored in key order stays sorted under FilterExec); otherwise perm[rank] = build row.  No CAS, no collisions, no
@@ -39,6 +39,13 @@ template <int KW>
 __device__ inline uint64_t key_offset(typename KeyT<KW>::type key, uint64_t kmin) {
     if constexpr (KW == 4) return (uint64_t)(uint32_t)(key - (uint32_t)kmin);
     else return key - kmin;
+}
+
+// offset inside the window?  (4-byte keys: offsets are < 2^32 and so is the window's last offset — a 32-bit compare)
+template <int KW>
+__device__ inline bool in_window(uint64_t off, uint64_t krange) {
+    if constexpr (KW == 4) return (uint32_t)off <= (uint32_t)krange;
+    else return off <= krange;
 }
 
 // ---- build ---------------------------------------------------------------------------------------------------------------
@@ -126,7 +133,7 @@ rank_bits_sorted_kernel(const void* __restrict__ keys_v, uint32_t n, uint64_t km
     for (uint32_t row = blockIdx.x * BLOCK + threadIdx.x; row < n_round; row += gridDim.x * BLOCK) {
         const bool in = row < n;
         const uint64_t d = in ? key_offset<KW>(keys[row], kmin) : 0;
-        const uint32_t wi = in ? (uint32_t)(d >> 5) : 0xFFFFFFFFu;              // (the window holds <= 2^30 values)
+        const uint32_t wi = in ? (uint32_t)(d >> 5) : 0xFFFFFFFFu;              // (the window holds <= 2^36 values)
         uint32_t m = in ? (1u << (d & 31)) : 0u;
         // inclusive segmented OR over runs of equal wi (runs are contiguous: the keys increase)
 #pragma unroll
@@ -295,10 +302,11 @@ join_filter_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const voi
 #pragma unroll
                 for (int k = 0; k < FP_ROWS; ++k) {
                     const uint64_t off = key_offset<KW>(cur.key[k], T.kmin64);
-                    live[k] = live[k] && off <= T.krange;
-                    d[k] = live[k] ? (uint32_t)off : 0u;                                  // the window holds <= 2^30 values
-                    if (ranked) word[k] = T.rpack[d[k] >> 5];                             // key set of the granule | keys before it << 32
-                    else word[k] = (uint64_t)T.present[d[k] >> 5];
+                    live[k] = live[k] && in_window<KW>(off, T.krange64);
+                    const uint32_t g = live[k] ? (uint32_t)(off >> 5) : 0u;               // the window holds <= 2^36 values (key-set bitmap: 2^30)
+                    d[k] = (uint32_t)off & 31u;
+                    if (ranked) word[k] = T.rpack[g];                                     // key set of the granule | keys before it << 32
+                    else word[k] = (uint64_t)T.present[g];
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 prefetch();
@@ -453,16 +461,18 @@ join_rank_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void*
                 for (int j = 0; j < NF; ++j)
                     if (j < F.n) p = p && cur.f[j][k] >= F.lo[j] && cur.f[j][k] <= F.hi[j];
                 const uint64_t off = key_offset<KW>(cur.key[k], T.kmin64);
-                d[k] = (uint32_t)off;                                                     // (the window holds <= 2^30 values)
+                // granule index and bit inside it (the window holds <= 2^36 values: < 2^31 granules; 4-byte keys stay in 32-bit arithmetic)
+                const uint32_t g = KW == 4 ? ((uint32_t)off >> 5) : (uint32_t)(off >> 5);
+                d[k] = (uint32_t)off & 31u;
                 // a row the filter dropped, or whose key lies outside the window, reads the all-zero granule behind the map: the
                 // bit test below is then the whole decision — ONE compare, whose lane mask is the ballot (a ballot of an AND of
                 // conditions costs two more vector instructions per row slot)
-                pk[k] = rpack[(p && off <= T.krange) ? d[k] >> 5 : T.rzero];
+                pk[k] = rpack[(p && in_window<KW>(off, T.krange64)) ? g : T.rzero];
             }
             if (!PERM && !RESID) prefetch();
 #pragma unroll
             for (int k = 0; k < FP_ROWS; ++k) {
-                const uint32_t bits = (uint32_t)pk[k], sh = d[k] & 31u;
+                const uint32_t bits = (uint32_t)pk[k], sh = d[k];
                 live[k] = ((bits >> sh) & 1u) != 0u;
                 m[k] = (uint32_t)(pk[k] >> 32) + (uint32_t)__popc(bits & ((1u << sh) - 1u));
             }

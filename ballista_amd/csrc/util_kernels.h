@@ -147,12 +147,15 @@ struct GenLineitemOut {
     int32_t* l_shipdate; int32_t* l_commitdate; int32_t* l_receiptdate;
     int32_t* flag_off; uint8_t* flag_data; int32_t* status_off; uint8_t* status_data;
 };
+// order key of order index `ord` (0-based): key_base + 1 + (sparse ? dbgen's layout — the low 3 bits kept, the rest shifted up by
+// two: 8 of every 32 values used, SF1000 keys reach 6 x 10^9 — : ord)
+struct GenKeyLayout { int64_t key_base; int32_t sparse; };
 hipError_t launch_gen_lineitem(const LaunchCfg& cfg, uint64_t seed, uint64_t row0, uint64_t n, uint64_t n_orders,
-                               uint64_t n_parts, uint64_t n_supp, const GenLineitemOut& out);
+                               uint64_t n_parts, uint64_t n_supp, const GenLineitemOut& out, GenKeyLayout keys = GenKeyLayout{0, 0});
 struct GenOrdersOut {
     int32_t* o_orderkey; int64_t* o_orderkey_i64; int32_t* o_custkey; int32_t* o_orderdate; int32_t* o_shippriority;
 };
 hipError_t launch_gen_orders(const LaunchCfg& cfg, uint64_t seed, uint64_t row0, uint64_t n, uint64_t n_cust,
-                             const GenOrdersOut& out);
+                             const GenOrdersOut& out, GenKeyLayout keys = GenKeyLayout{0, 0});
 
 }  // namespace bhip

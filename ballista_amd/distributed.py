@@ -115,6 +115,9 @@ class SingleGroup:
     def all_to_all(self, eng, parts):
         return list(parts)
 
+    def describe(self):
+        return dict(world=1, ranks_seen=[0], transport="none")
+
     def close(self):
         pass
 
@@ -191,6 +194,9 @@ class GlooGroup:
                 req.wait()
         return [parts[s] if s == self.rank else eng.from_wire(recv[s].numpy(), parts[s]) for s in range(self.world)]
 
+    def describe(self):
+        return dict(world=self.world, ranks_seen=list(range(self.world)), transport="gloo (host memory)")
+
     def close(self):
         self.dist.destroy_process_group()
 
@@ -201,12 +207,19 @@ class RcclGroup(GlooGroup):
     second HIP runtime through PyTorch."""
     backend = "nccl"
 
-    def __init__(self, dist):
+    def __init__(self, dist, allow_host_exchange=False):
         super().__init__(dist)
         self.comm = None
+        self.allow_host_exchange = allow_host_exchange
+        self.ranks_seen = []
 
     def device_index(self, local_rank):
         return local_rank
+
+    def describe(self):
+        if self.comm is None:
+            return dict(world=self.world, ranks_seen=[], transport="NONE: RCCL unavailable, batches through host memory over gloo")
+        return dict(world=self.world, ranks_seen=self.ranks_seen, transport="rccl")
 
     def attach(self, ctx):
         import torch
@@ -224,6 +237,7 @@ class RcclGroup(GlooGroup):
             mine = P.RecordBatch.from_columns(ctx, [("r", "Int32", [self.rank], None)])
             got = self.comm.all_gather(mine)
             seen = [int(b.column(0)[1][0]) for b in got]
+            self.ranks_seen = seen
             if seen != list(range(self.world)):
                 err = f"all_gather self-test returned {seen}"
         except Exception as e:                                   # noqa: BLE001 — any failure means the same thing here
@@ -237,7 +251,11 @@ class RcclGroup(GlooGroup):
                 except Exception:                                # noqa: BLE001
                     pass
             self.comm = None
-            self.backend = "gloo, batches through host memory (RCCL communicator unavailable: " + (err or "on another rank") + ")"
+            why = "RCCL communicator unavailable: " + (err or "on another rank")
+            if not self.allow_host_exchange:
+                # a scaling record must not show N ranks and a plausible value with RCCL never having moved a byte
+                raise RuntimeError(why + " — refusing to fall back to host-staged gloo (pass --allow-host-exchange to bench.py to rehearse that way)")
+            self.backend = "gloo, batches through host memory (" + why + ")"
 
     def all_gather(self, eng, batch):
         if self.comm is None:
@@ -262,12 +280,12 @@ class ProcessGroup:
         return SingleGroup()
 
     @staticmethod
-    def from_env(backend="nccl"):
+    def from_env(backend="nccl", allow_host_exchange=False):
         """RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as torch.distributed.run sets them"""
         import torch.distributed as dist
         if not dist.is_initialized():
             dist.init_process_group("gloo")
-        return RcclGroup(dist) if backend == "nccl" else GlooGroup(dist)
+        return RcclGroup(dist, allow_host_exchange) if backend == "nccl" else GlooGroup(dist)
 
 
 # ---- distributed query flows (engine- and transport-agnostic) -------------------------------------------------------
@@ -395,6 +413,18 @@ class Workload:
                          "q3": lambda: tpch.q3_plan(t["customer"], t["orders"], t["lineitem"]),
                          "q5": lambda: tpch.q5_plan(t["customer"], t["orders"], t["lineitem"], t["supplier"], t["nation"], t["region"])}[self.query]()
         ctx.synchronize()
+
+    def unload(self):
+        """release the tables and every plan over them (the next workload's tables need the HBM)"""
+        self.t.clear()
+        self.plan = None
+        self.cold, self.spent = [], []
+        import gc
+        gc.collect()
+        self.ctx.synchronize()
+
+    def host_overhead(self, reset=False):
+        return None
 
     def prepare(self, n):
         """n operator trees that have never run (tpch.fresh), built ahead of the timed region: a task's plan is decoded from the

@@ -941,13 +941,28 @@ def concat(ctx: Context, batches: Sequence[RecordBatch]) -> RecordBatch:
     return RecordBatch(h, ctx)
 
 
-def tpch_lineitem(ctx: Context, sf: float, seed: int, row0: int, n: int, key64=False, with_dates=False) -> RecordBatch:
+def _tpch_opts(key64, with_dates, sparse_keys, key_base, columns):
+    o = L.TpchOpts()
+    o.key64, o.with_dates, o.sparse_keys, o.key_base = int(bool(key64)), int(bool(with_dates)), int(bool(sparse_keys)), int(key_base)
+    keep = None
+    if columns:
+        keep = (C.c_char_p * len(columns))(*[c.encode() for c in columns])
+        o.columns, o.n_columns = keep, len(columns)
+    return o, keep
+
+
+def tpch_lineitem(ctx: Context, sf: float, seed: int, row0: int, n: int, key64=False, with_dates=False, sparse_keys=False, key_base=0,
+                  columns=None) -> RecordBatch:
+    """synthetic lineitem rows [row0, row0 + n) on the device.  sparse_keys: dbgen's order-key layout (8 of every 32 values);
+    key_base: added to every order key; columns: only these"""
     h = C.c_void_p()
-    L.check(L.lib().bhip_tpch_lineitem(ctx._h, sf, seed, row0, n, 1 if key64 else 0, 1 if with_dates else 0, C.byref(h)))
+    o, _keep = _tpch_opts(key64, with_dates, sparse_keys, key_base, columns)
+    L.check(L.lib().bhip_tpch_lineitem_opts(ctx._h, sf, seed, row0, n, C.byref(o), C.byref(h)))
     return RecordBatch(h, ctx)
 
 
-def tpch_orders(ctx: Context, sf: float, seed: int, row0: int, n: int, key64=False) -> RecordBatch:
+def tpch_orders(ctx: Context, sf: float, seed: int, row0: int, n: int, key64=False, sparse_keys=False, key_base=0, columns=None) -> RecordBatch:
     h = C.c_void_p()
-    L.check(L.lib().bhip_tpch_orders(ctx._h, sf, seed, row0, n, 1 if key64 else 0, C.byref(h)))
+    o, _keep = _tpch_opts(key64, False, sparse_keys, key_base, columns)
+    L.check(L.lib().bhip_tpch_orders_opts(ctx._h, sf, seed, row0, n, C.byref(o), C.byref(h)))
     return RecordBatch(h, ctx)

@@ -56,6 +56,13 @@ def parse(argv=None):
     ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the extra weak-scaling measurement")
     ap.add_argument("--join-exchange", default="shuffle", choices=["shuffle", "broadcast"],
                     help="N > 1, q3 / q5: hash-partition both sides of the order-key join (config #5) or broadcast the build side")
+    ap.add_argument("--configs", default="q6,q3,q5", help="N = 1 and --query q1 (the default run): further queries measured after Q1 and "
+                    "reported under \"configs\" (\"\" = none)")
+    ap.add_argument("--config-steps", type=int, default=10, help="timed steps of each query under --configs")
+    ap.add_argument("--config-cpu-rows", type=int, default=48_000_000, help="CPU-baseline sample rows of each query under --configs")
+    ap.add_argument("--allow-host-exchange", action="store_true",
+                    help="N > 1 with --backend nccl: if the RCCL communicator cannot be created, move batches through host memory over gloo "
+                         "instead of exiting non-zero (the line then says so in exchange_backend)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="transport for N > 1 (nccl = RCCL; gloo only to rehearse the N-rank flow on a box with fewer GPUs)")
     return ap.parse_args(argv)
@@ -104,7 +111,7 @@ def _best_of(fn, budget_s=10.0, min_reps=3):
     return best, total, reps
 
 
-def cpu_baseline(query, sf, sample_rows):
+def cpu_baseline(query, sf, sample_rows, budget_s=10.0):
     """oracle port (DataFusion structure: 32768-row batches, materialised intermediates, one partition per thread) on
     rows [0, sample_rows) of the same seeded lineitem (Q3 / Q5: with the matching prefix of orders and the whole small
     tables)"""
@@ -120,13 +127,13 @@ def cpu_baseline(query, sf, sample_rows):
         port = gen.JoinQueryPort(query, sf, sample_rows, tpch.dimension_arrays(sf))
         fn = lambda: port.run(parts, cores)
         what = f"oracle/oracle_ops.c::oracle_{query}_join_port (both hash-join builds inside the timed call)"
-    best, total, reps = _best_of(fn)
+    best, total, reps = _best_of(fn, budget_s)
     return dict(value=sample_rows / best, unit="rows/s", cores=cores, kind="port",
                 sample=f"lineitem rows [0,{sample_rows}) of the seeded SF{sf:g} table, {parts} partitions, best of {reps} passes "
                        f"({total:.1f} s of CPU work), {what}")
 
 
-def cpu_baseline_acero(query, sf, sample_rows):
+def cpu_baseline_acero(query, sf, sample_rows, budget_s=5.0):
     """Arrow C++ (pyarrow compute / Acero) on the same sample: an independent CPU engine, NOT the reference"""
     try:
         import numpy as np
@@ -161,48 +168,35 @@ def cpu_baseline_acero(query, sf, sample_rows):
         f = t.filter(m)
         return pc.sum(pc.multiply(f["l_extendedprice"], f["l_discount"]))
 
-    best, total, reps = _best_of(q1 if query == "q1" else q6, budget_s=5.0)
+    best, total, reps = _best_of(q1 if query == "q1" else q6, budget_s=budget_s)
     return dict(value=sample_rows / best, unit="rows/s", cores=_cpu_threads(), kind="acero",
                 sample=f"pyarrow {pa.__version__} compute + group_by on rows [0,{sample_rows}), best of {reps} passes ({total:.1f} s)")
 
 
 def pmc_traffic(kernel, rows, query):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic*.json, written by
-    tools/profile_bench.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 runs of this command).  FETCH_SIZE is
-    doubled (gfx950 counts wide streaming reads at half, MI355X_MICROARCH.md §HBM).  None when no pass exists for
-    this kernel, query and table size — counters cannot be read from inside."""
+    """(HBM bytes per launch of `kernel`, where that number comes from).  Counters cannot be read from inside a run: the
+    bytes are those of the COMMITTED PMC passes (profiles/pmc_traffic*.json, written by tools/profile_bench.sh: FETCH_SIZE
+    and WRITE_SIZE in separate rocprofv3 runs of this command), NOT a measurement of this run.  FETCH_SIZE is doubled
+    (gfx950 counts wide streaming reads at half, MI355X_MICROARCH.md §HBM).  (None, None) when no pass exists for this
+    kernel, query and table size."""
     for name in (f"pmc_traffic_{query}.json", "pmc_traffic.json"):
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", name)))
         except (OSError, ValueError):
             continue
         if kernel and kernel in rec.get("kernel", "") and rec.get("rows_per_launch") == rows and rec.get("query", "q1") == query:
-            return (2.0 * rec["fetch_size_kb_per_launch"] + rec["write_size_kb_per_launch"]) * 1024.0
-    return None
+            return ((2.0 * rec["fetch_size_kb_per_launch"] + rec["write_size_kb_per_launch"]) * 1024.0,
+                    f"profiles/{name} (committed rocprofv3 --pmc pass of this command, not measured in this run)")
+    return None, None
 
 
-def main():
-    args = parse()
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        sys.exit(self_launch(args))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+def measure(query, args, ctx, group, world, rank, n, cpu_rows, cpu_budget_s, steps, warmup):
+    """load `query`'s tables, time `steps` steps of it, return (line dict on rank 0 | None).  Frees the tables on return."""
+    import ballista_amd as ba                                       # noqa: F401
+    from ballista_amd import distributed as D
 
-    import ballista_amd as ba
-    from ballista_amd import tpch, distributed as D
-
-    group = D.ProcessGroup.from_env(args.backend) if world > 1 else D.ProcessGroup.single()
-    ctx = ba.Context(group.device_index(local_rank))
-    group.attach(ctx)
-
-    n = tpch.table_rows(args.sf)
-    if args.rows:
-        n["lineitem"] = args.rows
     key_bytes = 8 if args.key64 else 4
-    W = D.Workload(args.query, ctx, group, sf=args.sf, rows=n, key64=args.key64, join_exchange=args.join_exchange)
+    W = D.Workload(query, ctx, group, sf=args.sf, rows=n, key64=args.key64, join_exchange=args.join_exchange)
 
     def barrier():
         ctx.synchronize()
@@ -236,17 +230,19 @@ def main():
 
     # ---- strong scaling on the fixed tables (N = 1: the whole tables) -------------------------------------------
     W.load(mode="strong")
-    elapsed, result, kstats = timed(W.step, args.steps, args.warmup)
+    elapsed, result, kstats = timed(W.step, steps, warmup)
     exch = W.exchange_stats(reset=True)
+    host = W.host_overhead(reset=True)
 
     weak = None
     if world > 1 and not args.no_weak:
         W.load(mode="weak")
-        w_steps = max(3, args.steps // 4)
+        w_steps = max(3, steps // 4)
         w_elapsed, _, _ = timed(W.step, w_steps, 1)
         weak = dict(value=n["lineitem"] * world * w_steps / w_elapsed, unit="rows/s", ms_per_step=w_elapsed / w_steps * 1e3,
                     steps=w_steps, rows_per_gpu=n["lineitem"], note="every rank holds its own full-size shard of the seeded tables")
 
+    out = None
     if rank == 0:
         rows_job = n["lineitem"]
         rows_launch = W.rows_local("lineitem")                      # rows one launch of the dominant kernel covers
@@ -257,31 +253,83 @@ def main():
         algo_launch = dom_bytes / max(dom_n, 1) if dom_bytes else W.algorithmic_bytes_of_kernel(dom_name, key_bytes)
         achieved = algo_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         algo_job = W.algorithmic_bytes(key_bytes)
+        traffic, traffic_source = pmc_traffic(dom_name, rows_launch, query)
         out = {
-            "metric": f"tpch_{args.query}_sf{args.sf:g}_rows_per_sec", "value": rows_job * args.steps / elapsed, "unit": "rows/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "setup_passes": 2, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic",
+            "metric": f"tpch_{query}_sf{args.sf:g}_rows_per_sec", "value": rows_job * steps / elapsed, "unit": "rows/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "setup_passes": 2, "ms_per_step": elapsed / steps * 1e3,
+            "higher_is_better": True, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": W.describe(), "lineitem_rows": rows_job, "rows_per_gpu": rows_launch,
                        "partitioning": W.partitioning(), "plan_per_step": "an operator tree that has never run, built before the timed region; join builds and path choices happen inside it"},
-            "hbm_gbs_whole_step": algo_job * args.steps / elapsed / 1e9,
-            "hbm_frac_whole_step": algo_job * args.steps / elapsed / 1e9 / (HBM_PEAK_GBS * world),
+            # algorithmic = SURVEY.md §8(d)'s compulsory column bytes of the whole query / step time: NOT a bandwidth-utilisation
+            # figure (a fused probe never reads the payload of rows it rejects); the kernel-level number is `roofline`
+            "algorithmic_gbs_whole_step": algo_job * steps / elapsed / 1e9,
+            "algorithmic_frac_whole_step": algo_job * steps / elapsed / 1e9 / (HBM_PEAK_GBS * world),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(dom_name, rows_launch, args.query), "kernel": dom_name, "kernel_ms": kernel_ms,
+                         "traffic": traffic, "traffic_source": traffic_source, "kernel": dom_name, "kernel_ms": kernel_ms,
                          "launches": int(dom_n), "algorithmic_bytes_per_launch": algo_launch},
-            "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(kstats.items(), key=lambda kv: -kv[1][0])[:12]},
+            "kernels_ms_per_step": {k: round(v[0] / steps, 4) for k, v in sorted(kstats.items(), key=lambda kv: -kv[1][0])[:12]},
             "result_check": W.result_check(result),
         }
+        if world > 1:
+            # strong: the fixed SF tables are split N ways (the metric reads "Q1 SF100 at 1/2/4/8 GPUs"); at N = 1 there is nothing to scale
+            out["scaling"] = "strong"
+            out["exchange_backend"] = group.backend
+            out["rccl"] = group.describe()
+            if host:
+                out["host_overhead"] = host
         if weak is not None:
             out["weak_scaling"] = weak
         if exch:
             out["exchange"] = exch
-        if world == 1 and not args.no_cpu_baseline and args.cpu_rows > 0:      # the CPU legs run at N=1 only
-            sample = min(args.cpu_rows, rows_job)
-            out["cpu_baseline"] = cpu_baseline(args.query, args.sf, sample)
-            out["cpu_baseline_acero"] = cpu_baseline_acero(args.query, args.sf, sample)
+    del result
+    W.unload()
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline and cpu_rows > 0:      # the CPU legs run at N=1 only
+            sample = min(cpu_rows, n["lineitem"])
+            out["cpu_baseline"] = cpu_baseline(query, args.sf, sample, cpu_budget_s)
+            acero = cpu_baseline_acero(query, args.sf, sample, min(5.0, cpu_budget_s))
+            if acero is not None:
+                out["cpu_baseline_acero"] = acero
         else:
             out["cpu_baseline"] = None
+    return out
+
+
+def main():
+    args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import ballista_amd as ba
+    from ballista_amd import tpch, distributed as D
+
+    group = D.ProcessGroup.from_env(args.backend, allow_host_exchange=args.allow_host_exchange) if world > 1 else D.ProcessGroup.single()
+    ctx = ba.Context(group.device_index(local_rank))
+    group.attach(ctx)                      # raises (exit code != 0) when RCCL cannot carry the batches and --allow-host-exchange is not set
+
+    n = tpch.table_rows(args.sf)
+    if args.rows:
+        n["lineitem"] = args.rows
+
+    out = measure(args.query, args, ctx, group, world, rank, n, args.cpu_rows, 10.0, args.steps, args.warmup)
+    # the other single-GPU configurations of BASELINE.json (#3 Q6, #4 Q3, and the one-GPU leg of #5: Q5 at SF100), each with its own
+    # step time, dominant-kernel roofline and CPU baseline; the headline metric / value / roofline / cpu_baseline stay Q1's
+    extra = [q for q in args.configs.split(",") if q and q != args.query] if (world == 1 and args.query == "q1") else []
+    configs = {}
+    for q in extra:
+        if q not in ("q1", "q6", "q3", "q5"):
+            raise SystemExit(f"--configs: unknown query {q}")
+        line = measure(q, args, ctx, group, world, rank, n, min(args.cpu_rows, args.config_cpu_rows), 4.0, args.config_steps, 2)
+        if line is not None:
+            configs[q if q != "q5" else f"q5_sf{args.sf:g}_1gpu"] = line
+    if rank == 0:
+        if configs:
+            out["configs"] = configs
         print(json.dumps(out), flush=True)
     group.barrier()
     group.close()

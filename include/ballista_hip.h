@@ -415,6 +415,18 @@ bhip_status bhip_tpch_lineitem(bhip_ctx* ctx, double sf, uint64_t seed, uint64_t
                                int32_t with_dates, bhip_batch** out);
 bhip_status bhip_tpch_orders(bhip_ctx* ctx, double sf, uint64_t seed, uint64_t row0, uint64_t n, int32_t key64,
                              bhip_batch** out);
+/* The same with options.  sparse_keys: dbgen's order-key layout (the low 3 bits of the order number kept, the rest shifted up
+ * by two: 8 of every 32 key values used — SF1000 keys reach 6 x 10^9 and need Int64); key_base is added to every order key
+ * (small tables with keys beyond 2^32); columns: only these (NULL = all), in the table's column order. */
+typedef struct bhip_tpch_opts {
+    int32_t key64, with_dates, sparse_keys, n_columns;
+    int64_t key_base;
+    const char* const* columns;
+} bhip_tpch_opts;
+bhip_status bhip_tpch_lineitem_opts(bhip_ctx* ctx, double sf, uint64_t seed, uint64_t row0, uint64_t n, const bhip_tpch_opts* opts,
+                                    bhip_batch** out);
+bhip_status bhip_tpch_orders_opts(bhip_ctx* ctx, double sf, uint64_t seed, uint64_t row0, uint64_t n, const bhip_tpch_opts* opts,
+                                  bhip_batch** out);
 
 /* ---- measurement hooks --------------------------------------------------------------------- */
 /* time (ms, HIP events on the stream the kernels ran on) and launch count of the dominant scan

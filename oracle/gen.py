@@ -31,7 +31,20 @@ def _p(a, ct):
     return a.ctypes.data_as(ctypes.POINTER(ct)) if a is not None else None
 
 
-def lineitem_arrays(sf=0.001, row0=0, n=None, seed=SEED, key64=False, dates=False):
+def order_key_layout(keys, sparse_keys=False, key_base=0):
+    """the order-key layouts of the HIP generator's options (ballista_amd/csrc/kernels_gen.hip::order_key), restated in numpy on the
+    dense keys `order number + 1`: sparse = dbgen's layout (low 3 bits of the order number kept, the rest shifted up by two: 8 of
+    every 32 values used, SF1000 keys reach 6 x 10^9); key_base is added to every key.  Only meaningful with Int64 keys when the
+    result leaves the Int32 range."""
+    if not sparse_keys and not key_base:
+        return keys
+    o = keys.astype(np.int64) - 1
+    if sparse_keys:
+        o = ((o >> 3) << 5) | (o & 7)
+    return (o + 1 + int(key_base)).astype(keys.dtype)
+
+
+def lineitem_arrays(sf=0.001, row0=0, n=None, seed=SEED, key64=False, dates=False, sparse_keys=False, key_base=0):
     """raw numpy arrays of lineitem rows [row0, row0+n)"""
     card = cardinalities(sf)
     if n is None:
@@ -62,6 +75,7 @@ def lineitem_arrays(sf=0.001, row0=0, n=None, seed=SEED, key64=False, dates=Fals
     if dates:
         a["l_commitdate"] = commit
         a["l_receiptdate"] = receipt
+    a["l_orderkey"] = order_key_layout(a["l_orderkey"], sparse_keys, key_base)
     return a
 
 
@@ -70,8 +84,8 @@ def _utf8_from(off, data):
     return [b[off[i]:off[i + 1]].decode() for i in range(len(off) - 1)]
 
 
-def lineitem(sf=0.001, row0=0, n=None, seed=SEED, key64=False):
-    a = lineitem_arrays(sf, row0, n, seed, key64)
+def lineitem(sf=0.001, row0=0, n=None, seed=SEED, key64=False, sparse_keys=False, key_base=0):
+    a = lineitem_arrays(sf, row0, n, seed, key64, sparse_keys=sparse_keys, key_base=key_base)
     out = OrderedDict()
     out["l_orderkey"] = OCol("Int64" if key64 else "Int32", a["l_orderkey"])
     out["l_suppkey"] = OCol("Int32", a["l_suppkey"])
@@ -83,7 +97,7 @@ def lineitem(sf=0.001, row0=0, n=None, seed=SEED, key64=False):
     return out
 
 
-def orders_arrays(sf=0.001, row0=0, n=None, seed=SEED, key64=False):
+def orders_arrays(sf=0.001, row0=0, n=None, seed=SEED, key64=False, sparse_keys=False, key_base=0):
     card = cardinalities(sf)
     if n is None:
         n = card["orders"] - row0
@@ -98,11 +112,12 @@ def orders_arrays(sf=0.001, row0=0, n=None, seed=SEED, key64=False):
                           _p(a["o_orderkey"], ctypes.c_int64) if key64 else None,
                           _p(a["o_custkey"], ctypes.c_int32), _p(a["o_orderdate"], ctypes.c_int32),
                           _p(a["o_shippriority"], ctypes.c_int32))
+    a["o_orderkey"] = order_key_layout(a["o_orderkey"], sparse_keys, key_base)
     return a
 
 
-def orders(sf=0.001, seed=SEED, key64=False):
-    a = orders_arrays(sf, seed=seed, key64=key64)
+def orders(sf=0.001, seed=SEED, key64=False, sparse_keys=False, key_base=0):
+    a = orders_arrays(sf, seed=seed, key64=key64, sparse_keys=sparse_keys, key_base=key_base)
     return OrderedDict([
         ("o_orderkey", OCol("Int64" if key64 else "Int32", a["o_orderkey"])),
         ("o_custkey", OCol("Int32", a["o_custkey"])),

@@ -14,6 +14,7 @@ import ballista_amd as ba
 from oracle.engine import OCol
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def to_device(ctx, batch) -> ba.RecordBatch:

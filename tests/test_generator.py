@@ -70,6 +70,30 @@ def test_orders_generator_bit_identical(ctx, key64):
         _cmp(dev, cpu)
 
 
+@pytest.mark.parametrize("sparse,base", [(True, 0), (False, (1 << 32) + 17), (True, 5_000_000_000)])
+def test_generator_key_layouts_and_column_subsets(ctx, sparse, base):
+    """the order-key layouts config #5 needs (dbgen's sparse keys, keys beyond 2^32) and the column subset option: the HIP
+    generator against the oracle's numpy restatement of the layout"""
+    from collections import OrderedDict
+    from oracle.engine import OCol
+    sf, row0, n = 0.01, 1234, 40001
+    dev = ba.plan.tpch_lineitem(ctx, sf, tpch.SEED, row0, n, key64=True, sparse_keys=sparse, key_base=base,
+                                columns=["l_orderkey", "l_suppkey", "l_extendedprice", "l_discount"])
+    assert [f[0] for f in dev.schema3()] == ["l_orderkey", "l_suppkey", "l_extendedprice", "l_discount"]
+    a = gen.lineitem_arrays(sf, row0, n, key64=True, sparse_keys=sparse, key_base=base)
+    cpu = OrderedDict([("l_orderkey", OCol("Int64", a["l_orderkey"])), ("l_suppkey", OCol("Int32", a["l_suppkey"])),
+                       ("l_extendedprice", OCol("Float64", a["l_extendedprice"])), ("l_discount", OCol("Float64", a["l_discount"]))])
+    _cmp(dev, cpu)
+    assert int(a["l_orderkey"].max()) > (1 << 32) or sparse
+    if sparse and not base:
+        assert np.all(((a["l_orderkey"] - 1) & 31) < 8)                  # 8 of every 32 key values are used
+    dev = ba.plan.tpch_orders(ctx, sf, tpch.SEED, 100, 9000, key64=True, sparse_keys=sparse, key_base=base, columns=["o_orderkey", "o_custkey", "o_orderdate"])
+    o = gen.orders_arrays(sf, 100, 9000, key64=True, sparse_keys=sparse, key_base=base)
+    _cmp(dev, OrderedDict([("o_orderkey", OCol("Int64", o["o_orderkey"])), ("o_custkey", OCol("Int32", o["o_custkey"])),
+                           ("o_orderdate", OCol("Date32", o["o_orderdate"]))]))
+    assert np.all(np.diff(o["o_orderkey"]) > 0)                          # the layouts keep the table sorted by key
+
+
 def test_generator_pin(ctx):
     """the committed known-answer rows of the generator (tests/golden/gen_pin.json) hold for the HIP generator too"""
     import json

@@ -119,6 +119,80 @@ def test_hip_q5_matches_acero_golden(ctx):
     check_q5(helpers.concat(helpers.collect_product(plan)), g)
 
 
+# ---- config #5's key shapes: Int64 order keys in dbgen's sparse layout and beyond 2^32 ------------------------------------------
+# The layouts are bijections of the order number, so the committed Acero goldens hold with their order keys mapped the same way
+# (Q3) or unchanged (Q5 reports nations).  Reference schema: keys are Int32 (rust/benchmarks/tpch/src/main.rs:327-329), which
+# TPC-H SF1000 order keys (up to 6 x 10^9) overflow — BASELINE.json config #5 needs Int64.
+WIDE_KEYS = [dict(sparse_keys=True, key_base=0), dict(sparse_keys=False, key_base=(1 << 32) + 17), dict(sparse_keys=True, key_base=5_000_000_000)]
+
+
+def remap_q3_golden(g, layout):
+    rows = []
+    for r in g["rows"]:
+        k = int(gen.order_key_layout(np.array([r["l_orderkey"]], np.int64), **layout)[0])
+        rows.append(dict(r, l_orderkey=k))
+    return dict(g, rows=rows)
+
+
+@pytest.mark.parametrize("layout", WIDE_KEYS)
+def test_oracle_q3_q5_int64_wide_keys_match_acero_goldens(layout):
+    g = load("q3_synth.json")
+    sf = g["sf"]
+    od, li = gen.orders(sf, key64=True, **layout), gen.lineitem(sf, key64=True, **layout)
+    assert od["o_orderkey"].dtype == "Int64" and int(od["o_orderkey"].values.max()) > 4 * len(od["o_orderkey"].values) - 40
+    check_q3(oracle_q3(gen.customer(sf), od, li), remap_q3_golden(g, layout))
+    check_q5(oracle_q5(gen.customer(sf), od, li, gen.supplier(sf), gen.nation(), gen.region()), load("q5_synth.json"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", WIDE_KEYS)
+@pytest.mark.parametrize("n_part", [1, 3])
+def test_hip_q3_int64_wide_keys_match_acero_golden(ctx, layout, n_part):
+    g = load("q3_synth.json")
+    sf = g["sf"]
+    li = gen.lineitem(sf, key64=True, **layout)
+    n = og.batch_len(li)
+    per = (n + n_part - 1) // n_part
+    lim = helpers.memory_exec(ctx, [[helpers.slice_batch(li, p * per, (p + 1) * per)] for p in range(n_part)])
+    m = lambda b: helpers.memory_exec(ctx, [[b]])
+    plan = tpch.q3_plan(m(gen.customer(sf)), m(gen.orders(sf, key64=True, **layout)), lim)
+    check_q3(helpers.concat(helpers.collect_product(plan)), remap_q3_golden(g, layout))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", WIDE_KEYS)
+@pytest.mark.parametrize("join_table", ["rank_map", "cas_table"])
+def test_hip_q5_int64_wide_keys_match_acero_golden(ctx, layout, join_table, monkeypatch):
+    """device-generated Int64 tables (the bench's own generator) through Q5; the CAS table's 16-byte slots via a lowered rank-map
+    window (the order keys of the 1994 orders span more than 2^10 values)"""
+    g = load("q5_synth.json")
+    sf = g["sf"]
+    card = gen.cardinalities(sf)
+    li = ba.MemoryExec([[ba.plan.tpch_lineitem(ctx, sf, tpch.SEED, 0, card["lineitem"], key64=True, **layout)]], ctx)
+    od = ba.MemoryExec([[ba.plan.tpch_orders(ctx, sf, tpch.SEED, 0, card["orders"], key64=True, **layout)]], ctx)
+    m = lambda b: helpers.memory_exec(ctx, [[b]])
+    plan = tpch.q5_plan(m(gen.customer(sf)), od, li, m(gen.supplier(sf)), m(gen.nation()), m(gen.region()))
+    if join_table == "cas_table":
+        import subprocess, sys, json as js
+        # the window bound is read once per process: run this variant in a child
+        code = ("import os, sys, json; sys.path.insert(0, %r); sys.path.insert(0, %r); import ballista_amd as ba; from ballista_amd import tpch; "
+                "from oracle import gen; import helpers; ctx = ba.Context(0); layout = json.loads(%r); sf = %r; card = gen.cardinalities(sf); "
+                "li = ba.MemoryExec([[ba.plan.tpch_lineitem(ctx, sf, tpch.SEED, 0, card['lineitem'], key64=True, **layout)]], ctx); "
+                "od = ba.MemoryExec([[ba.plan.tpch_orders(ctx, sf, tpch.SEED, 0, card['orders'], key64=True, **layout)]], ctx); "
+                "m = lambda b: helpers.memory_exec(ctx, [[b]]); "
+                "plan = tpch.q5_plan(m(gen.customer(sf)), od, li, m(gen.supplier(sf)), m(gen.nation()), m(gen.region())); "
+                "got = helpers.concat(helpers.collect_product(plan)); "
+                "print(json.dumps(dict(n_name=got['n_name'].to_pylist(), revenue=got['revenue'].to_pylist())))"
+                ) % (helpers.ROOT, os.path.join(helpers.ROOT, "tests"), js.dumps(layout), sf)
+        env = dict(os.environ, BHIP_RANK_WINDOW_LOG2="10")
+        out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, text=True, check=True).stdout.strip().splitlines()[-1]
+        d = js.loads(out)
+        got = OrderedDict([("n_name", OCol("Utf8", d["n_name"])), ("revenue", OCol("Float64", np.array(d["revenue"])))])
+        check_q5(got, g)
+        return
+    check_q5(helpers.concat(helpers.collect_product(plan)), g)
+
+
 # ---- joins --------------------------------------------------------------------------------------------------------------
 
 def _col(dtype, vals):

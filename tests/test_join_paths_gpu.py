@@ -228,6 +228,35 @@ def test_rank_map_build_orders(ctx, jt, order, key_type):
     check(ba.HashJoinExec(lm, flt, [("lk", "rk")], jt), ["lk", "rk", "ry", "lx"])
 
 
+@pytest.mark.parametrize("jt", [ba.plan.INNER, ba.plan.LEFT])
+@pytest.mark.parametrize("order", ["sorted", "shuffled"])
+def test_rank_map_window_beyond_2_to_the_30(ctx, jt, order):
+    """TPC-H SF1000 order keys: Int64, a window of 6 x 10^9 values (dbgen's sparse layout), far more than 2^30 and more than 2^32
+    — the rank map's granule index is (offset >> 5) of a 64-bit offset (ops_join.cpp: windows up to 2^36).  400 K build keys
+    over [base, base + 6e9): ~1 KiB of map per build row, the sparsest a rank map is built for; probe keys inside, at both ends
+    of and outside the window, and 2^32 apart from build keys (an offset truncated to 32 bits would match them)."""
+    rng = np.random.default_rng(33)
+    n_left, n_right, span, base = 400_000, 700_000, 6_000_000_000, 7_000_000_123
+    lk = np.unique(rng.integers(0, span, n_left + 4096))[:n_left] + base
+    lk[0], lk[-1] = base, base + span - 1
+    if order == "shuffled":
+        lk = rng.permutation(lk)
+    n_left = len(lk)
+    pick = lk[rng.integers(0, n_left, n_right)]
+    rk = np.where(rng.random(n_right) < 0.4, pick, rng.integers(base - 1000, base + span + 1000, n_right))
+    alias = rng.random(n_right) < 0.1
+    rk = np.where(alias, pick + (1 << 32), rk)                                     # same low 32 bits as a build key
+    rk[:4] = [base - 1, base + span, base, base + span - 1]
+    left = OrderedDict([("lk", OCol("Int64", lk.astype(np.int64))), ("lx", OCol("Float64", rng.random(n_left)))])
+    right = OrderedDict([("rk", OCol("Int64", rk.astype(np.int64))), ("ry", OCol("Int64", rng.integers(0, 10 ** 9, n_right))),
+                         ("rd", OCol("Date32", rng.integers(9000, 10000, n_right).astype(np.int32)))])
+    lm, rm = helpers.memory_exec(ctx, [[left]]), helpers.memory_exec(ctx, [[right]])
+    ctx.kernel_stats(reset=True)
+    check(ba.HashJoinExec(lm, rm, [("lk", "rk")], jt), ["lk", "rk", "ry", "lx"])
+    flt = ba.FilterExec(E.coerce((col("rd") >= E.date32("1995-01-01")).and_(col("rd") < E.date32("1996-06-01")), {"rk": "Int64", "ry": "Int64", "rd": "Date32"}), rm)
+    check(ba.HashJoinExec(lm, flt, [("lk", "rk")], jt), ["lk", "rk", "ry", "lx"])
+
+
 @pytest.mark.parametrize("jt", JOIN_TYPES)
 def test_parents_that_read_only_some_join_columns(ctx, jt):
     """ProjectionExec / HashAggregateExec above a join ask it for the columns they read only (HashJoinExec::execute_needed):
