@@ -70,6 +70,27 @@ class LeafDesc(C.Structure):
                 ("stage_ids", C.POINTER(C.c_uint32)), ("partition_count", C.c_uint32)]
 
 
+class CommRegion(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("bytes", C.c_uint64), ("peer", C.c_int32)]
+
+
+HOST_ALL_GATHER = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
+HOST_EXCHANGE = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.POINTER(CommRegion), C.c_int32, C.POINTER(CommRegion))
+
+
+class CommHostTransport(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("all_gather", HOST_ALL_GATHER), ("exchange", HOST_EXCHANGE)]
+
+
+SHUFFLE_MAX_PEERS = 64
+
+
+class ShuffleStats(C.Structure):
+    _fields_ = [("rows_in", C.c_uint64), ("rows_out", C.c_uint64), ("chunks", C.c_uint64), ("streamed", C.c_uint64),
+                ("bytes_sent_remote", C.c_uint64), ("bytes_kept_local", C.c_uint64), ("staging_bytes", C.c_uint64),
+                ("rows_to", C.c_uint64 * SHUFFLE_MAX_PEERS), ("ms_count", C.c_double), ("ms_total", C.c_double)]
+
+
 class TpchOpts(C.Structure):
     _fields_ = [("key64", C.c_int32), ("with_dates", C.c_int32), ("sparse_keys", C.c_int32), ("n_columns", C.c_int32),
                 ("key_base", C.c_int64), ("columns", C.POINTER(C.c_char_p))]
@@ -152,7 +173,14 @@ SYMBOLS = {
     "bhip_ipc_open_file": (C.c_int32, [C.c_char_p, _P]),
     "bhip_comm_unique_id": (C.c_int32, [C.c_char_p]),
     "bhip_comm_create": (C.c_int32, [_P, C.c_char_p, C.c_int32, C.c_int32, _PP]),
+    "bhip_comm_create_loopback": (C.c_int32, [_P, C.c_char_p, C.c_int32, C.c_int32, _PP]),
+    "bhip_comm_create_host": (C.c_int32, [_P, C.POINTER(CommHostTransport), C.c_int32, C.c_int32, _PP]),
     "bhip_comm_release": (None, [_P]),
+    "bhip_comm_info": (C.c_int32, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_char_p)]),
+    "bhip_comm_stats": (C.c_int32, [_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "bhip_comm_shuffle": (C.c_int32, [_P, _P, C.c_char_p, C.c_int64, _PP, C.POINTER(ShuffleStats)]),
+    "bhip_plan_all_gather": (C.c_int32, [_P, _P, _PP]),
+    "bhip_plan_shuffle": (C.c_int32, [_P, _P, C.c_char_p, C.c_int64, _PP]),
     "bhip_comm_all_gather": (C.c_int32, [_P, _P, _PP]),
     "bhip_comm_all_to_all": (C.c_int32, [_P, _PP, _PP]),
     "bhip_batch_pack": (C.c_int32, [_P, C.POINTER(C.c_int64), C.c_int32, _P, C.c_int64, C.POINTER(C.c_int64)]),

@@ -16,12 +16,25 @@
 // RCCL is loaded with dlopen at the first communicator (the library itself does not link it), through the one HIP runtime of
 // the process; nothing here needs PyTorch.  The 128-byte unique id travels by whatever channel the ranks already share
 // (bench.py: a gloo broadcast on the CPU; an executor: its scheduler RPC).
+//
+// TRANSPORTS.  Everything above the byte movers — header matrices, block layout, who sends what to whom in which order, the
+// streaming shuffle — is ONE piece of code over a two-call interface (Transport: all_gather of equal-sized device regions, one
+// grouped exchange of point-to-point device regions).  Three implementations:
+//   rccl      ncclAllGather / grouped ncclSend + ncclRecv: the product path, one process per GPU;
+//   loopback  N communicators inside ONE process on ONE device, rendezvous on the host, hipMemcpyAsync device to device: the
+//             N-rank code paths (N = 2, 3, 8) run on the single-GPU test box (tests/test_exchange_gpu.py);
+//   host      the caller moves host bytes (two callbacks): bench.py's gloo rehearsal of the N-rank flow with ranks sharing a GPU,
+//             or an executor that only has its Flight / TCP channel between processes.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <map>
 #include <mutex>
 
+#include "../sort_kernels.h"
 #include "../util_kernels.h"
 #include "plan.hpp"
 
@@ -117,7 +130,9 @@ void pack_batch(const Exec& ex, const Batch& b, uint8_t* dst) {
         pieces.push_back({c.data ? c.data->ptr() : nullptr, db, at});
         at += align_up(db + BUFFER_SLACK);
         if (c.dtype == DT_UTF8) {
-            pieces.push_back({c.offsets->ptr(), (size_t)(b.n_rows + 1) * 4, at});
+            // (a 0-row Utf8 column may come without an offsets buffer — empty partitions are common after hash partitioning;
+            // the block is zero-filled where nothing is copied, and offsets[0] = 0 is the whole offsets array of an empty column)
+            pieces.push_back({c.offsets ? c.offsets->ptr() : nullptr, (size_t)(b.n_rows + 1) * 4, at});
             at += align_up((size_t)(b.n_rows + 1) * 4);
         }
         if (c.validity) {
@@ -138,10 +153,13 @@ void pack_batch(const Exec& ex, const Batch& b, uint8_t* dst) {
             ++pd.n;
         }
         if (pd.n) HIP_CHECK(launch_pack_buffers(ex.cfg(), pd, dst));
+        for (auto& p : pieces)                       // a buffer the batch does not have (offsets of a 0-row Utf8 column): zeros
+            if (p.bytes && !p.src) HIP_CHECK(hipMemsetAsync(dst + p.at, 0, p.bytes, ex.stream));
         return;
     }
     for (auto& p : pieces)
         if (p.bytes && p.src) HIP_CHECK(hipMemcpyAsync(dst + p.at, p.src, p.bytes, hipMemcpyDeviceToDevice, ex.stream));
+        else if (p.bytes) HIP_CHECK(hipMemsetAsync(dst + p.at, 0, p.bytes, ex.stream));
 }
 
 // the batch whose buffers are slices of `block` (kept alive by the columns)
@@ -174,30 +192,245 @@ BatchPtr unpack_batch(const ContextPtr& ctx, const SchemaPtr& schema, const Buff
     return b;
 }
 
-// ---- communicator --------------------------------------------------------------------------------------------------------
-class Communicator {
+// ---- transports ------------------------------------------------------------------------------------------------------------
+struct Xfer { void* ptr; size_t bytes; int peer; };
+
+class Transport {
 public:
-    Communicator(ContextPtr ctx, const uint8_t* id, int world, int rank) : ctx_(std::move(ctx)), world_(world), rank_(rank) {
-        if (world < 1 || rank < 0 || rank >= world) fail(BHIP_EINVAL, "communicator: rank outside the world");
-        ctx_->set_device();
+    virtual ~Transport() = default;
+    virtual const char* name() const = 0;
+    // recv[r * bytes, (r + 1) * bytes) = rank r's `send` region (device memory); ordered on `stream`
+    virtual void all_gather(const void* send, void* recv, size_t bytes, hipStream_t stream) = 0;
+    // ONE grouped exchange: every send reaches the matching receive of its peer; several regions per peer pair are matched in
+    // order.  Both sides derive their lists from common knowledge (header / count matrices), so sizes agree by construction.
+    virtual void exchange(const std::vector<Xfer>& sends, const std::vector<Xfer>& recvs, hipStream_t stream) = 0;
+};
+
+class RcclTransport : public Transport {
+public:
+    RcclTransport(const uint8_t* id, int world, int rank) {
         ncclUniqueId uid;
         static_assert(sizeof(uid) == BHIP_COMM_ID_BYTES, "unique id size");
         memcpy(&uid, id, sizeof(uid));
         NCCL_CHECK(rccl().CommInitRank(&comm_, world, uid, rank));
+    }
+    ~RcclTransport() override { if (comm_) rccl().CommDestroy(comm_); }
+    const char* name() const override { return "rccl"; }
+    void all_gather(const void* send, void* recv, size_t bytes, hipStream_t stream) override {
+        NCCL_CHECK(rccl().AllGather(send, recv, bytes, ncclUint8, comm_, stream));
+    }
+    void exchange(const std::vector<Xfer>& sends, const std::vector<Xfer>& recvs, hipStream_t stream) override {
+        // xGMI is point to point: one grouped launch keeps every peer's link busy at once
+        NCCL_CHECK(rccl().GroupStart());
+        for (auto& x : sends) NCCL_CHECK(rccl().Send(x.ptr, x.bytes, ncclUint8, x.peer, comm_, stream));
+        for (auto& x : recvs) NCCL_CHECK(rccl().Recv(x.ptr, x.bytes, ncclUint8, x.peer, comm_, stream));
+        NCCL_CHECK(rccl().GroupEnd());
+    }
+private:
+    ncclComm_t comm_ = nullptr;
+};
+
+// N ranks of ONE process on one device: what each rank posts is visible to the others after a host rendezvous, the bytes move
+// with hipMemcpyAsync.  A rank that never arrives (its thread failed) breaks the hub: the others get an error after the
+// timeout instead of hanging.
+struct LoopbackHub {
+    explicit LoopbackHub(int w) : world(w), posts((size_t)w) {}
+    const int world;
+    struct Post { const void* send = nullptr; size_t bytes = 0; std::vector<Xfer> sends; hipEvent_t ready = nullptr; };
+    std::vector<Post> posts;
+    int joined = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t generation = 0;
+    bool broken = false;
+    void barrier() {
+        std::unique_lock<std::mutex> g(mu);
+        if (broken) fail(BHIP_EEXEC, "loopback exchange: a peer rank failed");
+        const uint64_t gen = generation;
+        if (++arrived == world) {
+            arrived = 0;
+            ++generation;
+            cv.notify_all();
+            return;
+        }
+        static const int timeout_s = [] { const char* v = getenv("BHIP_LOOPBACK_TIMEOUT_S"); return v ? atoi(v) : 120; }();
+        if (!cv.wait_for(g, std::chrono::seconds(timeout_s), [&] { return generation != gen || broken; })) {
+            broken = true;
+            cv.notify_all();
+            fail(BHIP_EEXEC, "loopback exchange: a peer rank did not arrive (collective calls must be made by every rank)");
+        }
+        if (broken && generation == gen) fail(BHIP_EEXEC, "loopback exchange: a peer rank failed");
+    }
+};
+
+class LoopbackTransport : public Transport {
+public:
+    LoopbackTransport(const uint8_t* id, int world, int rank) : rank_(rank), key_(reinterpret_cast<const char*>(id), BHIP_COMM_ID_BYTES) {
+        std::lock_guard<std::mutex> g(registry_mu());
+        auto& slot = registry()[key_];
+        hub_ = slot.lock();
+        if (!hub_) { hub_ = std::make_shared<LoopbackHub>(world); slot = hub_; }
+        if (hub_->world != world) fail(BHIP_EINVAL, "loopback communicator: ranks disagree about the world size");
+        if (hub_->joined >= world) fail(BHIP_EINVAL, "loopback communicator: more ranks than the world holds (ids are single-use)");
+        ++hub_->joined;
+        HIP_CHECK(hipEventCreateWithFlags(&ready_, hipEventDisableTiming));
+    }
+    ~LoopbackTransport() override {
+        if (ready_) hipEventDestroy(ready_);
+        std::lock_guard<std::mutex> g(registry_mu());
+        hub_.reset();
+        auto it = registry().find(key_);
+        if (it != registry().end() && it->second.expired()) registry().erase(it);
+    }
+    const char* name() const override { return "loopback"; }
+    void all_gather(const void* send, void* recv, size_t bytes, hipStream_t stream) override {
+        HIP_CHECK(hipEventRecord(ready_, stream));
+        auto& mine = hub_->posts[(size_t)rank_];
+        mine.send = send; mine.bytes = bytes; mine.ready = ready_;
+        hub_->barrier();
+        for (int r = 0; r < hub_->world; ++r) {
+            const auto& p = hub_->posts[(size_t)r];
+            if (p.bytes != bytes) { finish(stream); fail(BHIP_EEXEC, "loopback all_gather: ranks posted regions of different sizes"); }
+            HIP_CHECK(hipStreamWaitEvent(stream, p.ready, 0));
+            if (bytes) HIP_CHECK(hipMemcpyAsync(static_cast<uint8_t*>(recv) + (size_t)r * bytes, p.send, bytes, hipMemcpyDeviceToDevice, stream));
+        }
+        finish(stream);
+    }
+    void exchange(const std::vector<Xfer>& sends, const std::vector<Xfer>& recvs, hipStream_t stream) override {
+        HIP_CHECK(hipEventRecord(ready_, stream));
+        auto& mine = hub_->posts[(size_t)rank_];
+        mine.sends = sends; mine.ready = ready_;
+        hub_->barrier();
+        std::vector<size_t> taken((size_t)hub_->world, 0);          // per peer: how many of its sends to me are matched already
+        std::string err;
+        for (auto& rv : recvs) {
+            const auto& p = hub_->posts[(size_t)rv.peer];
+            size_t& k = taken[(size_t)rv.peer];
+            while (k < p.sends.size() && p.sends[k].peer != rank_) ++k;
+            if (k == p.sends.size()) { err = "a receive without a matching send"; break; }
+            if (p.sends[k].bytes != rv.bytes) { err = "send and receive sizes differ (" + std::to_string(p.sends[k].bytes) + " vs " + std::to_string(rv.bytes) + ")"; break; }
+            HIP_CHECK(hipStreamWaitEvent(stream, p.ready, 0));
+            HIP_CHECK(hipMemcpyAsync(rv.ptr, p.sends[k].ptr, rv.bytes, hipMemcpyDeviceToDevice, stream));
+            ++k;
+        }
+        if (err.empty())
+            for (int r = 0; r < hub_->world && err.empty(); ++r) {
+                const auto& p = hub_->posts[(size_t)r];
+                size_t k = taken[(size_t)r];
+                while (k < p.sends.size() && p.sends[k].peer != rank_) ++k;
+                if (k != p.sends.size()) err = "a send without a matching receive";
+            }
+        finish(stream);
+        if (!err.empty()) fail(BHIP_EEXEC, "loopback exchange: " + err);
+    }
+private:
+    // the copies read the peers' buffers: nobody may release or overwrite its own until every rank's copies have completed
+    void finish(hipStream_t stream) {
+        const hipError_t e = hipStreamSynchronize(stream);
+        hub_->barrier();
+        HIP_CHECK(e);
+    }
+    static std::mutex& registry_mu() { static std::mutex m; return m; }
+    static std::map<std::string, std::weak_ptr<LoopbackHub>>& registry() { static std::map<std::string, std::weak_ptr<LoopbackHub>> r; return r; }
+    int rank_;
+    std::string key_;
+    std::shared_ptr<LoopbackHub> hub_;
+    hipEvent_t ready_ = nullptr;
+};
+
+// the caller moves host bytes: regions are staged device -> host, handed to the callbacks, staged host -> device
+class HostTransport : public Transport {
+public:
+    HostTransport(const bhip_comm_host_transport& cb, int world) : cb_(cb), world_(world) {
+        if (!cb.all_gather || !cb.exchange) fail(BHIP_EINVAL, "host transport: both callbacks are required");
+    }
+    const char* name() const override { return "host"; }
+    void all_gather(const void* send, void* recv, size_t bytes, hipStream_t stream) override {
+        std::vector<uint8_t> out(bytes ? bytes : 1), in((bytes ? bytes : 1) * (size_t)world_);
+        if (bytes) HIP_CHECK(hipMemcpyAsync(out.data(), send, bytes, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        if (cb_.all_gather(cb_.user, out.data(), in.data(), (uint64_t)bytes) != 0) fail(BHIP_EEXEC, "host transport: all_gather callback failed");
+        if (bytes) HIP_CHECK(hipMemcpyAsync(recv, in.data(), bytes * (size_t)world_, hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    void exchange(const std::vector<Xfer>& sends, const std::vector<Xfer>& recvs, hipStream_t stream) override {
+        std::vector<std::vector<uint8_t>> sb(sends.size()), rb(recvs.size());
+        std::vector<bhip_comm_region> s(sends.size()), r(recvs.size());
+        for (size_t i = 0; i < sends.size(); ++i) {
+            sb[i].resize(sends[i].bytes ? sends[i].bytes : 1);
+            if (sends[i].bytes) HIP_CHECK(hipMemcpyAsync(sb[i].data(), sends[i].ptr, sends[i].bytes, hipMemcpyDeviceToHost, stream));
+            s[i] = bhip_comm_region{sb[i].data(), (uint64_t)sends[i].bytes, sends[i].peer};
+        }
+        for (size_t i = 0; i < recvs.size(); ++i) {
+            rb[i].resize(recvs[i].bytes ? recvs[i].bytes : 1);
+            r[i] = bhip_comm_region{rb[i].data(), (uint64_t)recvs[i].bytes, recvs[i].peer};
+        }
+        HIP_CHECK(hipStreamSynchronize(stream));
+        if (cb_.exchange(cb_.user, (int32_t)s.size(), s.data(), (int32_t)r.size(), r.data()) != 0) fail(BHIP_EEXEC, "host transport: exchange callback failed");
+        for (size_t i = 0; i < recvs.size(); ++i)
+            if (recvs[i].bytes) HIP_CHECK(hipMemcpyAsync(recvs[i].ptr, rb[i].data(), recvs[i].bytes, hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+    }
+private:
+    bhip_comm_host_transport cb_;
+    int world_;
+};
+
+static BatchPtr empty_batch(const Exec& ex, const SchemaPtr& schema) {
+    auto e = std::make_shared<Batch>();
+    e->schema = schema;
+    e->ctx = ex.ctx;
+    for (auto& f : schema->fields) {
+        Column c;
+        c.dtype = f.dtype;
+        c.data = make_buffer(ex, 8);
+        if (f.dtype == DT_UTF8) { c.offsets = make_buffer(ex, 8); HIP_CHECK(hipMemsetAsync(c.offsets->ptr(), 0, 8, ex.stream)); }
+        e->cols.push_back(c);
+    }
+    return e;
+}
+
+static void same_schema(const Schema& a, const Schema& b, const char* what) {
+    bool ok = a.fields.size() == b.fields.size();
+    for (size_t i = 0; ok && i < a.fields.size(); ++i) ok = a.fields[i].dtype == b.fields[i].dtype;
+    if (!ok) fail(BHIP_EINVAL, std::string(what) + ": the batches of one collective call must share ONE schema");
+}
+
+// ---- communicator --------------------------------------------------------------------------------------------------------
+class Communicator {
+public:
+    Communicator(ContextPtr ctx, std::unique_ptr<Transport> t, int world, int rank) : ctx_(std::move(ctx)), t_(std::move(t)), world_(world), rank_(rank) {
+        ctx_->set_device();
         stream_ = ctx_->acquire_stream();
+        aux_ = ctx_->acquire_stream();
+        for (auto& e : ev_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     ~Communicator() {
-        if (comm_) rccl().CommDestroy(comm_);
+        for (auto e : ev_) if (e) hipEventDestroy(e);
+        t_.reset();
         if (stream_) ctx_->release_stream(stream_);
+        if (aux_) ctx_->release_stream(aux_);
     }
     int world() const { return world_; }
     int rank() const { return rank_; }
     const ContextPtr& ctx() const { return ctx_; }
+    const char* transport() const { return t_->name(); }
+
+    struct Stats { double seconds = 0; uint64_t bytes_out = 0, calls = 0; };
+    Stats stats(bool reset) {
+        std::lock_guard<std::mutex> g(mu_);
+        Stats s = stats_;
+        if (reset) stats_ = Stats{};
+        return s;
+    }
 
     // every rank's batch, in rank order (the order MergeExec concatenates partitions in)
     std::vector<BatchPtr> all_gather(const BatchPtr& mine) {
         std::vector<BatchPtr> out(world_);
         if (world_ == 1) { out[0] = mine; return out; }
+        std::lock_guard<std::mutex> g(mu_);
+        const auto t0 = std::chrono::steady_clock::now();
         ctx_->set_device();
         Exec ex{ctx_, stream_};
         const SchemaPtr schema = mine->schema;
@@ -207,47 +440,61 @@ public:
         std::vector<int64_t> h(H);
         pack_header(*mine, h.data());
         const size_t head_bytes = align_up(H * 8);
+        if (head_bytes > SLOT) fail(BHIP_ENOTIMPL, "all_gather: more columns than a header slot holds");
         const bool fits = head_bytes + (size_t)h[1] <= SLOT;
         auto send = make_buffer(ex, SLOT);
         auto recv = make_buffer(ex, SLOT * (size_t)world_);
-        HIP_CHECK(hipMemsetAsync(send->ptr(), 0, head_bytes, stream_));
+        HIP_CHECK(hipMemsetAsync(send->ptr(), 0, fits ? SLOT : head_bytes, stream_));
         HIP_CHECK(hipMemcpyAsync(send->ptr(), h.data(), H * 8, hipMemcpyHostToDevice, stream_));
         if (fits) pack_batch(ex, *mine, send->as<uint8_t>() + head_bytes);
-        NCCL_CHECK(rccl().AllGather(send->ptr(), recv->ptr(), SLOT, ncclUint8, comm_, stream_));
+        t_->all_gather(send->ptr(), recv->ptr(), SLOT, stream_);
         std::vector<int64_t> heads((size_t)world_ * H);
         for (int r = 0; r < world_; ++r)
             HIP_CHECK(hipMemcpyAsync(&heads[(size_t)r * H], recv->as<uint8_t>() + (size_t)r * SLOT, H * 8, hipMemcpyDeviceToHost, stream_));
         HIP_CHECK(hipStreamSynchronize(stream_));
+        for (int r = 0; r < world_; ++r) check_header(&heads[(size_t)r * H], *schema, "all_gather");
         bool all_fit = true;
         for (int r = 0; r < world_; ++r) all_fit = all_fit && head_bytes + (size_t)heads[(size_t)r * H + 1] <= SLOT;
         if (all_fit) {
             for (int r = 0; r < world_; ++r)
                 out[r] = r == rank_ ? mine : unpack_batch(ctx_, schema, recv, (size_t)r * SLOT + head_bytes, &heads[(size_t)r * H]);
+            recv->set_stream(nullptr);
+            account(t0, (uint64_t)h[1] * (uint64_t)(world_ - 1));
             return out;
         }
         // round 2: blocks of any size, point to point (every rank took the same branch: the headers are common knowledge)
         auto mine_block = make_buffer(ex, (size_t)h[1] + ALIGN);
         pack_batch(ex, *mine, mine_block->as<uint8_t>());
         std::vector<BufferPtr> blocks(world_);
-        NCCL_CHECK(rccl().GroupStart());
+        std::vector<Xfer> sends, recvs;
         for (int p = 0; p < world_; ++p) {
             if (p == rank_) continue;
             const size_t nb = (size_t)heads[(size_t)p * H + 1];
             blocks[p] = make_buffer(ex, nb + ALIGN);
-            if (h[1]) NCCL_CHECK(rccl().Send(mine_block->ptr(), (size_t)h[1], ncclUint8, p, comm_, stream_));
-            if (nb) NCCL_CHECK(rccl().Recv(blocks[p]->ptr(), nb, ncclUint8, p, comm_, stream_));
+            if (h[1]) sends.push_back(Xfer{mine_block->ptr(), (size_t)h[1], p});
+            if (nb) recvs.push_back(Xfer{blocks[p]->ptr(), nb, p});
         }
-        NCCL_CHECK(rccl().GroupEnd());
+        t_->exchange(sends, recvs, stream_);
         HIP_CHECK(hipStreamSynchronize(stream_));
-        for (int r = 0; r < world_; ++r) out[r] = r == rank_ ? mine : unpack_batch(ctx_, schema, blocks[r], 0, &heads[(size_t)r * H]);
+        for (int r = 0; r < world_; ++r) {
+            if (r != rank_) blocks[r]->set_stream(nullptr);
+            out[r] = r == rank_ ? mine : unpack_batch(ctx_, schema, blocks[r], 0, &heads[(size_t)r * H]);
+        }
+        account(t0, (uint64_t)h[1] * (uint64_t)(world_ - 1));
         return out;
     }
 
     // parts[d] goes to rank d; out[s] = the batch rank s held for this rank
     std::vector<BatchPtr> all_to_all(const std::vector<BatchPtr>& parts) {
         if ((int)parts.size() != world_) fail(BHIP_EINVAL, "all_to_all needs one batch per rank");
+        for (auto& p : parts) {
+            if (!p) fail(BHIP_EINVAL, "all_to_all: null part");
+            same_schema(*parts[0]->schema, *p->schema, "all_to_all");
+        }
         std::vector<BatchPtr> out(world_);
         if (world_ == 1) { out[0] = parts[0]; return out; }
+        std::lock_guard<std::mutex> g(mu_);
+        const auto t0 = std::chrono::steady_clock::now();
         ctx_->set_device();
         Exec ex{ctx_, stream_};
         const SchemaPtr schema = parts[0]->schema;
@@ -255,46 +502,361 @@ public:
         // headers of my world outgoing blocks -> everyone (world x world x H int64)
         std::vector<int64_t> mine((size_t)world_ * H);
         for (int d = 0; d < world_; ++d) pack_header(*parts[d], &mine[(size_t)d * H]);
-        auto hs = make_buffer(ex, mine.size() * 8);
-        auto hr = make_buffer(ex, mine.size() * 8 * (size_t)world_);
-        HIP_CHECK(hipMemcpyAsync(hs->ptr(), mine.data(), mine.size() * 8, hipMemcpyHostToDevice, stream_));
-        NCCL_CHECK(rccl().AllGather(hs->ptr(), hr->ptr(), mine.size() * 8, ncclUint8, comm_, stream_));
-        std::vector<int64_t> all((size_t)world_ * world_ * H);
-        HIP_CHECK(hipMemcpyAsync(all.data(), hr->ptr(), all.size() * 8, hipMemcpyDeviceToHost, stream_));
-        // pack while the headers travel back
+        const std::vector<int64_t> all = gather_words(mine);
+        // pack while nothing else is pending
         std::vector<BufferPtr> sendb(world_), recvb(world_);
+        uint64_t out_bytes = 0;
         for (int d = 0; d < world_; ++d) {
             if (d == rank_) continue;
             const size_t nb = (size_t)mine[(size_t)d * H + 1];
             sendb[d] = make_buffer(ex, nb + ALIGN);
             pack_batch(ex, *parts[d], sendb[d]->as<uint8_t>());
+            out_bytes += nb;
         }
-        HIP_CHECK(hipStreamSynchronize(stream_));
         auto head_of = [&](int src, int dst) { return &all[((size_t)src * world_ + dst) * H]; };
-        NCCL_CHECK(rccl().GroupStart());
+        for (int s = 0; s < world_; ++s) check_header(head_of(s, rank_), *schema, "all_to_all");
+        std::vector<Xfer> sends, recvs;
         for (int p = 0; p < world_; ++p) {
             if (p == rank_) continue;
             const size_t out_b = (size_t)mine[(size_t)p * H + 1], in_b = (size_t)head_of(p, rank_)[1];
             recvb[p] = make_buffer(ex, in_b + ALIGN);
-            if (out_b) NCCL_CHECK(rccl().Send(sendb[p]->ptr(), out_b, ncclUint8, p, comm_, stream_));
-            if (in_b) NCCL_CHECK(rccl().Recv(recvb[p]->ptr(), in_b, ncclUint8, p, comm_, stream_));
+            if (out_b) sends.push_back(Xfer{sendb[p]->ptr(), out_b, p});
+            if (in_b) recvs.push_back(Xfer{recvb[p]->ptr(), in_b, p});
         }
-        NCCL_CHECK(rccl().GroupEnd());
+        t_->exchange(sends, recvs, stream_);
         HIP_CHECK(hipStreamSynchronize(stream_));
-        for (int s = 0; s < world_; ++s) out[s] = s == rank_ ? parts[s] : unpack_batch(ctx_, schema, recvb[s], 0, head_of(s, rank_));
+        for (int s = 0; s < world_; ++s) {
+            if (s != rank_) recvb[s]->set_stream(nullptr);
+            out[s] = s == rank_ ? parts[s] : unpack_batch(ctx_, schema, recvb[s], 0, head_of(s, rank_));
+        }
+        account(t0, out_bytes);
+        return out;
+    }
+
+    // RepartitionExec(Hash([key], world)) + the shuffle read in one call: the rows of every rank's `in` whose key hashes to this
+    // rank, in source-rank order and input order within a source (what all_to_all of bhip_batch_hash_partition + concat returns).
+    //
+    // Fixed-width NULL-free columns and one NULL-free integer key (every exchange of the TPC-H joins) STREAM: a count pass over
+    // the key column sizes everything (a [chunk][destination] matrix, gathered from every rank), the result columns are
+    // allocated once at their exact size, and the input goes through in chunks of `chunk_rows` — partition_scatter into one of
+    // two staging buffers on the auxiliary stream while the previous chunk's grouped send / receive is in flight on the
+    // communicator's stream; a peer's rows land directly at their final position.  Device memory beyond input and result:
+    // two chunks (not the N partitions + N packed blocks + N received blocks + the concatenation the general path holds).
+    BatchPtr shuffle(const BatchPtr& in, const std::string& key, int64_t chunk_rows, bhip_shuffle_stats* st) {
+        if (st) memset(st, 0, sizeof(*st));
+        const int ki = in->schema->index_of(key);
+        if (ki < 0) fail(BHIP_EINVAL, "shuffle: no column named '" + key + "'");
+        if (world_ > 256) fail(BHIP_ENOTIMPL, "shuffle over more than 256 ranks");
+        const Column& kc = in->cols[(size_t)ki];
+        const int kw = kc.validity ? 0 : (kc.dtype == DT_INT32 || kc.dtype == DT_DATE32) ? 4 : (kc.dtype == DT_INT64 || kc.dtype == DT_UINT64) ? 8 : 0;
+        bool fixed = kw != 0 && (int)in->cols.size() <= TAKE_MANY_MAX;
+        for (auto& c : in->cols) fixed = fixed && !c.validity && !c.is_view() && c.dtype != DT_UTF8 && c.dtype != DT_BOOLEAN;
+        static const bool no_stream = [] { const char* v = getenv("BHIP_NO_STREAMING_SHUFFLE"); return v && atoi(v) != 0; }();
+        const auto t0 = std::chrono::steady_clock::now();
+        // every rank must take the same path: the schema decides it (NULL-ability of a column is part of what is gathered below)
+        std::vector<int64_t> me = {in->n_rows, fixed && !no_stream ? 1 : 0};
+        std::vector<int64_t> everyone;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            ctx_->set_device();
+            everyone = world_ == 1 ? me : gather_words(me);
+        }
+        bool all_fixed = true;
+        for (int r = 0; r < world_; ++r) all_fixed = all_fixed && everyone[(size_t)r * 2 + 1] != 0;
+        if (!all_fixed) {
+            // general path: any column type, NULLs, expressions' worth of keys
+            ctx_->set_device();
+            Exec ex{ctx_, stream_};
+            std::vector<ExprPtr> exprs = {make_column(key)};
+            std::vector<BatchPtr> parts;
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                parts = hash_partition_batch(ex, in, exprs, world_);
+                HIP_CHECK(hipStreamSynchronize(stream_));
+            }
+            if (st) for (int d = 0; d < world_ && d < BHIP_SHUFFLE_MAX_PEERS; ++d) st->rows_to[d] = (uint64_t)parts[(size_t)d]->n_rows;
+            auto got = all_to_all(parts);
+            std::lock_guard<std::mutex> g(mu_);
+            std::vector<BatchPtr> live;
+            for (auto& b : got) if (b->n_rows) live.push_back(b);
+            BatchPtr out = live.empty() ? got[0] : live.size() == 1 ? live[0] : concat_batches(ex, in->schema, live);
+            HIP_CHECK(hipStreamSynchronize(stream_));
+            if (st) {
+                st->rows_in = (uint64_t)in->n_rows; st->rows_out = (uint64_t)out->n_rows; st->streamed = 0;
+                st->ms_total = ms_since(t0);
+            }
+            return out;
+        }
+        std::lock_guard<std::mutex> g(mu_);
+        ctx_->set_device();
+        Exec ex{ctx_, stream_}, ax{ctx_, aux_};
+        const int64_t quantum = partition_chunk_quantum();
+        if (chunk_rows <= 0) chunk_rows = 64ll << 20;                                  // 64 Mi rows: 1.8 GB of Q5's 28-byte lineitem rows per staging buffer
+        chunk_rows = (chunk_rows + quantum - 1) / quantum * quantum;
+        const int64_t n = in->n_rows;
+        int64_t max_rows = 0;
+        for (int r = 0; r < world_; ++r) max_rows = std::max(max_rows, everyone[(size_t)r * 2]);
+        if (chunk_rows > max_rows) chunk_rows = std::max<int64_t>(quantum, (max_rows + quantum - 1) / quantum * quantum);
+        const int64_t C = (max_rows + chunk_rows - 1) / chunk_rows;                     // chunks every rank walks (its own may run out earlier)
+        const int64_t C_me = (n + chunk_rows - 1) / chunk_rows;
+        // ---- count pass: counts[c][d] = rows of my chunk c that go to rank d --------------------------------------------------
+        std::vector<int64_t> counts((size_t)std::max<int64_t>(C, 1) * world_, 0);
+        if (n > 0) {
+            Temp tmp(ex);
+            uint64_t* dev = tmp.get<uint64_t>(counts.size());
+            HIP_CHECK(hipMemsetAsync(dev, 0, counts.size() * 8, stream_));
+            TIMED_LAUNCH_B(ex, "partition_count", n, (uint64_t)n * kw, partition_count(ex.cfg(), kc.data->ptr(), kw, n, (uint32_t)world_, chunk_rows, dev));
+            HIP_CHECK(hipMemcpyAsync(counts.data(), dev, counts.size() * 8, hipMemcpyDeviceToHost, stream_));
+            HIP_CHECK(hipStreamSynchronize(stream_));
+        }
+        const double ms_count = ms_since(t0);
+        const std::vector<int64_t> all = world_ == 1 ? counts : gather_words(counts);   // [src][chunk][dst]
+        auto cnt = [&](int src, int64_t c, int dst) { return all[((size_t)src * C + (size_t)c) * world_ + dst]; };
+        // rows I receive from each source, where each source's rows start in the result
+        std::vector<int64_t> from((size_t)world_, 0), start((size_t)world_ + 1, 0);
+        for (int s = 0; s < world_; ++s) {
+            for (int64_t c = 0; c < C; ++c) from[(size_t)s] += cnt(s, c, rank_);
+            start[(size_t)s + 1] = start[(size_t)s] + from[(size_t)s];
+        }
+        const int64_t n_out = start[(size_t)world_];
+        if (n_out > 0xFFFFFFF0ll) fail(BHIP_ENOTIMPL, "shuffle: this rank would receive more than 2^32-16 rows in one batch");
+        // ---- result columns, two staging sets -----------------------------------------------------------------------------------
+        const size_t n_cols = in->cols.size();
+        auto out = std::make_shared<Batch>();
+        out->schema = in->schema;
+        out->ctx = ctx_;
+        out->n_rows = n_out;
+        size_t row_bytes = 0;
+        for (auto& c : in->cols) {
+            Column oc;
+            oc.dtype = c.dtype;
+            oc.length = n_out;
+            oc.data = make_buffer(ex, (size_t)n_out * dtype_width(c.dtype) + 8);
+            out->cols.push_back(oc);
+            row_bytes += (size_t)dtype_width(c.dtype);
+        }
+        const int64_t stage_rows = std::min<int64_t>(chunk_rows, std::max<int64_t>(n, 1));
+        std::vector<BufferPtr> stage[2];
+        BufferPtr scatter_tmp[2];
+        const int n_stage = C > 1 ? 2 : 1;
+        for (int b = 0; b < n_stage; ++b) {
+            for (auto& c : in->cols) stage[b].push_back(make_buffer(ax, (size_t)stage_rows * dtype_width(c.dtype) + 8));
+            scatter_tmp[b] = make_buffer(ax, partition_scatter_temp_bytes(stage_rows) + 64);
+        }
+        std::vector<int64_t> got((size_t)world_, 0);                    // rows of each source already placed
+        uint64_t bytes_remote = 0, bytes_local = 0;
+        // the producer's stream finished before this call (the plan node waits); the result buffers were allocated on stream_
+        for (int64_t c = 0; c < C; ++c) {
+            const int b = (int)(c % n_stage);
+            const int64_t lo = c * chunk_rows, rows = c < C_me ? std::min(chunk_rows, n - lo) : 0;
+            if (c >= n_stage) HIP_CHECK(hipStreamWaitEvent(aux_, ev_[2 + b], 0));       // the exchange that read this staging set is done
+            if (rows > 0) {
+                TakeMany tm;
+                tm.n = 0;
+                for (size_t ci = 0; ci < n_cols; ++ci) {
+                    const int w = dtype_width(in->cols[ci].dtype);
+                    tm.src[tm.n] = in->cols[ci].data->as<uint8_t>() + (size_t)lo * w;
+                    tm.dst[tm.n] = stage[b][ci]->ptr();
+                    tm.width[tm.n] = w;
+                    ++tm.n;
+                }
+                KernelTimer kt(ax, "partition_scatter", rows, (uint64_t)rows * (2 * row_bytes + 2 * (size_t)kw));
+                HIP_CHECK(partition_scatter(ax.cfg(), kc.data->as<uint8_t>() + (size_t)lo * kw, kw, rows, (uint32_t)world_, tm, scatter_tmp[b]->ptr(), nullptr));
+            }
+            HIP_CHECK(hipEventRecord(ev_[b], aux_));
+            HIP_CHECK(hipStreamWaitEvent(stream_, ev_[b], 0));
+            // this chunk's sends (from the staging set, partition-contiguous) and receives (straight into the result)
+            std::vector<Xfer> sends, recvs;
+            int64_t first = 0;
+            for (int d = 0; d < world_; ++d) {
+                const int64_t k = c < C_me ? cnt(rank_, c, d) : 0;
+                if (k > 0) {
+                    for (size_t ci = 0; ci < n_cols; ++ci) {
+                        const size_t w = (size_t)dtype_width(in->cols[ci].dtype);
+                        uint8_t* src = stage[b][ci]->as<uint8_t>() + (size_t)first * w;
+                        if (d == rank_) {
+                            uint8_t* dst = out->cols[ci].data->as<uint8_t>() + (size_t)(start[(size_t)rank_] + got[(size_t)rank_]) * w;
+                            HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)k * w, hipMemcpyDeviceToDevice, stream_));
+                            bytes_local += (uint64_t)k * w;
+                        } else {
+                            sends.push_back(Xfer{src, (size_t)k * w, d});
+                            bytes_remote += (uint64_t)k * w;
+                        }
+                    }
+                    if (st && d < BHIP_SHUFFLE_MAX_PEERS) st->rows_to[d] += (uint64_t)k;
+                }
+                first += k;
+            }
+            got[(size_t)rank_] += c < C_me ? cnt(rank_, c, rank_) : 0;
+            for (int s = 0; s < world_; ++s) {
+                if (s == rank_) continue;
+                const int64_t k = cnt(s, c, rank_);
+                if (k <= 0) continue;
+                for (size_t ci = 0; ci < n_cols; ++ci) {
+                    const size_t w = (size_t)dtype_width(in->cols[ci].dtype);
+                    recvs.push_back(Xfer{out->cols[ci].data->as<uint8_t>() + (size_t)(start[(size_t)s] + got[(size_t)s]) * w, (size_t)k * w, s});
+                }
+                got[(size_t)s] += k;
+            }
+            if (!sends.empty() || !recvs.empty()) t_->exchange(sends, recvs, stream_);
+            HIP_CHECK(hipEventRecord(ev_[2 + b], stream_));
+        }
+        HIP_CHECK(hipStreamSynchronize(stream_));
+        HIP_CHECK(hipStreamSynchronize(aux_));
+        for (auto& c : out->cols) c.data->set_stream(nullptr);
+        for (int s = 0; s < world_; ++s)
+            if (got[(size_t)s] != from[(size_t)s]) fail(BHIP_EEXEC, "shuffle: received rows do not add up to the count matrix");
+        if (st) {
+            st->rows_in = (uint64_t)n; st->rows_out = (uint64_t)n_out; st->streamed = 1; st->chunks = (uint64_t)C;
+            st->bytes_sent_remote = bytes_remote; st->bytes_kept_local = bytes_local;
+            st->staging_bytes = (uint64_t)n_stage * ((uint64_t)stage_rows * row_bytes + partition_scatter_temp_bytes(stage_rows));
+            st->ms_count = ms_count; st->ms_total = ms_since(t0);
+        }
+        stats_.seconds += ms_since(t0) * 1e-3;
+        stats_.bytes_out += bytes_remote;
+        stats_.calls += 1;
         return out;
     }
 
 private:
+    static double ms_since(std::chrono::steady_clock::time_point t0) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    void account(std::chrono::steady_clock::time_point t0, uint64_t bytes_out) {
+        stats_.seconds += ms_since(t0) * 1e-3;
+        stats_.bytes_out += bytes_out;
+        stats_.calls += 1;
+    }
+    // a header another rank sent: plausible for `schema`?  (a rank that called with a different schema would otherwise make this
+    // one slice a block by a foreign layout)
+    static void check_header(const int64_t* h, const Schema& schema, const char* what) {
+        bool ok = h[0] >= 0 && h[1] >= 0;
+        for (size_t i = 0; ok && i < schema.fields.size(); ++i) {
+            const bool utf8 = schema.fields[i].dtype == DT_UTF8;
+            ok = h[2 + 3 * i] >= 0 && (h[3 + 3 * i] != 0) == utf8;
+            const int w = dtype_width(schema.fields[i].dtype);
+            if (ok && w > 0) ok = h[2 + 3 * i] == h[0] * w;
+        }
+        if (!ok) fail(BHIP_EEXEC, std::string(what) + ": a peer's block header does not fit this rank's schema (collective calls need ONE schema on every rank)");
+    }
+    // all_gather of a few int64 words per rank (the same count on every rank) -> [rank][words]
+    std::vector<int64_t> gather_words(const std::vector<int64_t>& mine) {
+        Exec ex{ctx_, stream_};
+        const size_t nb = mine.size() * 8;
+        auto hs = make_buffer(ex, nb);
+        auto hr = make_buffer(ex, nb * (size_t)world_);
+        HIP_CHECK(hipMemcpyAsync(hs->ptr(), mine.data(), nb, hipMemcpyHostToDevice, stream_));
+        t_->all_gather(hs->ptr(), hr->ptr(), nb, stream_);
+        std::vector<int64_t> all(mine.size() * (size_t)world_);
+        HIP_CHECK(hipMemcpyAsync(all.data(), hr->ptr(), all.size() * 8, hipMemcpyDeviceToHost, stream_));
+        HIP_CHECK(hipStreamSynchronize(stream_));
+        return all;
+    }
+
     ContextPtr ctx_;
+    std::unique_ptr<Transport> t_;
     int world_, rank_;
-    ncclComm_t comm_ = nullptr;
-    hipStream_t stream_ = nullptr;
+    hipStream_t stream_ = nullptr, aux_ = nullptr;
+    hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};          // [0,1] staging set scattered, [2,3] staging set sent
+    std::mutex mu_;                                                    // one collective at a time per communicator
+    Stats stats_;
+};
+
+// ---- the exchange as plan nodes ----------------------------------------------------------------------------------------------
+// A stage boundary inside ONE plan per rank: where the reference writes a stage's partitions to IPC files and the next stage's
+// ShuffleReaderExec pulls them (rust/scheduler/src/planner.rs:136-171, rust/core/src/execution_plans/shuffle_reader.rs:77-99),
+// these nodes move the batches between the ranks' GPUs when they are executed — so a rank's whole distributed query is one
+// operator tree and one bhip_plan_collect per step.
+class ExchangeNode : public UnaryExec {
+protected:
+    std::shared_ptr<Communicator> comm_;
+    struct Cache { std::mutex mu; bool done = false; std::vector<BatchPtr> parts; };
+    std::shared_ptr<Cache> cache_ = std::make_shared<Cache>();
+    // every partition of the input as ONE batch, complete in memory (the communicator works on its own streams)
+    BatchPtr drain_input(const Exec& ex) const {
+        std::vector<BatchPtr> all;
+        const int n_in = input_->output_partitioning().count;
+        for (int p = 0; p < n_in; ++p) {
+            auto s = input_->execute(p, ex);
+            while (BatchPtr b = s->next())
+                if (b->n_rows) all.push_back(materialize_batch(ex, b));
+        }
+        BatchPtr one = all.empty() ? empty_batch(ex, input_->schema()) : all.size() == 1 ? all[0] : concat_batches(ex, input_->schema(), all);
+        stream_wait(ex);
+        return one;
+    }
+};
+
+class AllGatherExec : public ExchangeNode {
+public:
+    AllGatherExec(std::shared_ptr<Communicator> comm, PlanPtr input) {
+        comm_ = std::move(comm);
+        input_ = std::move(input);
+        ctx_ = input_->context() ? input_->context() : comm_->ctx();
+    }
+    const char* name() const override { return "AllGatherExec"; }
+    SchemaPtr schema() const override { return input_->schema(); }
+    Partitioning output_partitioning() const override { return Partitioning{BHIP_PART_UNKNOWN, comm_->world(), {}}; }
+    PlanPtr with_new_children(const std::vector<PlanPtr>& c) const override {
+        if (c.size() != 1) fail(BHIP_EINVAL, "AllGatherExec wrong number of children");
+        return std::make_shared<AllGatherExec>(comm_, c[0]);
+    }
+    std::string describe() const override { return std::string("AllGatherExec: ") + comm_->transport() + ", world=" + std::to_string(comm_->world()); }
+    StreamPtr execute(int partition, const Exec& ex) const override {
+        check_partition(*this, partition);
+        auto self = std::static_pointer_cast<const AllGatherExec>(shared_from_this());
+        return StreamPtr(new LazyStream(schema(), [self, partition, ex]() {
+            std::lock_guard<std::mutex> g(self->cache_->mu);
+            if (!self->cache_->done) {
+                self->cache_->parts = self->comm_->all_gather(self->drain_input(ex));
+                self->cache_->done = true;
+            }
+            return std::vector<BatchPtr>{self->cache_->parts[(size_t)partition]};
+        }));
+    }
+};
+
+class ShuffleExchangeExec : public ExchangeNode {
+public:
+    ShuffleExchangeExec(std::shared_ptr<Communicator> comm, PlanPtr input, std::string key, int64_t chunk_rows)
+        : key_(std::move(key)), chunk_rows_(chunk_rows) {
+        comm_ = std::move(comm);
+        input_ = std::move(input);
+        ctx_ = input_->context() ? input_->context() : comm_->ctx();
+        if (input_->schema()->index_of(key_) < 0) fail(BHIP_EINVAL, "ShuffleExchangeExec: No field named '" + key_ + "'");
+    }
+    const char* name() const override { return "ShuffleExchangeExec"; }
+    SchemaPtr schema() const override { return input_->schema(); }
+    // this rank's partition of Hash([key], world)
+    Partitioning output_partitioning() const override { return Partitioning{BHIP_PART_UNKNOWN, 1, {}}; }
+    PlanPtr with_new_children(const std::vector<PlanPtr>& c) const override {
+        if (c.size() != 1) fail(BHIP_EINVAL, "ShuffleExchangeExec wrong number of children");
+        return std::make_shared<ShuffleExchangeExec>(comm_, c[0], key_, chunk_rows_);
+    }
+    std::string describe() const override {
+        return "ShuffleExchangeExec: partitioning=Hash([" + key_ + "], " + std::to_string(comm_->world()) + "), " + comm_->transport() + ", rank " +
+               std::to_string(comm_->rank());
+    }
+    StreamPtr execute(int partition, const Exec& ex) const override {
+        check_partition(*this, partition);
+        auto self = std::static_pointer_cast<const ShuffleExchangeExec>(shared_from_this());
+        return StreamPtr(new LazyStream(schema(), [self, ex]() {
+            std::lock_guard<std::mutex> g(self->cache_->mu);
+            if (!self->cache_->done) {
+                self->cache_->parts = {self->comm_->shuffle(self->drain_input(ex), self->key_, self->chunk_rows_, nullptr)};
+                self->cache_->done = true;
+            }
+            return self->cache_->parts;
+        }));
+    }
+private:
+    std::string key_;
+    int64_t chunk_rows_;
 };
 
 }  // namespace bhip
 
-struct bhip_comm { std::unique_ptr<bhip::Communicator> c; };
+struct bhip_comm { std::shared_ptr<bhip::Communicator> c; };
 
 using namespace bhip;
 
@@ -316,16 +878,63 @@ bhip_status bhip_comm_unique_id(uint8_t* id) {
     BHIP_X_END
 }
 
+static void check_world(int32_t world, int32_t rank) {
+    if (world < 1 || rank < 0 || rank >= world) fail(BHIP_EINVAL, "communicator: rank outside the world");
+}
+
 bhip_status bhip_comm_create(bhip_ctx* ctx, const uint8_t* id, int32_t world, int32_t rank, bhip_comm** out) {
     BHIP_X_BEGIN
     if (!ctx || !id || !out) fail(BHIP_EINVAL, "null argument");
+    check_world(world, rank);
+    ctx->p->set_device();
     auto h = std::make_unique<bhip_comm>();
-    h->c = std::make_unique<Communicator>(ctx->p, id, world, rank);
+    h->c = std::make_shared<Communicator>(ctx->p, std::make_unique<RcclTransport>(id, world, rank), world, rank);
+    *out = h.release();
+    BHIP_X_END
+}
+
+bhip_status bhip_comm_create_loopback(bhip_ctx* ctx, const uint8_t* id, int32_t world, int32_t rank, bhip_comm** out) {
+    BHIP_X_BEGIN
+    if (!ctx || !id || !out) fail(BHIP_EINVAL, "null argument");
+    check_world(world, rank);
+    ctx->p->set_device();
+    auto h = std::make_unique<bhip_comm>();
+    h->c = std::make_shared<Communicator>(ctx->p, std::make_unique<LoopbackTransport>(id, world, rank), world, rank);
+    *out = h.release();
+    BHIP_X_END
+}
+
+bhip_status bhip_comm_create_host(bhip_ctx* ctx, const bhip_comm_host_transport* transport, int32_t world, int32_t rank, bhip_comm** out) {
+    BHIP_X_BEGIN
+    if (!ctx || !transport || !out) fail(BHIP_EINVAL, "null argument");
+    check_world(world, rank);
+    ctx->p->set_device();
+    auto h = std::make_unique<bhip_comm>();
+    h->c = std::make_shared<Communicator>(ctx->p, std::make_unique<HostTransport>(*transport, world), world, rank);
     *out = h.release();
     BHIP_X_END
 }
 
 void bhip_comm_release(bhip_comm* comm) { delete comm; }
+
+bhip_status bhip_comm_info(bhip_comm* comm, int32_t* world, int32_t* rank, const char** transport) {
+    BHIP_X_BEGIN
+    if (!comm) fail(BHIP_EINVAL, "null argument");
+    if (world) *world = comm->c->world();
+    if (rank) *rank = comm->c->rank();
+    if (transport) *transport = comm->c->transport();
+    BHIP_X_END
+}
+
+bhip_status bhip_comm_stats(bhip_comm* comm, int32_t reset, double* seconds, uint64_t* bytes_out, uint64_t* calls) {
+    BHIP_X_BEGIN
+    if (!comm) fail(BHIP_EINVAL, "null argument");
+    const auto s = comm->c->stats(reset != 0);
+    if (seconds) *seconds = s.seconds;
+    if (bytes_out) *bytes_out = s.bytes_out;
+    if (calls) *calls = s.calls;
+    BHIP_X_END
+}
 
 static bhip_batch* wrap(BatchPtr b) {
     auto h = new bhip_batch();
@@ -351,6 +960,32 @@ bhip_status bhip_comm_all_to_all(bhip_comm* comm, bhip_batch* const* parts, bhip
     }
     auto got = comm->c->all_to_all(in);
     for (size_t i = 0; i < got.size(); ++i) out[i] = wrap(got[i]);
+    BHIP_X_END
+}
+
+bhip_status bhip_comm_shuffle(bhip_comm* comm, bhip_batch* batch, const char* key_column, int64_t chunk_rows, bhip_batch** out,
+                              bhip_shuffle_stats* stats) {
+    BHIP_X_BEGIN
+    if (!comm || !batch || !key_column || !out) fail(BHIP_EINVAL, "null argument");
+    *out = wrap(comm->c->shuffle(batch->p, key_column, chunk_rows, stats));
+    BHIP_X_END
+}
+
+bhip_status bhip_plan_all_gather(bhip_comm* comm, bhip_plan* input, bhip_plan** out) {
+    BHIP_X_BEGIN
+    if (!comm || !input || !out) fail(BHIP_EINVAL, "null argument");
+    auto h = new bhip_plan();
+    try { h->p = std::make_shared<AllGatherExec>(comm->c, input->p); } catch (...) { delete h; throw; }
+    *out = h;
+    BHIP_X_END
+}
+
+bhip_status bhip_plan_shuffle(bhip_comm* comm, bhip_plan* input, const char* key_column, int64_t chunk_rows, bhip_plan** out) {
+    BHIP_X_BEGIN
+    if (!comm || !input || !key_column || !out) fail(BHIP_EINVAL, "null argument");
+    auto h = new bhip_plan();
+    try { h->p = std::make_shared<ShuffleExchangeExec>(comm->c, input->p, key_column, chunk_rows); } catch (...) { delete h; throw; }
+    *out = h;
     BHIP_X_END
 }
 

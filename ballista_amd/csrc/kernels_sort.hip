@@ -158,6 +158,37 @@ partition_scatter_kernel(const void* keys, int64_t n, uint32_t n_parts, const ui
     }
 }
 
+// counts[(row / rows_per_chunk) * n_parts + partition] += 1 for every row: the streaming shuffle (host/exchange.cpp) sizes every
+// chunk's sends and every receive buffer from this matrix before a single payload byte moves.  rows_per_chunk is a multiple of
+// SORT_CHUNK, so a workgroup's rows belong to one chunk: an LDS histogram, then n_parts global atomics per workgroup.
+template <int KEYW>
+__global__ void __launch_bounds__(SORT_BLOCK)
+partition_count_kernel(const void* keys, int64_t n, uint32_t n_parts, int64_t rows_per_chunk, unsigned long long* counts) {
+    __shared__ uint32_t s_hist[256];
+    s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * SORT_CHUNK;
+#pragma unroll
+    for (int i = 0; i < SORT_ITEMS; ++i) {
+        const int64_t j = base + i * SORT_BLOCK + threadIdx.x;
+        if (j < n) atomicAdd(&s_hist[partition_of<KEYW>(keys, j, n_parts)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < n_parts && s_hist[threadIdx.x])
+        atomicAdd(&counts[(size_t)(base / rows_per_chunk) * n_parts + threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
+}
+
+hipError_t partition_count(const LaunchCfg& cfg, const void* keys, int key_width, int64_t n, uint32_t n_parts, int64_t rows_per_chunk,
+                           uint64_t* counts) {
+    if (n_parts == 0 || n_parts > 256 || (key_width != 4 && key_width != 8) || rows_per_chunk <= 0 || rows_per_chunk % SORT_CHUNK) return hipErrorInvalidValue;
+    if (n == 0) return hipSuccess;
+    const int n_blocks = (int)((n + SORT_CHUNK - 1) / SORT_CHUNK);
+    if (key_width == 4) hipLaunchKernelGGL(partition_count_kernel<4>, dim3(n_blocks), dim3(SORT_BLOCK), 0, cfg.stream, keys, n, n_parts, rows_per_chunk, (unsigned long long*)counts);
+    else hipLaunchKernelGGL(partition_count_kernel<8>, dim3(n_blocks), dim3(SORT_BLOCK), 0, cfg.stream, keys, n, n_parts, rows_per_chunk, (unsigned long long*)counts);
+    return hipGetLastError();
+}
+int64_t partition_chunk_quantum() { return SORT_CHUNK; }
+
 size_t partition_scatter_temp_bytes(int64_t n) {
     const int64_t n_blocks = (n + SORT_CHUNK - 1) / SORT_CHUNK;
     const size_t hist = (size_t)256 * (n_blocks > 0 ? n_blocks : 1) * 4;
@@ -168,7 +199,7 @@ size_t partition_scatter_temp_bytes(int64_t n) {
 hipError_t partition_scatter(const LaunchCfg& cfg, const void* keys, int key_width, int64_t n, uint32_t n_parts, const TakeMany& cols,
                              void* temp, uint32_t* first_host) {
     if (n_parts == 0 || n_parts > 256 || (key_width != 4 && key_width != 8)) return hipErrorInvalidValue;
-    for (uint32_t p = 0; p <= n_parts; ++p) first_host[p] = 0;
+    if (first_host) for (uint32_t p = 0; p <= n_parts; ++p) first_host[p] = 0;
     if (n == 0) return hipSuccess;
     const int n_blocks = (int)((n + SORT_CHUNK - 1) / SORT_CHUNK);
     const size_t hist_elems = (size_t)256 * n_blocks;
@@ -182,6 +213,7 @@ hipError_t partition_scatter(const LaunchCfg& cfg, const void* keys, int key_wid
     if (key_width == 4) hipLaunchKernelGGL(partition_scatter_kernel<4>, dim3(n_blocks), dim3(SORT_BLOCK), 0, cfg.stream, keys, n, n_parts, offsets, n_blocks, cols);
     else hipLaunchKernelGGL(partition_scatter_kernel<8>, dim3(n_blocks), dim3(SORT_BLOCK), 0, cfg.stream, keys, n, n_parts, offsets, n_blocks, cols);
     if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (!first_host) return hipSuccess;              // the caller knows the partition sizes (partition_count): nothing to read back, no wait
     // offsets[p * n_blocks] = rows of partitions < p
     e = hipMemcpy2DAsync(first_host, 4, offsets, (size_t)n_blocks * 4, 4, n_parts, hipMemcpyDeviceToHost, cfg.stream);
     if (e != hipSuccess) return e;

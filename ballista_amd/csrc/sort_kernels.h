@@ -43,6 +43,12 @@ hipError_t launch_utf8_max_len(const LaunchCfg& cfg, const int32_t* offsets, int
 size_t partition_scatter_temp_bytes(int64_t n);
 hipError_t partition_scatter(const LaunchCfg& cfg, const void* keys, int key_width, int64_t n, uint32_t n_parts, const TakeMany& cols,
                              void* temp, uint32_t* first_host);
+// first_host == nullptr: only enqueues (no read-back, no wait) — for callers that already hold the partition sizes
+// partition_count: counts[chunk * n_parts + p] += rows of chunk `chunk` (rows_per_chunk each, a multiple of partition_chunk_quantum())
+// that go to partition p; counts zeroed by the caller
+hipError_t partition_count(const LaunchCfg& cfg, const void* keys, int key_width, int64_t n, uint32_t n_parts, int64_t rows_per_chunk,
+                           uint64_t* counts);
+int64_t partition_chunk_quantum();
 hipError_t launch_hash_to_pid(const LaunchCfg& cfg, const uint64_t* hashes, int64_t n, uint32_t n_parts, uint64_t* out);
 hipError_t launch_partition_bounds(const LaunchCfg& cfg, const uint64_t* sorted_keys, int64_t n, uint32_t n_parts, uint32_t* first);
 

@@ -391,13 +391,56 @@ bhip_status bhip_batch_concat(bhip_ctx* ctx, int32_t n, bhip_batch* const* batch
 typedef struct bhip_comm bhip_comm;
 bhip_status bhip_comm_unique_id(uint8_t* id /* BHIP_COMM_ID_BYTES */);
 bhip_status bhip_comm_create(bhip_ctx* ctx, const uint8_t* id, int32_t world, int32_t rank, bhip_comm** out);
+/* Everything above the byte movers (block layout, header / count matrices, who sends what to whom, the streaming shuffle)
+ * is one piece of code over a two-call transport; RCCL is one of three:
+ * bhip_comm_create_loopback: `world` communicators inside ONE process on one device (any 128 bytes as the id; an id serves
+ * one world once), each driven by its own thread; regions move with device-to-device copies after a host rendezvous.  It runs
+ * the N-rank code paths on a single-GPU box (tests).
+ * bhip_comm_create_host: the caller moves HOST bytes through two callbacks (0 = ok): an executor that only has its
+ * Flight / TCP channel between processes, or a rehearsal over gloo.  Regions of one peer pair are matched in order. */
+bhip_status bhip_comm_create_loopback(bhip_ctx* ctx, const uint8_t* id, int32_t world, int32_t rank, bhip_comm** out);
+typedef struct bhip_comm_region { void* ptr; uint64_t bytes; int32_t peer; } bhip_comm_region;
+typedef struct bhip_comm_host_transport {
+    void* user;
+    /* recv[r * bytes, (r + 1) * bytes) <- rank r's send[0, bytes) */
+    int32_t (*all_gather)(void* user, const void* send, void* recv, uint64_t bytes);
+    /* one grouped exchange: every send reaches the matching receive of its peer */
+    int32_t (*exchange)(void* user, int32_t n_sends, const bhip_comm_region* sends, int32_t n_recvs, const bhip_comm_region* recvs);
+} bhip_comm_host_transport;
+bhip_status bhip_comm_create_host(bhip_ctx* ctx, const bhip_comm_host_transport* transport, int32_t world, int32_t rank, bhip_comm** out);
 void bhip_comm_release(bhip_comm* comm);
+/* world, rank and the transport's name ("rccl" | "loopback" | "host"; valid while the communicator lives) */
+bhip_status bhip_comm_info(bhip_comm* comm, int32_t* world, int32_t* rank, const char** transport);
+/* wall seconds inside collective calls, bytes this rank sent to other ranks, calls — since the last reset */
+bhip_status bhip_comm_stats(bhip_comm* comm, int32_t reset, double* seconds, uint64_t* bytes_out, uint64_t* calls);
 /* the MergeExec side of a stage boundary: out[r] = rank r's batch, r = 0 .. world-1 (out[rank] is `mine`); the caller
  * releases every handle.  Small batches (partial aggregate states) travel in ONE ncclAllGather. */
 bhip_status bhip_comm_all_gather(bhip_comm* comm, bhip_batch* mine, bhip_batch** out /* world handles */);
 /* the shuffle of RepartitionExec(Hash(keys), world): parts[d] (bhip_batch_hash_partition) goes to rank d;
  * out[s] = what rank s held for this rank.  One grouped ncclSend / ncclRecv per peer pair. */
 bhip_status bhip_comm_all_to_all(bhip_comm* comm, bhip_batch* const* parts /* world */, bhip_batch** out /* world handles */);
+/* RepartitionExec(Hash([key_column], world)) (rust/core/src/serde/physical_plan/from_proto.rs:133-147) + the shuffle read
+ * (rust/core/src/execution_plans/shuffle_reader.rs:77-99) in one collective call: *out = the rows of every rank's `batch`
+ * whose key hashes to this rank, in source-rank order, input order within a source.  Fixed-width NULL-free columns with a
+ * NULL-free integer key STREAM in chunks of `chunk_rows` rows (<= 0: 64 Mi): a count pass sizes the result exactly, a peer's
+ * rows land at their final position, device memory beyond input and result is two chunks.  Anything else goes through
+ * bhip_batch_hash_partition + bhip_comm_all_to_all + concat inside the call.  stats may be NULL. */
+#define BHIP_SHUFFLE_MAX_PEERS 64
+typedef struct bhip_shuffle_stats {
+    uint64_t rows_in, rows_out, chunks, streamed;       /* streamed: 1 = the chunked path ran */
+    uint64_t bytes_sent_remote, bytes_kept_local, staging_bytes;
+    uint64_t rows_to[BHIP_SHUFFLE_MAX_PEERS];           /* rows of `batch` that went to each rank (the xGMI numerator) */
+    double ms_count, ms_total;                          /* the count pass; the whole call (host wall clock) */
+} bhip_shuffle_stats;
+bhip_status bhip_comm_shuffle(bhip_comm* comm, bhip_batch* batch, const char* key_column, int64_t chunk_rows, bhip_batch** out,
+                              bhip_shuffle_stats* stats);
+/* The exchange as plan nodes, so that a rank's whole distributed query is ONE operator tree (one bhip_plan_collect per step).
+ * AllGatherExec: executes every partition of `input`, all_gathers the result; `world` output partitions, partition r = rank
+ * r's batch (what MergeExec over the previous stage's partitions reads, rust/scheduler/src/planner.rs:136-171).
+ * ShuffleExchangeExec: executes every partition of `input`, bhip_comm_shuffle by `key_column`; one output partition.
+ * The plan keeps the communicator alive.  Every rank must execute the same exchange nodes in the same order. */
+bhip_status bhip_plan_all_gather(bhip_comm* comm, bhip_plan* input, bhip_plan** out);
+bhip_status bhip_plan_shuffle(bhip_comm* comm, bhip_plan* input, const char* key_column, int64_t chunk_rows, bhip_plan** out);
 /* The block form the exchange moves, for transports other than RCCL: header = 2 + 3 * columns int64 words (rows, block
  * bytes, then per column: data bytes, has offsets, has validity); the block holds every buffer, 64-byte aligned.
  * host_block NULL: only the header and *block_bytes are produced.  bhip_batch_unpack is the inverse (one copy to the
