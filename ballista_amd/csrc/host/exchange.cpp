@@ -220,6 +220,7 @@ public:
         NCCL_CHECK(rccl().AllGather(send, recv, bytes, ncclUint8, comm_, stream));
     }
     void exchange(const std::vector<Xfer>& sends, const std::vector<Xfer>& recvs, hipStream_t stream) override {
+        if (sends.empty() && recvs.empty()) return;
         // xGMI is point to point: one grouped launch keeps every peer's link busy at once
         NCCL_CHECK(rccl().GroupStart());
         for (auto& x : sends) NCCL_CHECK(rccl().Send(x.ptr, x.bytes, ncclUint8, x.peer, comm_, stream));
@@ -698,7 +699,7 @@ public:
                 }
                 got[(size_t)s] += k;
             }
-            if (!sends.empty() || !recvs.empty()) t_->exchange(sends, recvs, stream_);
+            t_->exchange(sends, recvs, stream_);         // every rank, every chunk (a rendezvous transport counts calls), even with nothing to move
             HIP_CHECK(hipEventRecord(ev_[2 + b], stream_));
         }
         HIP_CHECK(hipStreamSynchronize(stream_));

@@ -139,14 +139,16 @@ struct FbTable {
     size_t pos = 0;                     // position of the table
     bool ok() const { return base != nullptr; }
     template <class T> T rd(size_t at) const {
-        if (at + sizeof(T) > len) fail(BHIP_EEXEC, "Arrow IPC: metadata runs past its buffer");
+        if (at > len || sizeof(T) > len - at) fail(BHIP_EEXEC, "Arrow IPC: metadata runs past its buffer");    // (no `at + size`: it could wrap)
         T v;
         memcpy(&v, base + at, sizeof(T));
         return v;
     }
     size_t field(int slot) const {      // absolute position of the field, 0 = absent
         const int32_t soff = rd<int32_t>(pos);
-        const size_t vt = (size_t)((int64_t)pos - soff);
+        const int64_t vt_s = (int64_t)pos - (int64_t)soff;
+        if (vt_s < 0 || (uint64_t)vt_s >= len) fail(BHIP_EEXEC, "Arrow IPC: vtable outside the metadata");
+        const size_t vt = (size_t)vt_s;
         const uint16_t vsize = rd<uint16_t>(vt);
         const size_t entry = 4 + 2 * (size_t)slot;
         if (entry + 2 > vsize) return 0;
@@ -164,7 +166,7 @@ struct FbTable {
         if (!f) return std::string();
         const size_t s = f + rd<uint32_t>(f);
         const uint32_t n = rd<uint32_t>(s);
-        if (s + 4 + n > len) fail(BHIP_EEXEC, "Arrow IPC: string runs past the metadata");
+        if (s > len || len - s < 4 || n > len - s - 4) fail(BHIP_EEXEC, "Arrow IPC: string runs past the metadata");
         return std::string((const char*)base + s + 4, n);
     }
     // vector: position of element 0 and the count
@@ -174,6 +176,7 @@ struct FbTable {
         const size_t v = f + rd<uint32_t>(f);
         n = rd<uint32_t>(v);
         first = v + 4;
+        if (n > len) fail(BHIP_EEXEC, "Arrow IPC: vector longer than the metadata that holds it");
         return true;
     }
     FbTable vec_table(size_t first, uint32_t i) const {
@@ -185,6 +188,7 @@ struct FbTable {
 FbTable fb_root(const uint8_t* p, size_t len) {
     FbTable t{p, len, 0};
     t.pos = t.rd<uint32_t>(0);
+    if (t.pos > len || len - t.pos < 4) fail(BHIP_EEXEC, "Arrow IPC: root table outside the metadata");
     return t;
 }
 
@@ -548,7 +552,7 @@ void load_file(IpcFile& F) {
         fail(BHIP_EEXEC, "Arrow IPC: " + F.path + " is not an Arrow file (magic missing)");
     int32_t flen;
     memcpy(&flen, p + len - 10, 4);
-    if (flen <= 0 || (size_t)flen + 18 > len) fail(BHIP_EEXEC, "Arrow IPC: corrupt footer length in " + F.path);
+    if (flen <= 0 || (size_t)flen > len - 18) fail(BHIP_EEXEC, "Arrow IPC: corrupt footer length in " + F.path);
     const FbTable footer = fb_root(p + len - 10 - flen, (size_t)flen);
     const FbTable st = footer.table(1);
     if (!st.ok()) fail(BHIP_EEXEC, "Arrow IPC: footer without a schema");
@@ -571,7 +575,11 @@ void export_next(const std::shared_ptr<IpcFile>& Fp, ArrowArray* out) {
     const Fb::Block blk = F.blocks[F.next++];
     const uint8_t* p = F.bytes.data();
     const size_t len = F.bytes.size();
-    if (blk.offset < 8 || (size_t)blk.offset + (size_t)blk.meta + (size_t)blk.body > len) fail(BHIP_EEXEC, "Arrow IPC: record batch block outside the file");
+    // the footer's Block fields come from the file: every comparison by subtraction, nothing that could wrap
+    if (blk.offset < 8 || (uint64_t)blk.offset > len || blk.meta < 12 || (uint64_t)blk.meta > len - (size_t)blk.offset || blk.body < 0 ||
+        (uint64_t)blk.body > len - (size_t)blk.offset - (size_t)blk.meta)
+        fail(BHIP_EEXEC, "Arrow IPC: record batch block outside the file");
+    if ((blk.offset & 7) || (blk.meta & 7)) fail(BHIP_EEXEC, "Arrow IPC: record batch block not 8-byte aligned");
     size_t m = (size_t)blk.offset;
     uint32_t first_word;
     memcpy(&first_word, p + m, 4);
@@ -581,6 +589,7 @@ void export_next(const std::shared_ptr<IpcFile>& Fp, ArrowArray* out) {
     const FbTable rb = msg.table(2);
     if (rb.field(3)) fail(BHIP_ENOTIMPL, "Arrow IPC: compressed record batch bodies");
     const int64_t n_rows = rb.scalar<int64_t>(0, 0);
+    if (n_rows < 0 || n_rows > 0xFFFFFFF0ll) fail(BHIP_EEXEC, "Arrow IPC: record batch row count out of range");
     size_t nodes, bufs;
     uint32_t n_nodes, n_bufs;
     rb.vec(1, nodes, n_nodes);
@@ -597,7 +606,8 @@ void export_next(const std::shared_ptr<IpcFile>& Fp, ArrowArray* out) {
         if (bi >= n_bufs) fail(BHIP_EEXEC, "Arrow IPC: record batch has too few buffers");
         const int64_t off = rb.rd<int64_t>(bufs + 16 * (size_t)bi), bl = rb.rd<int64_t>(bufs + 16 * (size_t)bi + 8);
         ++bi;
-        if (off < 0 || bl < 0 || off + bl > blk.body) fail(BHIP_EEXEC, "Arrow IPC: buffer outside the record batch body");
+        if (off < 0 || bl < 0 || off > blk.body || bl > blk.body - off) fail(BHIP_EEXEC, "Arrow IPC: buffer outside the record batch body");
+        if (off & 7) fail(BHIP_EEXEC, "Arrow IPC: buffer not 8-byte aligned in the record batch body");       // (the format requires it; the consumers read words)
         blen = bl;
         return bl ? body + off : nullptr;
     };
@@ -607,6 +617,7 @@ void export_next(const std::shared_ptr<IpcFile>& Fp, ArrowArray* out) {
         a.length = rb.rd<int64_t>(nodes + 16 * c);
         a.null_count = rb.rd<int64_t>(nodes + 16 * c + 8);
         if (a.length != n_rows) fail(BHIP_EEXEC, "Arrow IPC: field node length differs from the batch length");
+        if (a.null_count < 0 || a.null_count > n_rows) fail(BHIP_EEXEC, "Arrow IPC: field node null count out of range");
         const int dt = F.schema->fields[c].large ? (int)DT_LARGE_UTF8 : F.schema->fields[c].dtype;
         int64_t bl;
         const void* validity = next_buf(bl);
@@ -620,6 +631,8 @@ void export_next(const std::shared_ptr<IpcFile>& Fp, ArrowArray* out) {
             int64_t dl;
             const void* d = next_buf(dl);
             if (n_rows > 0 && (oi[0] < 0 || oi[n_rows] < oi[0] || oi[n_rows] > dl)) fail(BHIP_EEXEC, "Arrow IPC: string offsets outside the data buffer");
+            for (int64_t i = 0; i < n_rows; ++i)                  // interior offsets reach a device gather: they must ascend
+                if (oi[i + 1] < oi[i]) fail(BHIP_EEXEC, "Arrow IPC: string offsets do not ascend");
             X->buffers[c].push_back(oi);
             X->buffers[c].push_back(d ? d : (const void*)zero_offset);
         } else if (dt == DT_UTF8) {
@@ -629,6 +642,8 @@ void export_next(const std::shared_ptr<IpcFile>& Fp, ArrowArray* out) {
             int64_t dl;
             const void* d = next_buf(dl);
             if (n_rows > 0 && (oi[0] < 0 || oi[n_rows] < oi[0] || oi[n_rows] > dl)) fail(BHIP_EEXEC, "Arrow IPC: string offsets outside the data buffer");
+            for (int64_t i = 0; i < n_rows; ++i)
+                if (oi[i + 1] < oi[i]) fail(BHIP_EEXEC, "Arrow IPC: string offsets do not ascend");
             X->buffers[c].push_back(oi);
             X->buffers[c].push_back(d ? d : (const void*)zero_offset);
         } else {

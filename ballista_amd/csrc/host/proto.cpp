@@ -255,7 +255,17 @@ ExprPtr unary(int kind, Pb r) {      // message { LogicalExprNode expr = 1; }
     return e;
 }
 
+// nesting of one wire plan: expressions inside expressions, plan nodes inside plan nodes.  A message nested deeper than any
+// planner writes (TPC-H's deepest expression is ~8 levels, a plan ~12) would otherwise walk the C++ stack down with it.
+constexpr int MAX_NESTING = 128;
+struct NestGuard {
+    static int& depth() { static thread_local int d = 0; return d; }
+    NestGuard() { if (++depth() > MAX_NESTING) { --depth(); fail(BHIP_EINVAL, "protobuf: message nested deeper than 128 levels"); } }
+    ~NestGuard() { --depth(); }
+};
+
 ExprPtr decode_expr(Pb r) {
+    NestGuard nest;
     uint32_t f, wt;
     ExprPtr out;
     while (r.next(f, wt)) {
@@ -708,6 +718,7 @@ struct Decoder {
     }
 
     PlanPtr plan(Pb r) {
+        NestGuard nest;
         uint32_t f, wt;
         PlanPtr out;
         while (r.next(f, wt)) {

@@ -4,98 +4,41 @@ The reference splits a query into stages at every exchange (rust/scheduler/src/p
 input partition, its output is pulled by the next stage through `ShuffleReaderExec`
 (rust/core/src/execution_plans/shuffle_reader.rs:77-99), and a stage that repartitions by key carries
 `RepartitionExec(Hash(exprs, n))` (rust/core/src/serde/physical_plan/from_proto.rs:133-147).  Here a rank is a
-partition, the exchange is a collective over xGMI instead of Flight over TCP:
+partition and the stage boundary is a NODE of the rank's plan — `AllGatherExec` / `ShuffleExchangeExec`
+(csrc/host/exchange.cpp) — that moves batches between the ranks' GPUs over xGMI when it is executed.  A rank's whole
+distributed query is ONE operator tree, a step is ONE `bhip_plan_collect`:
 
-  * Q1 / Q6 — scan -> filter -> partial aggregate per row block; ONE small all_gather of the partial-state batches;
-    MergeExec -> Final aggregate -> Sort on every rank.  No data-path collective.
-  * Q3 / Q5 — the order-key join's sides are not co-partitioned.  `shuffle` (BASELINE.json config #5): both sides are
-    split by `row_hash(orderkey) % N` on the device (`bhip_batch_hash_partition`) and exchanged all-to-all; every rank
-    joins and aggregates its own keys; the partial states are all_gathered.  `broadcast`: the (filtered, small) build
-    side is all_gathered instead and the probe side never moves — the reference's collect-left join, where every task
-    sees the whole build side (from_proto.rs:253-276).
+  * Q1 / Q6 — scan -> filter -> partial aggregate per row block -> AllGatherExec (the partial-state batches, a few hundred
+    bytes) -> MergeExec -> Final aggregate -> Sort, on every rank.  No data-path collective.
+  * Q3 / Q5 — the order-key join's sides are not co-partitioned.  `shuffle` (BASELINE.json config #5): both sides go
+    through ShuffleExchangeExec(Hash([orderkey], N)): split by `row_hash(orderkey) % N` on the device and exchanged (a
+    streaming, chunked all-to-all; rows land at their final position); every rank joins and aggregates its own keys; the
+    partial states are all_gathered.  `broadcast`: the (filtered, small) build side goes through AllGatherExec instead and
+    the probe side never moves — the reference's collect-left join, where every task sees the whole build side
+    (from_proto.rs:253-276).
 
-The flows are written against two small interfaces so that the SAME code runs under the CPU tests
-(tests/test_distributed_cpu.py: 2 gloo ranks, the oracle as the engine) and on the GPUs:
+The plan builders below take their operator classes from `tpch.P`, so the SAME definitions run on the HIP library
+(ballista_amd.plan) and, under the CPU tests, on the oracle (tests/plan_nodes.py evaluated by oracle/plan_eval.py over two
+gloo ranks: tests/test_distributed_cpu.py).
 
-  Engine  — how one rank computes: ProductEngine = the plans of ballista_amd.plan on the HIP library.
-  Group   — how batches travel: RcclGroup (bhip_comm_*: RCCL on device buffers, inside libballista_hip.so),
-            GlooGroup (the same blocks through host memory over torch.distributed gloo: rehearsal and CPU tests), SingleGroup.
+Groups — the control plane of a run (barrier, timing reduce, how the communicator is formed):
+  RcclGroup    control over gloo on the CPU, batches over the library's RCCL communicator (bhip_comm_create);
+  GlooGroup    batches through host memory over gloo, as the `host` transport of the SAME communicator code
+               (bhip_comm_create_host): rehearsal of the N-rank flow on a box with fewer GPUs;
+  SingleGroup  one rank.
 """
 from __future__ import annotations
 
-import os
 import time
-from typing import List, Sequence
 
 from . import tpch
-from .expr import col
-
-
-# ---- engines ---------------------------------------------------------------------------------------------------
-
-class ProductEngine:
-    """plans on libballista_hip.so; batches are device-resident ballista_amd.plan.RecordBatch"""
-
-    def __init__(self, ctx):
-        from . import plan as P
-        self.P, self.ctx = P, ctx
-
-    def leaf(self, partitions):
-        """MemoryExec over `partitions` (a batch, or a list of batches = one partition each)"""
-        if not isinstance(partitions, (list, tuple)):
-            partitions = [partitions]
-        return self.P.MemoryExec([[b] for b in partitions], self.ctx)
-
-    def run(self, plan):
-        """execute every partition of a NEW copy of the plan (tpch.fresh) -> one batch"""
-        plan = tpch.fresh(plan)
-        out = [b for b in plan.collect() if b.num_rows]
-        if not out:
-            return self.empty(plan.schema())
-        return out[0] if len(out) == 1 else self.P.concat(self.ctx, out)
-
-    def empty(self, schema):
-        import numpy as np
-        from . import expr as E
-        cols = []
-        for name, dtype, _ in schema:
-            vals = [] if dtype in (E.UTF8,) else np.zeros(0, self.P.NP_DTYPE.get(dtype, np.bool_))
-            cols.append((name, dtype, vals, None))
-        return self.P.RecordBatch.from_columns(self.ctx, cols)
-
-    def hash_partition(self, batch, key, n):
-        return self.P.hash_partition(batch, [col(key)], n)
-
-    def concat(self, batches):
-        live = [b for b in batches if b.num_rows]
-        if not live:
-            return batches[0]
-        return live[0] if len(live) == 1 else self.P.concat(self.ctx, live)
-
-    def num_rows(self, batch):
-        return batch.num_rows
-
-    def nbytes(self, batch):
-        return batch.memory_size()
-
-    def to_wire(self, batch):
-        """the block form the library's exchange moves (bhip_batch_pack), as host bytes: header words, then the block"""
-        import numpy as np
-        header, block = self.P.pack_batch(batch)
-        return np.concatenate([np.array([header.size], np.int64).view(np.uint8), header.view(np.uint8), block])
-
-    def from_wire(self, raw, like):
-        import numpy as np
-        raw = np.ascontiguousarray(raw, np.uint8)
-        n = int(raw[:8].view(np.int64)[0])
-        header = raw[8:8 + 8 * n].view(np.int64).copy()
-        return self.P.unpack_batch(self.ctx, like.schema3(), header, raw[8 + 8 * n:])
 
 
 # ---- groups ----------------------------------------------------------------------------------------------------
 
 class SingleGroup:
     rank, world, backend = 0, 1, "single"
+    comm = None
 
     def device_index(self, local_rank):
         return local_rank
@@ -109,12 +52,6 @@ class SingleGroup:
     def max_over_ranks(self, x):
         return x
 
-    def all_gather(self, eng, batch):
-        return [batch]
-
-    def all_to_all(self, eng, parts):
-        return list(parts)
-
     def describe(self):
         return dict(world=1, ranks_seen=[0], transport="none")
 
@@ -123,15 +60,16 @@ class SingleGroup:
 
 
 class GlooGroup:
-    """torch.distributed (gloo) for control AND payload: batches travel through host memory in the engine's wire form
-    (ProductEngine: the packed block of bhip_batch_pack; the CPU tests' oracle engine: Arrow IPC stream bytes).
-    The CPU tests' transport; on a GPU box it rehearses the N-rank flow with ranks sharing the GPU."""
+    """torch.distributed (gloo) for control AND payload.  The payload side is the `host` transport of the library's
+    communicator: header matrices, block layout and the streaming shuffle are the same C++ as over RCCL, only the bytes
+    travel through host memory.  On a GPU box it rehearses the N-rank flow with ranks sharing the GPU."""
     backend = "gloo"
 
     def __init__(self, dist):
         self.dist = dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
-        self.n_dev = None
+        self.comm = None
+        self.ranks_seen = []
 
     def device_index(self, local_rank):
         import ctypes
@@ -143,8 +81,53 @@ class GlooGroup:
         except OSError:
             return 0
 
+    # -- the two callbacks of bhip_comm_host_transport, over gloo
+    def _host_all_gather(self, send, recv):
+        import torch
+        n = len(send)
+        if n == 0:
+            return
+        out = torch.empty(n * self.world, dtype=torch.uint8)
+        self.dist.all_gather_into_tensor(out, torch.frombuffer(bytearray(send), dtype=torch.uint8))
+        recv[:] = memoryview(out.numpy()).cast("B")
+
+    def _host_exchange(self, sends, recvs):
+        """regions of one peer pair travel as ONE message in list order (both sides know every size)"""
+        import torch
+        out, inc = {}, {}
+        for view, peer in sends:
+            out.setdefault(peer, []).append(view)
+        for view, peer in recvs:
+            inc.setdefault(peer, []).append(view)
+        sbuf = {p: torch.frombuffer(bytearray(b"".join(bytes(v) for v in vs)), dtype=torch.uint8) for p, vs in out.items()}
+        rbuf = {p: torch.empty(sum(len(v) for v in vs), dtype=torch.uint8) for p, vs in inc.items()}
+        ops = []
+        for p in sorted(set(sbuf) | set(rbuf)):
+            if p in sbuf:
+                ops.append(self.dist.P2POp(self.dist.isend, sbuf[p], p))
+            if p in rbuf:
+                ops.append(self.dist.P2POp(self.dist.irecv, rbuf[p], p))
+        if ops:
+            for req in self.dist.batch_isend_irecv(ops):
+                req.wait()
+        for p, vs in inc.items():
+            raw, at = memoryview(rbuf[p].numpy()).cast("B"), 0
+            for v in vs:
+                v[:] = raw[at:at + len(v)]
+                at += len(v)
+
     def attach(self, ctx):
-        pass
+        from . import plan as P
+        self.comm = P.Communicator.host(ctx, self.world, self.rank, self._host_all_gather, self._host_exchange)
+        self._self_test(ctx)
+
+    def _self_test(self, ctx):
+        """a one-row all_gather checked against what every rank must see"""
+        from . import plan as P
+        mine = P.RecordBatch.from_columns(ctx, [("r", "Int32", [self.rank], None)])
+        self.ranks_seen = [int(b.column(0)[1][0]) for b in self.comm.all_gather(mine)]
+        if self.ranks_seen != list(range(self.world)):
+            raise RuntimeError(f"all_gather self-test returned {self.ranks_seen}")
 
     def barrier(self):
         self.dist.barrier()
@@ -155,49 +138,13 @@ class GlooGroup:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
-    def all_gather(self, eng, batch):
-        """every rank's batch, in rank order (the order MergeExec concatenates partitions in)"""
-        import torch
-        raw = eng.to_wire(batch)
-        size = torch.tensor([raw.size], dtype=torch.int64)
-        sizes = [torch.empty_like(size) for _ in range(self.world)]
-        self.dist.all_gather(sizes, size)
-        sizes = [int(s.item()) for s in sizes]
-        cap = max(sizes)
-        buf = torch.zeros(cap, dtype=torch.uint8)
-        buf[:raw.size] = torch.from_numpy(raw.copy())
-        out = torch.empty(self.world * cap, dtype=torch.uint8)
-        self.dist.all_gather_into_tensor(out, buf)
-        host = out.numpy().reshape(self.world, cap)
-        return [batch if r == self.rank else eng.from_wire(host[r, :sizes[r]], batch) for r in range(self.world)]
-
-    def all_to_all(self, eng, parts):
-        """parts[d] goes to rank d; returns what every rank holds for me, in source-rank order"""
-        import torch
-        if len(parts) != self.world:
-            raise ValueError(f"need one outgoing batch per rank ({self.world}), got {len(parts)}")
-        payload = [eng.to_wire(p) for p in parts]
-        sizes = torch.tensor([p.size for p in payload], dtype=torch.int64)
-        all_sizes = [torch.empty_like(sizes) for _ in range(self.world)]
-        self.dist.all_gather(all_sizes, sizes)
-        incoming = [int(all_sizes[src][self.rank].item()) for src in range(self.world)]
-        send = [torch.from_numpy(payload[d].copy()) for d in range(self.world)]
-        recv = [torch.empty(incoming[s], dtype=torch.uint8) for s in range(self.world)]
-        ops = []
-        for peer in range(self.world):
-            if peer == self.rank:
-                continue
-            ops.append(self.dist.P2POp(self.dist.isend, send[peer], peer))
-            ops.append(self.dist.P2POp(self.dist.irecv, recv[peer], peer))
-        if ops:
-            for req in self.dist.batch_isend_irecv(ops):
-                req.wait()
-        return [parts[s] if s == self.rank else eng.from_wire(recv[s].numpy(), parts[s]) for s in range(self.world)]
-
     def describe(self):
-        return dict(world=self.world, ranks_seen=list(range(self.world)), transport="gloo (host memory)")
+        return dict(world=self.world, ranks_seen=self.ranks_seen, transport=self.comm.info()["transport"] if self.comm else "none")
 
     def close(self):
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None
         self.dist.destroy_process_group()
 
 
@@ -209,39 +156,32 @@ class RcclGroup(GlooGroup):
 
     def __init__(self, dist, allow_host_exchange=False):
         super().__init__(dist)
-        self.comm = None
         self.allow_host_exchange = allow_host_exchange
-        self.ranks_seen = []
 
     def device_index(self, local_rank):
         return local_rank
-
-    def describe(self):
-        if self.comm is None:
-            return dict(world=self.world, ranks_seen=[], transport="NONE: RCCL unavailable, batches through host memory over gloo")
-        return dict(world=self.world, ranks_seen=self.ranks_seen, transport="rccl")
 
     def attach(self, ctx):
         import torch
         from . import plan as P
         uid = torch.zeros(P.Communicator.UNIQUE_ID_BYTES, dtype=torch.uint8)
+        err = None
         if self.rank == 0:
-            uid = torch.frombuffer(bytearray(P.Communicator.unique_id()), dtype=torch.uint8).clone()
+            try:
+                uid = torch.frombuffer(bytearray(P.Communicator.unique_id()), dtype=torch.uint8).clone()
+            except Exception as e:                               # noqa: BLE001 — reported through the agreement below
+                err = f"{type(e).__name__}: {e}"
         self.dist.broadcast(uid, src=0)
         # The communicator is created and exercised once (a one-row all_gather checked against what every rank must see).  If any
-        # rank cannot do that — no RCCL on the box, a transport the fabric refuses — ALL ranks agree (over gloo) to move batches
-        # through host memory instead, and the bench line says so: a scaling run still completes and reports what it measured.
-        err = None
-        try:
-            self.comm = P.Communicator(ctx, bytes(uid.numpy().tobytes()), self.world, self.rank)
-            mine = P.RecordBatch.from_columns(ctx, [("r", "Int32", [self.rank], None)])
-            got = self.comm.all_gather(mine)
-            seen = [int(b.column(0)[1][0]) for b in got]
-            self.ranks_seen = seen
-            if seen != list(range(self.world)):
-                err = f"all_gather self-test returned {seen}"
-        except Exception as e:                                   # noqa: BLE001 — any failure means the same thing here
-            err = f"{type(e).__name__}: {e}"
+        # rank cannot do that — no RCCL on the box, a transport the fabric refuses — ALL ranks learn it (over gloo) and the run
+        # FAILS: a scaling record must not show N ranks and a plausible value with RCCL never having moved a byte.  Only with
+        # allow_host_exchange (bench.py --allow-host-exchange) do the ranks agree to move batches through host memory instead.
+        if err is None:
+            try:
+                self.comm = P.Communicator(ctx, bytes(uid.numpy().tobytes()), self.world, self.rank)
+                self._self_test(ctx)
+            except Exception as e:                               # noqa: BLE001 — any failure means the same thing here
+                err = f"{type(e).__name__}: {e}"
         flag = torch.tensor([1 if err else 0], dtype=torch.int32)
         self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
         if int(flag[0]):
@@ -253,25 +193,9 @@ class RcclGroup(GlooGroup):
             self.comm = None
             why = "RCCL communicator unavailable: " + (err or "on another rank")
             if not self.allow_host_exchange:
-                # a scaling record must not show N ranks and a plausible value with RCCL never having moved a byte
-                raise RuntimeError(why + " — refusing to fall back to host-staged gloo (pass --allow-host-exchange to bench.py to rehearse that way)")
+                raise RuntimeError(why + " — refusing to fall back to host-staged gloo (bench.py --allow-host-exchange rehearses that way)")
             self.backend = "gloo, batches through host memory (" + why + ")"
-
-    def all_gather(self, eng, batch):
-        if self.comm is None:
-            return super().all_gather(eng, batch)
-        return self.comm.all_gather(batch)
-
-    def all_to_all(self, eng, parts):
-        if self.comm is None:
-            return super().all_to_all(eng, parts)
-        return self.comm.all_to_all(parts)
-
-    def close(self):
-        if self.comm is not None:
-            self.comm.close()
-            self.comm = None
-        super().close()
+            GlooGroup.attach(self, ctx)
 
 
 class ProcessGroup:
@@ -288,130 +212,135 @@ class ProcessGroup:
         return RcclGroup(dist, allow_host_exchange) if backend == "nccl" else GlooGroup(dist)
 
 
-# ---- distributed query flows (engine- and transport-agnostic) -------------------------------------------------------
+# ---- a rank's plan of a distributed query ---------------------------------------------------------------------------------
+# `comm`: the exchange handle the nodes are built over (ballista_amd.plan.Communicator; the CPU tests pass their own with the
+# same `world` attribute); None or world == 1: no exchange nodes at all.  orders / lineitem are this rank's row blocks, the
+# small tables are replicated.  `chunk_rows`: rows per chunk of the streaming shuffle (0 = the library's default).
 
-class ExchangeStats:
-    def __init__(self):
-        self.reset()
-
-    def reset(self):
-        self.seconds, self.bytes_out, self.calls = 0.0, 0, 0
-
-    def add(self, dt, nbytes):
-        self.seconds += dt
-        self.bytes_out += nbytes
-        self.calls += 1
+def _many(comm):
+    return comm is not None and comm.world > 1
 
 
-def _shuffle(eng, group, batch, key, stats=None, sync=None):
-    """RepartitionExec(Hash([key], world)) + the shuffle read: my rows of every rank's batch"""
-    t0 = time.perf_counter()
-    parts = eng.hash_partition(batch, key, group.world)
-    out_bytes = sum(eng.nbytes(p) for r, p in enumerate(parts) if r != group.rank)
-    got = group.all_to_all(eng, parts)
-    mine = eng.concat(got)
-    if sync is not None:
-        sync()
-    if stats is not None:
-        stats.add(time.perf_counter() - t0, out_bytes)
-    return mine
-
-
-def q1_distributed(eng, group, lineitem, query="q1"):
+def q1_rank_plan(comm, lineitem, query="q1"):
     """stage 1 on this rank's rows, all_gather of the partial states, Merge -> Final (-> Sort) on every rank"""
-    if query == "q1":
-        part = eng.run(tpch.q1_stage1(lineitem))
-        states = group.all_gather(eng, part)
-        return eng.run(tpch.q1_final(eng.leaf(states)))
-    part = eng.run(tpch.q6_stage1(lineitem))
-    states = group.all_gather(eng, part)
-    return eng.run(tpch.q6_final(eng.leaf(states)))
+    stage1 = tpch.q1_stage1(lineitem) if query == "q1" else tpch.q6_stage1(lineitem)
+    states = tpch.P.AllGatherExec(stage1, comm) if _many(comm) else stage1
+    return tpch.q1_final(states) if query == "q1" else tpch.q6_final(states)
 
 
-def q3_distributed(eng, group, customer, orders, lineitem, join_exchange="shuffle", stats=None, sync=None):
-    """customer is replicated, orders / lineitem are this rank's row blocks"""
-    j1 = eng.run(tpch.q3_build_side(customer, orders))
-    if join_exchange == "broadcast":
-        t0 = time.perf_counter()
-        j1_all = eng.concat(group.all_gather(eng, j1))
-        if stats is not None:
-            if sync is not None:
-                sync()
-            stats.add(time.perf_counter() - t0, eng.nbytes(j1) * (group.world - 1))
-        partial = eng.run(tpch.q3_partial(eng.leaf(j1_all), tpch.q3_probe_side(lineitem)))
-    else:
-        li = eng.run(tpch.q3_probe_side(lineitem))
-        j1_mine = _shuffle(eng, group, j1, "o_orderkey", stats, sync)
-        li_mine = _shuffle(eng, group, li, "l_orderkey", stats, sync)
-        partial = eng.run(tpch.q3_partial(eng.leaf(j1_mine), eng.leaf(li_mine)))
-    states = group.all_gather(eng, partial)
-    return eng.run(tpch.q3_final(eng.leaf(states)))
+def q3_rank_plan(comm, customer, orders, lineitem, join_exchange="shuffle", chunk_rows=0):
+    P = tpch.P
+    j1, li = tpch.q3_build_side(customer, orders), tpch.q3_probe_side(lineitem)
+    if _many(comm):
+        if join_exchange == "broadcast":
+            j1 = P.AllGatherExec(j1, comm)                   # world partitions: the join drains them all (collect-left)
+        else:
+            j1 = P.ShuffleExchangeExec(j1, comm, "o_orderkey", chunk_rows)
+            li = P.ShuffleExchangeExec(li, comm, "l_orderkey", chunk_rows)
+    partial = tpch.q3_partial(j1, li)
+    return tpch.q3_final(P.AllGatherExec(partial, comm) if _many(comm) else partial)
 
 
-def q5_distributed(eng, group, customer, orders, lineitem, supplier, nation, region, join_exchange="shuffle", stats=None, sync=None):
-    """customer / supplier / nation / region are replicated, orders / lineitem are this rank's row blocks"""
-    co = eng.run(tpch.q5_build_side(customer, orders, nation, region))
-    if join_exchange == "broadcast":
-        t0 = time.perf_counter()
-        co_all = eng.concat(group.all_gather(eng, co))
-        if stats is not None:
-            if sync is not None:
-                sync()
-            stats.add(time.perf_counter() - t0, eng.nbytes(co) * (group.world - 1))
-        partial = eng.run(tpch.q5_partial(eng.leaf(co_all), tpch.q5_probe_side(lineitem), supplier))
-    else:
-        li = eng.run(tpch.q5_probe_side(lineitem))
-        co_mine = _shuffle(eng, group, co, "o_orderkey", stats, sync)
-        li_mine = _shuffle(eng, group, li, "l_orderkey", stats, sync)
-        partial = eng.run(tpch.q5_partial(eng.leaf(co_mine), eng.leaf(li_mine), supplier))
-    states = group.all_gather(eng, partial)
-    return eng.run(tpch.q5_final(eng.leaf(states)))
+def q5_rank_plan(comm, customer, orders, lineitem, supplier, nation, region, join_exchange="shuffle", chunk_rows=0):
+    P = tpch.P
+    co, li = tpch.q5_build_side(customer, orders, nation, region), tpch.q5_probe_side(lineitem)
+    if _many(comm):
+        if join_exchange == "broadcast":
+            co = P.AllGatherExec(co, comm)
+        else:
+            co = P.ShuffleExchangeExec(co, comm, "o_orderkey", chunk_rows)
+            li = P.ShuffleExchangeExec(li, comm, "l_orderkey", chunk_rows)
+    partial = tpch.q5_partial(co, li, supplier)
+    return tpch.q5_final(P.AllGatherExec(partial, comm) if _many(comm) else partial)
+
+
+def rank_plan(query, comm, t, join_exchange="shuffle", chunk_rows=0):
+    """t: {table name: leaf plan}"""
+    if query in ("q1", "q6"):
+        return q1_rank_plan(comm, t["lineitem"], query)
+    if query == "q3":
+        return q3_rank_plan(comm, t["customer"], t["orders"], t["lineitem"], join_exchange, chunk_rows)
+    return q5_rank_plan(comm, t["customer"], t["orders"], t["lineitem"], t["supplier"], t["nation"], t["region"], join_exchange, chunk_rows)
+
+
+def row_block(n, rank, world):
+    """(first row, rows) of rank's block of an n-row table split `world` ways"""
+    per = (n + world - 1) // world
+    lo = min(n, rank * per)
+    return lo, min(n, lo + per) - lo
+
+
+# ---- per-rank memory plan of the order-key shuffle (BASELINE.json config #5) ------------------------------------------------
+
+def q5_memory_plan(sf, world, key_bytes=8, chunk_rows=64 << 20, hbm_bytes=288e9):
+    """Device bytes ONE rank holds at the peak of Q5's order-key exchange at scale factor `sf` over `world` GPUs, from the row
+    counts alone (lineitem l_orderkey + l_suppkey + 2 x f64, orders o_orderkey + o_custkey + o_orderdate).
+    `resident` stays for the whole query; `peak_staging` is what the streaming shuffle adds (the received side at its exact
+    size + two chunks); `general_path` is what hash_partition + all_to_all + concat would hold instead (N partitions, N packed
+    blocks, N received blocks, the concatenation: ~4 more copies)."""
+    n = tpch.table_rows(sf)
+    li_row, od_row = key_bytes + 4 + 16, key_bytes + 8
+    li_rows, od_rows = n["lineitem"] / world, n["orders"] / world
+    od_kept = od_rows * 0.152                                    # orders of 1994 that survive customer(ASIA): ~15.2 % x 1/5 ... upper bound: the date filter alone
+    resident = dict(lineitem=li_rows * li_row, orders=od_rows * (key_bytes + 12), customer=n["customer"] * 8, supplier=n["supplier"] * 8)
+    received = li_rows * li_row + od_kept * (key_bytes + 4 + 16)  # my share of every rank's rows ~= my own row count
+    staging = 2 * min(chunk_rows, li_rows) * li_row
+    join = od_kept * 2 * (key_bytes + 8) + li_rows * 0.152 * 24   # rank map / table + the matches handed on (upper bounds)
+    peak = sum(resident.values()) + received + staging + join
+    general = sum(resident.values()) + 5 * li_rows * li_row + join
+    return dict(sf=sf, world=world, lineitem_rows_per_rank=int(li_rows), orders_rows_per_rank=int(od_rows),
+                resident_bytes=int(sum(resident.values())), received_bytes=int(received), staging_bytes=int(staging),
+                join_bytes=int(join), peak_bytes=int(peak), general_path_peak_bytes=int(general), hbm_bytes=int(hbm_bytes),
+                fits=bool(peak < 0.92 * hbm_bytes), general_path_fits=bool(general < 0.92 * hbm_bytes),
+                exchange_bytes_out_per_rank=int((li_rows * li_row + od_kept * (key_bytes + 4 + 16)) * (world - 1) / world),
+                xgmi_floor_ms=(li_rows * li_row + od_kept * (key_bytes + 4 + 16)) / world / 153e9 * 1e3)
 
 
 # ---- bench.py's workloads ------------------------------------------------------------------------------------------
 
 class Workload:
     """tables in HBM + one step of a query, for bench.py.  mode "strong": the fixed tables split N ways by row
-    block; "weak": every rank its own full-size block."""
+    block; "weak" (Q1 / Q6): every rank its own full-size block."""
 
-    def __init__(self, query, ctx, group, sf, rows, key64=False, join_exchange="shuffle"):
+    def __init__(self, query, ctx, group, sf, rows, key64=False, join_exchange="shuffle", chunk_rows=0):
+        from . import plan as P
+        self.P = P
         self.query, self.ctx, self.group, self.sf, self.rows, self.key64 = query, ctx, group, sf, dict(rows), key64
-        self.join_exchange = join_exchange
-        self.eng = ProductEngine(ctx)
-        self.stats = ExchangeStats()
+        self.join_exchange, self.chunk_rows = join_exchange, chunk_rows
         self.local = {}
         self.t = {}
         self.plan = None
         self.cold, self.spent = [], []
+        self.step_seconds = []
 
     def _block(self, table, mode):
         n = self.rows[table]
         if mode == "weak" or self.group.world == 1:
             return self.group.rank * n, n
-        per = (n + self.group.world - 1) // self.group.world
-        lo = min(n, self.group.rank * per)
-        return lo, min(n, lo + per) - lo
+        return row_block(n, self.group.rank, self.group.world)
+
+    def _leaf(self, batch):
+        return self.P.MemoryExec([[batch]], self.ctx)
 
     def load(self, mode):
-        P, ctx = self.eng.P, self.ctx
-        self.t.clear()                         # release the previous tables first
-        self.plan = None
-        self.cold, self.spent = [], []
+        P, ctx = self.P, self.ctx
+        self.unload()                          # release the previous tables first
+        # only the columns the query reads: an SF1000 rank block of all nine lineitem columns would be twice Q5's four
+        li_cols = {"q1": ["l_quantity", "l_extendedprice", "l_discount", "l_tax", "l_returnflag", "l_linestatus", "l_shipdate"],
+                   "q6": ["l_quantity", "l_extendedprice", "l_discount", "l_shipdate"],
+                   "q3": ["l_orderkey", "l_extendedprice", "l_discount", "l_shipdate"],
+                   "q5": ["l_orderkey", "l_suppkey", "l_extendedprice", "l_discount"]}[self.query]
         lo, n = self._block("lineitem", mode)
         self.local["lineitem"] = n
-        li = P.tpch_lineitem(ctx, self.sf, tpch.SEED, lo, n, key64=self.key64)
-        self.t["lineitem"] = self.eng.leaf(li)
+        self.t["lineitem"] = self._leaf(P.tpch_lineitem(ctx, self.sf, tpch.SEED, lo, n, key64=self.key64, columns=li_cols))
         if self.query in ("q3", "q5"):
             lo, n = self._block("orders", mode)
             self.local["orders"] = n
-            self.t["orders"] = self.eng.leaf(P.tpch_orders(ctx, self.sf, tpch.SEED, lo, n, key64=self.key64))
+            od_cols = ["o_orderkey", "o_custkey", "o_orderdate"] + (["o_shippriority"] if self.query == "q3" else [])
+            self.t["orders"] = self._leaf(P.tpch_orders(ctx, self.sf, tpch.SEED, lo, n, key64=self.key64, columns=od_cols))
             for k, b in tpch.dimension_tables(ctx, self.sf).items():
-                self.t[k] = self.eng.leaf(b)
-        t = self.t
-        if self.group.world == 1:
-            self.plan = {"q1": lambda: tpch.q1_plan(t["lineitem"]), "q6": lambda: tpch.q6_plan(t["lineitem"]),
-                         "q3": lambda: tpch.q3_plan(t["customer"], t["orders"], t["lineitem"]),
-                         "q5": lambda: tpch.q5_plan(t["customer"], t["orders"], t["lineitem"], t["supplier"], t["nation"], t["region"])}[self.query]()
+                self.t[k] = self._leaf(b)
+        self.plan = rank_plan(self.query, self.group.comm, self.t, self.join_exchange, self.chunk_rows)
         ctx.synchronize()
 
     def unload(self):
@@ -423,32 +352,26 @@ class Workload:
         gc.collect()
         self.ctx.synchronize()
 
-    def host_overhead(self, reset=False):
-        return None
-
     def prepare(self, n):
         """n operator trees that have never run (tpch.fresh), built ahead of the timed region: a task's plan is decoded from the
         wire before `plan.execute(partition)` is called (rust/executor/src/flight_service.rs:87-121); what a step times is the
-        execution of a cold tree — join builds, path choices and all"""
+        execution of a cold tree — join builds, path choices, exchanges and all.  The same for every world size: a rank's
+        distributed query is one tree (exchange nodes included), so no plan is built inside the timed loop."""
         self.spent = []
-        self.cold = [tpch.fresh(self.plan) for _ in range(n)] if self.group.world == 1 else []
+        self.cold = [tpch.fresh(self.plan) for _ in range(n)]
+        self.step_seconds = []
 
     def step(self):
-        t, g = self.t, self.group
-        if g.world == 1:
-            # the previous step's operator tree goes first, as a task's plan does when the task is done: its join build sides
-            # return to the allocator's cache and this step's builds take them from there (kept until the end of the timed
-            # region, every step went to hipMalloc for its build sides: 7 calls per Q3 step, 0.2-5 ms depending on the driver's mood)
-            self.spent.clear()
-            plan = self.cold.pop() if getattr(self, "cold", None) else tpch.fresh(self.plan)
-            self.spent.append(plan)
-            return plan.collect()
-        if self.query in ("q1", "q6"):
-            return [q1_distributed(self.eng, g, t["lineitem"], self.query)]
-        if self.query == "q3":
-            return [q3_distributed(self.eng, g, t["customer"], t["orders"], t["lineitem"], self.join_exchange, self.stats, self.ctx.synchronize)]
-        return [q5_distributed(self.eng, g, t["customer"], t["orders"], t["lineitem"], t["supplier"], t["nation"], t["region"],
-                               self.join_exchange, self.stats, self.ctx.synchronize)]
+        # the previous step's operator tree goes first, as a task's plan does when the task is done: its join build sides
+        # return to the allocator's cache and this step's builds take them from there (kept until the end of the timed
+        # region, every step went to hipMalloc for its build sides: 7 calls per Q3 step, 0.2-5 ms depending on the driver's mood)
+        self.spent.clear()
+        plan = self.cold.pop() if self.cold else tpch.fresh(self.plan)
+        self.spent.append(plan)
+        t0 = time.perf_counter()
+        out = plan.collect()                                      # ONE C call: bhip_plan_collect
+        self.step_seconds.append(time.perf_counter() - t0)
+        return out
 
     # -- reporting
     def rows_local(self, table):
@@ -486,15 +409,27 @@ class Workload:
         return tpch.KERNEL_BYTES.get(kernel, lambda n, kb: 0)(n, key_bytes)
 
     def exchange_stats(self, reset=False):
-        s = self.stats
-        if not s.calls:
+        comm = self.group.comm
+        if comm is None:
             return None
-        out = dict(calls=s.calls, seconds=s.seconds, bytes_out_per_rank=s.bytes_out,
-                   gbs_per_rank=s.bytes_out / s.seconds / 1e9 if s.seconds else 0.0,
-                   gbs_per_link=s.bytes_out / s.seconds / 1e9 / max(1, self.group.world - 1) if s.seconds else 0.0,
-                   note="hash partition + all-to-all + concat, wall time on rank 0; one xGMI link per peer")
+        s = comm.stats(reset)
+        if not s["calls"]:
+            return None
+        sec, out = s["seconds"], s["bytes_out"]
+        return dict(calls=s["calls"], seconds=sec, bytes_out_per_rank=out, gbs_per_rank=out / sec / 1e9 if sec else 0.0,
+                    gbs_per_link=out / sec / 1e9 / max(1, self.group.world - 1) if sec else 0.0, transport=comm.info()["transport"],
+                    note="collective calls of this rank since the last reset (all_gather, shuffle: count pass + scatter + grouped "
+                         "send / receive), host wall time inside the library; one xGMI link per peer")
+
+    def host_overhead(self, reset=False):
+        """per-step wall time of the ONE C call a step is, on this rank (bench.py subtracts nothing from it: kernels and
+        transport are inside); the Python side of a step is what the step loop adds on top"""
+        if not self.step_seconds:
+            return None
+        s = sorted(self.step_seconds)
+        out = dict(collect_ms_median=s[len(s) // 2] * 1e3, collect_ms_min=s[0] * 1e3, steps=len(s))
         if reset:
-            s.reset()
+            self.step_seconds = []
         return out
 
     def result_check(self, result):
@@ -504,7 +439,7 @@ class Workload:
         out = {"result_rows": n_rows}
         head = result[0]
         if head.num_rows > 64:
-            head = self.eng.run(self.eng.P.GlobalLimitExec(self.eng.leaf(head), 8))
+            head = self.P.GlobalLimitExec(self._leaf(head), 8).collect()[0]
         d = head.to_pydict()
         if "count_order" in d:
             out["groups"] = len(d["count_order"])

@@ -854,7 +854,9 @@ class IpcFileExec(ExecutionPlan):
 
 
 class Communicator:
-    """bhip_comm: the library's own RCCL communicator (one per process and GPU).  All calls are collective."""
+    """bhip_comm: batches between the ranks of one node (one communicator per process and GPU; csrc/host/exchange.cpp).
+    All calls are collective.  Transports: RCCL (the constructor), `loopback` (N communicators in one process on one device,
+    one thread each: the N-rank code on a single-GPU box), `host` (the caller moves host bytes: a rehearsal over gloo)."""
     UNIQUE_ID_BYTES = 128
 
     @staticmethod
@@ -863,16 +865,73 @@ class Communicator:
         L.check(L.lib().bhip_comm_unique_id(buf))
         return buf.raw
 
-    def __init__(self, ctx: Context, unique_id: bytes, world: int, rank: int):
-        if len(unique_id) != self.UNIQUE_ID_BYTES:
-            raise ValueError("unique id must be 128 bytes")
+    def __init__(self, ctx: Context, unique_id: bytes, world: int, rank: int, _handle=None, _keep=None):
+        if _handle is None:
+            if len(unique_id) != self.UNIQUE_ID_BYTES:
+                raise ValueError("unique id must be 128 bytes")
+            _handle = C.c_void_p()
+            L.check(L.lib().bhip_comm_create(ctx._h, unique_id, world, rank, C.byref(_handle)))
+        self._h, self.ctx, self.world, self.rank, self._keep = _handle, ctx, world, rank, _keep
+
+    @classmethod
+    def loopback(cls, ctx: Context, hub_id: bytes, world: int, rank: int) -> "Communicator":
+        """rank `rank` of a world of communicators that live in THIS process (the same hub_id on every rank, any bytes)"""
+        hub_id = (hub_id + b"\0" * cls.UNIQUE_ID_BYTES)[:cls.UNIQUE_ID_BYTES]
         h = C.c_void_p()
-        L.check(L.lib().bhip_comm_create(ctx._h, unique_id, world, rank, C.byref(h)))
-        self._h, self.ctx, self.world, self.rank = h, ctx, world, rank
+        L.check(L.lib().bhip_comm_create_loopback(ctx._h, hub_id, world, rank, C.byref(h)))
+        return cls(ctx, b"", world, rank, _handle=h)
+
+    @classmethod
+    def host(cls, ctx: Context, world: int, rank: int, all_gather, exchange) -> "Communicator":
+        """the caller moves host bytes.  all_gather(send: memoryview, recv: memoryview(world * len(send)));
+        exchange(sends: [(memoryview, peer)], recvs: [(memoryview, peer)]) — regions of one peer pair are matched in order"""
+        def view(ptr, n):
+            return memoryview((C.c_uint8 * n).from_address(ptr)).cast("B") if n else memoryview(b"")
+
+        def _ag(_user, send, recv, nbytes):
+            try:
+                all_gather(view(send, nbytes), view(recv, nbytes * world))
+                return 0
+            except BaseException as e:                       # noqa: BLE001 - must not unwind through C
+                err.append(e)
+                return 1
+
+        def _ex(_user, ns, sends, nr, recvs):
+            try:
+                exchange([(view(sends[i].ptr, sends[i].bytes), sends[i].peer) for i in range(ns)],
+                         [(view(recvs[i].ptr, recvs[i].bytes), recvs[i].peer) for i in range(nr)])
+                return 0
+            except BaseException as e:                       # noqa: BLE001
+                err.append(e)
+                return 1
+
+        err = []
+        t = L.CommHostTransport(None, L.HOST_ALL_GATHER(_ag), L.HOST_EXCHANGE(_ex))
+        h = C.c_void_p()
+        L.check(L.lib().bhip_comm_create_host(ctx._h, C.byref(t), world, rank, C.byref(h)))
+        comm = cls(ctx, b"", world, rank, _handle=h, _keep=(t, err))
+        return comm
+
+    def _check(self, status):
+        if self._keep and self._keep[1]:
+            e = self._keep[1].pop()
+            self._keep[1].clear()
+            raise e
+        L.check(status)
+
+    def info(self):
+        w, r, t = C.c_int32(), C.c_int32(), C.c_char_p()
+        L.check(L.lib().bhip_comm_info(self._h, C.byref(w), C.byref(r), C.byref(t)))
+        return dict(world=w.value, rank=r.value, transport=t.value.decode())
+
+    def stats(self, reset=False):
+        s, b, n = C.c_double(), C.c_uint64(), C.c_uint64()
+        L.check(L.lib().bhip_comm_stats(self._h, 1 if reset else 0, C.byref(s), C.byref(b), C.byref(n)))
+        return dict(seconds=s.value, bytes_out=b.value, calls=n.value)
 
     def all_gather(self, batch: "RecordBatch") -> List["RecordBatch"]:
         out = (C.c_void_p * self.world)()
-        L.check(L.lib().bhip_comm_all_gather(self._h, batch._h, out))
+        self._check(L.lib().bhip_comm_all_gather(self._h, batch._h, out))
         return [RecordBatch(C.c_void_p(out[i]), self.ctx) for i in range(self.world)]
 
     def all_to_all(self, parts: Sequence["RecordBatch"]) -> List["RecordBatch"]:
@@ -880,8 +939,20 @@ class Communicator:
             raise ValueError(f"need one outgoing batch per rank ({self.world}), got {len(parts)}")
         arr = (C.c_void_p * self.world)(*[p._h for p in parts])
         out = (C.c_void_p * self.world)()
-        L.check(L.lib().bhip_comm_all_to_all(self._h, arr, out))
+        self._check(L.lib().bhip_comm_all_to_all(self._h, arr, out))
         return [RecordBatch(C.c_void_p(out[i]), self.ctx) for i in range(self.world)]
+
+    def shuffle(self, batch: "RecordBatch", key: str, chunk_rows: int = 0, with_stats=False):
+        """bhip_comm_shuffle: my rows of every rank's batch under Hash([key], world), source-rank order"""
+        h = C.c_void_p()
+        st = L.ShuffleStats()
+        self._check(L.lib().bhip_comm_shuffle(self._h, batch._h, key.encode(), chunk_rows, C.byref(h), C.byref(st)))
+        out = RecordBatch(h, self.ctx)
+        if not with_stats:
+            return out
+        d = {k: getattr(st, k) for k, _ in L.ShuffleStats._fields_ if k != "rows_to"}
+        d["rows_to"] = [st.rows_to[i] for i in range(min(self.world, L.SHUFFLE_MAX_PEERS))]
+        return out, d
 
     def close(self):
         if getattr(self, "_h", None):
@@ -893,6 +964,29 @@ class Communicator:
             self.close()
         except Exception:
             pass
+
+
+class AllGatherExec(ExecutionPlan):
+    """bhip_plan_all_gather: the stage boundary of a partial aggregate inside one plan — executes every partition of `input`,
+    all_gathers the result over `comm`; `world` output partitions (partition r = rank r's batch), what the next stage's
+    MergeExec reads (rust/scheduler/src/planner.rs:136-171)."""
+
+    def __init__(self, input: ExecutionPlan, comm: Communicator):
+        h = C.c_void_p()
+        L.check(L.lib().bhip_plan_all_gather(comm._h, input._h, C.byref(h)))
+        super().__init__(h, input.ctx, [input])
+        self.input, self.comm = input, comm
+
+
+class ShuffleExchangeExec(ExecutionPlan):
+    """bhip_plan_shuffle: RepartitionExec(Hash([key], world)) (from_proto.rs:133-147) + the shuffle read of this rank's
+    partition (shuffle_reader.rs:77-99) as one node; one output partition."""
+
+    def __init__(self, input: ExecutionPlan, comm: Communicator, key: str, chunk_rows: int = 0):
+        h = C.c_void_p()
+        L.check(L.lib().bhip_plan_shuffle(comm._h, input._h, key.encode(), chunk_rows, C.byref(h)))
+        super().__init__(h, input.ctx, [input])
+        self.input, self.comm, self.key, self.chunk_rows = input, comm, key, chunk_rows
 
 
 def pack_batch(batch: "RecordBatch"):

@@ -56,6 +56,7 @@ def parse(argv=None):
     ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the extra weak-scaling measurement")
     ap.add_argument("--join-exchange", default="shuffle", choices=["shuffle", "broadcast"],
                     help="N > 1, q3 / q5: hash-partition both sides of the order-key join (config #5) or broadcast the build side")
+    ap.add_argument("--chunk-rows", type=int, default=0, help="N > 1, --join-exchange shuffle: rows per chunk of the streaming shuffle (0 = the library's default, 64 Mi)")
     ap.add_argument("--configs", default="q6,q3,q5", help="N = 1 and --query q1 (the default run): further queries measured after Q1 and "
                     "reported under \"configs\" (\"\" = none)")
     ap.add_argument("--config-steps", type=int, default=10, help="timed steps of each query under --configs")
@@ -196,7 +197,7 @@ def measure(query, args, ctx, group, world, rank, n, cpu_rows, cpu_budget_s, ste
     from ballista_amd import distributed as D
 
     key_bytes = 8 if args.key64 else 4
-    W = D.Workload(query, ctx, group, sf=args.sf, rows=n, key64=args.key64, join_exchange=args.join_exchange)
+    W = D.Workload(query, ctx, group, sf=args.sf, rows=n, key64=args.key64, join_exchange=args.join_exchange, chunk_rows=args.chunk_rows)
 
     def barrier():
         ctx.synchronize()
@@ -235,7 +236,9 @@ def measure(query, args, ctx, group, world, rank, n, cpu_rows, cpu_budget_s, ste
     host = W.host_overhead(reset=True)
 
     weak = None
-    if world > 1 and not args.no_weak:
+    # weak scaling (every rank its own full-size block) is defined for the scans only: a join's row blocks of different ranks must
+    # come from ONE pair of tables for their keys to meet
+    if world > 1 and not args.no_weak and query in ("q1", "q6"):
         W.load(mode="weak")
         w_steps = max(3, steps // 4)
         w_elapsed, _, _ = timed(W.step, w_steps, 1)

@@ -69,7 +69,32 @@ def execute(plan, partition):
         for p in range(n_partitions(plan.input)):
             allb.extend(execute(plan.input, p))
         return [b for i, b in enumerate(allb) if i % part.count == partition]
+    if k in ("AllGatherExec", "ShuffleExchangeExec"):
+        # the stage boundary between ranks (ballista_amd/csrc/host/exchange.cpp): every partition of the input as one batch goes
+        # through plan.comm ONCE per node (a collective call), whichever output partition is asked for first
+        if "_exchanged" not in plan.__dict__:
+            mine = _whole_input(plan.input)
+            plan._exchanged = plan.comm.all_gather(mine) if k == "AllGatherExec" else [plan.comm.shuffle(mine, plan.key)]
+        return [plan._exchanged[partition]]
     raise NotImplementedError(k)
+
+
+def _whole_input(plan):
+    """every partition of `plan` as ONE batch (an empty one with the plan's schema when there is no row at all)"""
+    import numpy as np
+    out = []
+    for p in range(n_partitions(plan)):
+        out.extend(b for b in execute(plan, p))
+    live = [b for b in out if og.batch_len(b)]
+    if live:
+        return og.concat_batches(live)
+    if out:
+        return out[0]
+    empty = OrderedDict()
+    for name, dtype, _ in plan.schema():
+        np_t = {"Float64": np.float64, "Int64": np.int64, "UInt64": np.uint64, "UInt8": np.uint8, "Boolean": np.bool_}.get(dtype, np.int32)
+        empty[name] = og.OCol(dtype, [] if dtype == "Utf8" else np.zeros(0, np_t))
+    return empty
 
 
 def n_partitions(plan):
@@ -80,6 +105,10 @@ def n_partitions(plan):
         return 1
     if k == "RepartitionExec":
         return plan.partitioning.count
+    if k == "AllGatherExec":
+        return plan.comm.world
+    if k == "ShuffleExchangeExec":
+        return 1
     if k == "HashJoinExec":
         return n_partitions(plan.right)
     return n_partitions(plan.input)

@@ -179,3 +179,24 @@ class RepartitionExec(_Node):
 
     def schema(self):
         return self.input.schema()
+
+
+class AllGatherExec(_Node):
+    """ballista_amd.plan.AllGatherExec: `comm.world` output partitions, partition r = rank r's (concatenated) input.
+    comm: an object with world / rank / all_gather(batch) -> [batch] (tests/test_distributed_cpu.py: OracleComm over gloo)"""
+
+    def __init__(self, input, comm):
+        self.input, self.comm = input, comm
+
+    def schema(self):
+        return self.input.schema()
+
+
+class ShuffleExchangeExec(_Node):
+    """ballista_amd.plan.ShuffleExchangeExec: this rank's partition of Hash([key], world) over every rank's input"""
+
+    def __init__(self, input, comm, key, chunk_rows=0):
+        self.input, self.comm, self.key, self.chunk_rows = input, comm, key, chunk_rows
+
+    def schema(self):
+        return self.input.schema()

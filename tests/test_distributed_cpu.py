@@ -1,6 +1,7 @@
-"""The N > 1 flows of ballista_amd/distributed.py on CPU: two gloo ranks, each owning one row block of the seeded tables, run
-EXACTLY the functions `bench.py --gpus N` runs (q1_distributed / q3_distributed / q5_distributed over GlooGroup) with the ORACLE
-as the engine — there is no GPU in this tier.  Under test: row-block sharding, hash routing, source-rank order, the
+"""The N > 1 plans of ballista_amd/distributed.py on CPU: two gloo ranks, each owning one row block of the seeded tables, build
+EXACTLY the per-rank plan `bench.py --gpus N` builds (distributed.rank_plan: the query with AllGatherExec / ShuffleExchangeExec at
+its stage boundaries) and evaluate it with the ORACLE (oracle/plan_eval.py; the exchange nodes call an OracleComm over gloo) —
+there is no GPU in this tier.  Under test: row-block sharding, hash routing, source-rank order, the
 shuffle-vs-broadcast variants, framing of the batches on the wire, and the property the strong-scaling bench relies on:
     answer(2 ranks) == answer(1 rank)      (reference: stage 1 Partial -> exchange -> Final, rust/scheduler/src/planner.rs:136-171;
                                             RepartitionExec(Hash), rust/core/src/serde/physical_plan/from_proto.rs:133-147)."""
@@ -61,45 +62,18 @@ def from_arrow(rb):
     return out
 
 
-class OracleEngine:
-    """the Engine interface of ballista_amd/distributed.py over oracle/ (plans are tests/plan_nodes.py trees)"""
+class OracleComm:
+    """the exchange handle of the plan nodes (tests/plan_nodes.py AllGatherExec / ShuffleExchangeExec, evaluated by
+    oracle/plan_eval.py) over torch.distributed gloo: oracle batches travel as Arrow IPC stream bytes.  `world` / `rank` /
+    all_gather(batch) / shuffle(batch, key) — the surface of ballista_amd.plan.Communicator the plan builders rely on."""
 
-    def leaf(self, partitions):
-        import plan_nodes as N
-        if not isinstance(partitions, (list, tuple)):
-            partitions = [partitions]
-        return N.MemoryExec([[b] for b in partitions])
+    def __init__(self, dist):
+        self.dist = dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.calls = 0
 
-    def run(self, plan):
-        from oracle import plan_eval, engine as og
-        from oracle.engine import OCol
-        got = plan_eval.collect(plan)
-        if got:
-            return got
-        out = OrderedDict()                       # no batch at all: an empty one with the plan's schema
-        for name, dtype, _ in plan.schema():
-            out[name] = OCol(dtype, [] if dtype == "Utf8" else np.zeros(0, {"Float64": np.float64, "Int64": np.int64, "UInt64": np.uint64}.get(dtype, np.int32)))
-        return out
-
-    def hash_partition(self, batch, key, n):
-        from oracle import engine as og
-        from ballista_amd.expr import col
-        return og.repartition_hash(batch, [col(key)], n)
-
-    def concat(self, batches):
-        from oracle import engine as og
-        live = [b for b in batches if og.batch_len(b)]
-        return og.concat_batches(live) if live else batches[0]
-
-    def num_rows(self, batch):
-        from oracle import engine as og
-        return og.batch_len(batch)
-
-    def nbytes(self, batch):
-        return 0
-
-    def to_wire(self, batch):
-        """Arrow IPC stream bytes of the batch"""
+    @staticmethod
+    def to_wire(batch):
         import pyarrow as pa
         rb = to_arrow(batch)
         sink = pa.BufferOutputStream()
@@ -107,11 +81,65 @@ class OracleEngine:
             w.write_batch(rb)
         return np.frombuffer(sink.getvalue(), dtype=np.uint8)
 
-    def from_wire(self, raw, like):
+    @staticmethod
+    def from_wire(raw, like):
         import pyarrow as pa
         t = pa.ipc.open_stream(pa.py_buffer(np.ascontiguousarray(raw).tobytes())).read_all()
         b = t.combine_chunks().to_batches()
         return from_arrow(b[0]) if b else OrderedDict((k, c.take(np.zeros(0, np.int64))) for k, c in like.items())
+
+    def all_gather(self, batch):
+        """every rank's batch, in rank order (the order MergeExec concatenates partitions in)"""
+        import torch
+        self.calls += 1
+        raw = self.to_wire(batch)
+        size = torch.tensor([raw.size], dtype=torch.int64)
+        sizes = [torch.empty_like(size) for _ in range(self.world)]
+        self.dist.all_gather(sizes, size)
+        sizes = [int(s.item()) for s in sizes]
+        cap = max(sizes)
+        buf = torch.zeros(cap, dtype=torch.uint8)
+        buf[:raw.size] = torch.from_numpy(raw.copy())
+        out = torch.empty(self.world * cap, dtype=torch.uint8)
+        self.dist.all_gather_into_tensor(out, buf)
+        host = out.numpy().reshape(self.world, cap)
+        return [batch if r == self.rank else self.from_wire(host[r, :sizes[r]], batch) for r in range(self.world)]
+
+    def all_to_all(self, parts):
+        """parts[d] goes to rank d; returns what every rank holds for me, in source-rank order"""
+        import torch
+        assert len(parts) == self.world
+        payload = [self.to_wire(p) for p in parts]
+        sizes = torch.tensor([p.size for p in payload], dtype=torch.int64)
+        all_sizes = [torch.empty_like(sizes) for _ in range(self.world)]
+        self.dist.all_gather(all_sizes, sizes)
+        incoming = [int(all_sizes[src][self.rank].item()) for src in range(self.world)]
+        send = [torch.from_numpy(payload[d].copy()) for d in range(self.world)]
+        recv = [torch.empty(incoming[s], dtype=torch.uint8) for s in range(self.world)]
+        ops = []
+        for peer in range(self.world):
+            if peer == self.rank:
+                continue
+            ops.append(self.dist.P2POp(self.dist.isend, send[peer], peer))
+            ops.append(self.dist.P2POp(self.dist.irecv, recv[peer], peer))
+        if ops:
+            for req in self.dist.batch_isend_irecv(ops):
+                req.wait()
+        return [parts[s] if s == self.rank else self.from_wire(recv[s].numpy(), parts[s]) for s in range(self.world)]
+
+    def shuffle(self, batch, key):
+        """RepartitionExec(Hash([key], world)) + the shuffle read: my rows of every rank's batch, source-rank order"""
+        from oracle import engine as og
+        from ballista_amd.expr import col
+        self.calls += 1
+        got = self.all_to_all(og.repartition_hash(batch, [col(key)], self.world))
+        live = [b for b in got if og.batch_len(b)]
+        return og.concat_batches(live) if live else got[0]
+
+
+def leaf(batch):
+    import plan_nodes as N
+    return N.MemoryExec([[batch]])
 
 
 def _tables(rank, world):
@@ -140,37 +168,34 @@ def _rank_main(rank, world, port, query, join_exchange, q):
     try:
         import plan_nodes as N
         import helpers
+        import torch.distributed as dist
+        from oracle import plan_eval, engine as og
         from ballista_amd import tpch, distributed as D
         tpch.P = N                                       # the plan builders over GPU-free plan descriptions
-        group = D.ProcessGroup.from_env("gloo")
-        assert (group.rank, group.world) == (rank, world)
-        eng = OracleEngine()
+        dist.init_process_group("gloo")
+        comm = OracleComm(dist)
+        assert (comm.rank, comm.world) == (rank, world)
         full, mine = _tables(rank, world)
-        L = lambda t, k: eng.leaf(t[k])
-        stats = D.ExchangeStats()
 
-        def run(g, t):
-            stats_ = stats if g is group else None
-            if query in ("q1", "q6"):
-                return D.q1_distributed(eng, g, L(t, "lineitem"), query)
-            if query == "q3":
-                return D.q3_distributed(eng, g, L(t, "customer"), L(t, "orders"), L(t, "lineitem"), join_exchange, stats_)
-            return D.q5_distributed(eng, g, L(t, "customer"), L(t, "orders"), L(t, "lineitem"), L(t, "supplier"), L(t, "nation"), L(t, "region"),
-                                    join_exchange, stats_)
+        def run(c, t):
+            # EXACTLY the plan bench.py's Workload builds for this rank (distributed.rank_plan), evaluated by the oracle
+            return plan_eval.collect(D.rank_plan(query, c, {k: leaf(b) for k, b in t.items()}, join_exchange))
 
-        got = run(group, mine)
-        want = run(D.ProcessGroup.single(), full)        # the same flow on one rank over the whole tables
+        got = run(comm, mine)
+        want = run(None, full)                           # the same builders on one rank over the whole tables: no exchange nodes
         key = {"q1": ["l_returnflag", "l_linestatus"], "q6": None, "q3": ["l_orderkey"], "q5": ["n_name"]}[query]
         helpers.assert_rows_equal(got, want, ordered=False, float_rtol=1e-9, key_cols=key)
-        assert eng.num_rows(got) > 0
+        assert og.batch_len(got) > 0
         if query in ("q3", "q5"):
-            assert stats.calls == (1 if join_exchange == "broadcast" else 2)
+            # exchange nodes executed: the partial-state all_gather + (build-side all_gather | two shuffles)
+            assert comm.calls == (2 if join_exchange == "broadcast" else 3), comm.calls
             # ORDER BY survives the distribution (every rank sorts the gathered states itself)
             rev = got["revenue"].to_pylist()
             assert all(a >= b for a, b in zip(rev, rev[1:]))
-        group.barrier()
-        assert group.max_over_ranks(float(rank)) == float(world - 1)
-        group.close()
+        else:
+            assert comm.calls == 1
+        dist.barrier()
+        dist.destroy_process_group()
         q.put((rank, "ok"))
     except BaseException as e:          # noqa: BLE001 - reported to the parent
         import traceback
@@ -200,15 +225,17 @@ def test_two_rank_flows_equal_one_rank_gloo(query, join_exchange):
 
 
 def _routing_main(rank, world, port, _a, _b, q):
-    """GlooGroup.all_to_all / all_gather: who gets what, in which order, empty parts included"""
+    """OracleComm.all_to_all / all_gather / shuffle: who gets what, in which order, empty parts included"""
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     try:
+        import torch.distributed as dist
+        from oracle import engine as og
         from oracle.engine import OCol
-        from ballista_amd import distributed as D
-        group = D.ProcessGroup.from_env("gloo")
-        eng = OracleEngine()
+        from ballista_amd.expr import col
+        dist.init_process_group("gloo")
+        comm = OracleComm(dist)
 
         def batch(src, dst, n):
             return OrderedDict([("src", OCol("Int32", np.full(n, src, np.int32))), ("dst", OCol("Int32", np.full(n, dst, np.int32))),
@@ -217,17 +244,22 @@ def _routing_main(rank, world, port, _a, _b, q):
 
         sizes = lambda s, d: 0 if (s + d) % 3 == 0 else 5 + 7 * s + 3 * d      # some parts are empty
         parts = [batch(rank, d, sizes(rank, d)) for d in range(world)]
-        got = group.all_to_all(eng, parts)
+        got = comm.all_to_all(parts)
         assert len(got) == world
         for s, b in enumerate(got):                                               # source-rank order, payload intact
             want = batch(s, rank, sizes(s, rank))
-            assert eng.num_rows(b) == sizes(s, rank)
+            assert og.batch_len(b) == sizes(s, rank)
             assert b["s"].to_pylist() == want["s"].to_pylist() and list(b["x"].values) == list(want["x"].values)
             assert all(v == s for v in b["src"].values) and all(v == rank for v in b["dst"].values)
-        gathered = group.all_gather(eng, batch(rank, -1, 3 + rank))
-        assert [eng.num_rows(b) for b in gathered] == [3 + r for r in range(world)]
+        gathered = comm.all_gather(batch(rank, -1, 3 + rank))
+        assert [og.batch_len(b) for b in gathered] == [3 + r for r in range(world)]
         assert all(all(v == r for v in b["src"].values) for r, b in enumerate(gathered))
-        group.close()
+        # shuffle = every rank's rows whose key hashes to me, source-rank order, input order inside a source
+        mk = lambda r: OrderedDict([("k", OCol("Int64", np.arange(100 * r, 100 * r + 40 + r, dtype=np.int64) * 7919)), ("src", OCol("Int32", np.full(40 + r, r, np.int32)))])
+        mine = comm.shuffle(mk(rank), "k")
+        want = og.concat_batches([og.repartition_hash(mk(r), [col("k")], world)[rank] for r in range(world)])
+        assert list(mine["k"].values) == list(want["k"].values) and list(mine["src"].values) == list(want["src"].values)
+        dist.destroy_process_group()
         q.put((rank, "ok"))
     except BaseException as e:          # noqa: BLE001
         import traceback

@@ -210,6 +210,29 @@ def test_malformed_and_unsupported_plans_are_errors_not_crashes(nodes_tpch):
     assert ba.ExecutionPlan.from_proto(None, ok).as_any() == "FilterExec"
 
 
+def test_deeply_nested_messages_are_refused_not_recursed_into():
+    """a NOT inside a NOT inside ... 10 000 deep, and 5 000 nested LocalLimit nodes: the decoder refuses at 128 levels
+    instead of walking the C++ stack down with the message"""
+    import ctypes as C
+    from ballista_amd import _lib as L
+    e = pe.expr(col("x"))
+    for _ in range(10_000):
+        e = pe.f_bytes(8, pe.f_bytes(1, e))                      # LogicalExprNode.not_expr = 8 { expr = 1 } (ballista.proto:34)
+    buf = C.create_string_buffer(256)
+    assert L.lib().bhip_expr_from_proto_display(e, len(e), buf, len(buf)) == L.EINVAL
+    assert b"nested deeper" in L.lib().bhip_last_error()
+    p = pe.plan(leaf("t", gen.orders(0.001)))
+    for _ in range(5_000):
+        p = pe.f_bytes(7, pe.f_bytes(1, p) + pe.f_varint(2, 3))   # LocalLimitExecNode { input, limit }
+    with pytest.raises(ba.PlanError, match="nested deeper"):
+        ba.ExecutionPlan.from_proto(None, p)
+    # 100 levels are fine
+    p = pe.plan(leaf("t", gen.orders(0.001)))
+    for _ in range(100):
+        p = pe.f_bytes(7, pe.f_bytes(1, p) + pe.f_varint(2, 3))
+    assert ba.ExecutionPlan.from_proto(None, p).as_any() == "LocalLimitExec"
+
+
 def pe_fn(fun, *args):
     e = object.__new__(E.ScalarFunctionExpr)          # bypass the host mirror's "supported functions" check: the wire can carry any
     e.fun, e.args = fun, list(args)
