@@ -262,6 +262,15 @@ join_filter_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const voi
             for (int j = 0; j < NF; ++j) r.f[j][k] = F.col[j < F.n ? j : 0][rc];
         }
     };
+    uint32_t flo[NFR], fspan[NFR];
+    uint32_t alive = 1u;
+#pragma unroll
+    for (int j = 0; j < NFR; ++j) {
+        const bool have = j < NF && j < F.n;
+        flo[j] = have ? (uint32_t)F.lo[j] : 0u;
+        fspan[j] = have ? (uint32_t)F.hi[j] - (uint32_t)F.lo[j] : 0xFFFFFFFFu;
+        if (have && F.hi[j] < F.lo[j]) alive = 0u;
+    }
     Regs cur, nxt;
     if (wave_id < n_tiles) load(wave_id * SEL_TILE, cur);
     for (uint32_t t = wave_id; t < n_tiles; t += n_waves) {
@@ -285,10 +294,10 @@ join_filter_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const voi
 #pragma unroll
             for (int k = 0; k < FP_ROWS; ++k) {
                 const uint32_t row = base + 64u * k + lane;
-                bool p = row < n_right;
+                uint32_t ok = (uint32_t)(row < n_right) & alive;                        // branch-free: see join_rank_probe_kernel
 #pragma unroll
-                for (int j = 0; j < NF; ++j)
-                    if (j < F.n) p = p && cur.f[j][k] >= F.lo[j] && cur.f[j][k] <= F.hi[j];
+                for (int j = 0; j < NF; ++j) ok &= (uint32_t)(((uint32_t)cur.f[j][k] - flo[j]) <= fspan[j]);
+                const bool p = ok != 0u;
                 pass[k] = p;
                 m[k] = 0xFFFFFFFFu;
                 live[k] = p;
@@ -384,7 +393,10 @@ join_filter_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const voi
 // wave's cycles waiting on memory), so everything wave-uniform is kept scalar: the wave's tile index goes through readfirstlane,
 // interior tiles (all but a batch's last) run a variant without row-bound tests and address clamps, the streamed loads and the
 // staging stores address `scalar base + lane offset`.
-template <int KW, int NF, int FP_ROWS, bool RESID, bool PERM>
+// MAPBUF: the packed map is shorter than 2 GiB (windows up to 2^33 key values: every join of TPC-H up to SF1000 with dense keys,
+// SF300 with dbgen's sparse ones): it is read through a buffer descriptor too, and the descriptor's range check IS the window
+// test and the "dropped rows read zeros" rule — an offset past the map's last granule returns 0 without touching memory.
+template <int KW, int NF, int FP_ROWS, bool RESID, bool PERM, bool MAPBUF>
 __global__ void __launch_bounds__(BLOCK)
 join_rank_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void* __restrict__ rkeys_v, uint32_t n_right,
                        uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts, uint32_t* __restrict__ staging,
@@ -399,37 +411,64 @@ join_rank_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void*
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t n_tiles = (uint32_t)(((uint64_t)n_right + SEL_TILE - 1) / SEL_TILE);
     const uint32_t full_tiles = n_right / SEL_TILE;                  // tiles before this one hold SEL_TILE rows each
-    const uint32_t last_row = n_right - 1;
     const uint32_t wave_id = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)));
     const uint32_t n_waves = gridDim.x * (BLOCK / 64);
     const uint64_t* __restrict__ rpack = T.rpack;
     const bool staged = staging != nullptr;            // (staging and staging_rows come together: host/ops_join.cpp process_fused)
 
     struct Regs { K key[FP_ROWS]; int32_t f[NFR][FP_ROWS]; uint32_t g[RESID ? FP_ROWS : 1]; };
-    // rows [base, base + FP_CHUNK) of the streamed columns; EDGE: the chunk may reach past the last row (index clamped)
-    auto load = [&](uint32_t base, Regs& r, auto edge) {
-        constexpr bool EDGE = decltype(edge)::value;
-#pragma unroll
-        for (int k = 0; k < FP_ROWS; ++k) {
-            if (EDGE) {
-                const uint32_t row = base + 64u * k + lane;
-                const uint32_t rc = row < last_row ? row : last_row;
-                r.key[k] = rkeys[rc];
-                if (RESID) r.g[RESID ? k : 0] = resid_probe[rc];
-#pragma unroll
-                for (int j = 0; j < NF; ++j) r.f[j][k] = F.col[j < F.n ? j : 0][rc];
-            } else {
-                r.key[k] = (rkeys + base)[64u * k + lane];
-                if (RESID) r.g[RESID ? k : 0] = (resid_probe + base)[64u * k + lane];
-#pragma unroll
-                for (int j = 0; j < NF; ++j) r.f[j][k] = (F.col[j < F.n ? j : 0] + base)[64u * k + lane];
-            }
-        }
+    // rows [base, base + FP_CHUNK) of the streamed columns, as BUFFER loads: a 128-bit descriptor over [column + base, end of the
+    // column) built from wave-uniform values (scalar instructions), the lane's byte offset in one VGPR shared by every load, the
+    // row slot's 256 / 512-byte step in the instruction's immediate offset — no vector instruction computes an address (the flat
+    // loads here cost one v_lshl_add_u64 each: 16-24 per pass of a kernel bound by vector issue), and the hardware's range check
+    // returns 0 for rows past the end of the column, so the last tile needs no index clamping (the row < n test stays a predicate).
+    // A descriptor holds a 32-bit byte count: it is rebuilt per pass from the pass's first row, so columns beyond 4 GiB
+    // (Int64 keys of an SF100+ lineitem) need nothing special.
+    const uint32_t lane_b4 = lane * 4u, lane_bk = lane * (uint32_t)KW;
+    auto rsrc_of = [&](const void* col, uint32_t base, uint32_t width) {
+        const uint64_t remain = base < n_right ? (uint64_t)(n_right - base) * width : 0;   // (a prefetch may start past the last row: zero records, every lane reads 0)
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(static_cast<const uint8_t*>(col)) + (uint64_t)base * width, 0,
+                                                 (int)(remain > 0x7FFFFFFFull ? 0x7FFFFFFFull : remain), 0x00020000);
     };
     auto load_any = [&](uint32_t base, Regs& r) {
-        if (base / SEL_TILE < full_tiles) load(base, r, std::false_type{});       // wave-uniform
-        else load(base, r, std::true_type{});
+        const auto rk = rsrc_of(rkeys_v, base, KW);
+#pragma unroll
+        for (int k = 0; k < FP_ROWS; ++k) {
+            if constexpr (KW == 4) r.key[k] = (K)__builtin_amdgcn_raw_buffer_load_b32(rk, (int)(lane_bk + 256u * k), 0, 0);
+            else {
+                typedef unsigned int v2u_t __attribute__((ext_vector_type(2)));
+                const v2u_t v = __builtin_amdgcn_raw_buffer_load_b64(rk, (int)(lane_bk + 512u * k), 0, 0);
+                r.key[k] = (K)(((uint64_t)v.y << 32) | v.x);
+            }
+        }
+        if (RESID) {
+            const auto rg = rsrc_of(resid_probe, base, 4);
+#pragma unroll
+            for (int k = 0; k < FP_ROWS; ++k) r.g[RESID ? k : 0] = __builtin_amdgcn_raw_buffer_load_b32(rg, (int)(lane_b4 + 256u * k), 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const auto rf = rsrc_of(F.col[j < F.n ? j : 0], base, 4);
+#pragma unroll
+            for (int k = 0; k < FP_ROWS; ++k) r.f[j][k] = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rf, (int)(lane_b4 + 256u * k), 0, 0);
+        }
     };
+    // The range predicates, branch-free: lo <= f <= hi  <=>  (uint32)(f - lo) <= (uint32)(hi - lo) — one subtraction and one compare
+    // per column, and the conditions of a row are combined with `&` on their lane masks.  (Written as `p = p && f >= lo && f <= hi`
+    // hipcc lowered every `&&` to an exec-mask branch — s_and_saveexec / s_xor / s_or around each compare: ~20 scalar and vector
+    // instructions per row slot and column, half of this kernel's issue slots, in a kernel that is bound by instruction issue.)
+    // A column the plan does not have gets the full span: every value passes.  An empty range (lo > hi) kills every row.
+    uint32_t flo[NFR], fspan[NFR];
+    uint32_t alive = 1u;
+#pragma unroll
+    for (int j = 0; j < NFR; ++j) {
+        const bool have = j < NF && j < F.n;
+        flo[j] = have ? (uint32_t)F.lo[j] : 0u;
+        fspan[j] = have ? (uint32_t)F.hi[j] - (uint32_t)F.lo[j] : 0xFFFFFFFFu;
+        if (have && F.hi[j] < F.lo[j]) alive = 0u;
+    }
+    // granules [0, rzero) of the map (the host only picks MAPBUF when rzero * 8 < 2^31)
+    const auto rmap = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(rpack), 0, MAPBUF ? (int)(T.rzero * 8u) : 0, 0x00020000);
     Regs cur, nxt;
     if (wave_id < n_tiles) load_any(wave_id * SEL_TILE, cur);
     for (uint32_t t = wave_id; t < n_tiles; t += n_waves) {
@@ -452,29 +491,41 @@ join_rank_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void*
                 __builtin_amdgcn_sched_barrier(0);
             };
             bool live[FP_ROWS];
-            uint32_t d[FP_ROWS], m[FP_ROWS];
+            uint32_t d[FP_ROWS], m[FP_ROWS], lv[FP_ROWS];
             uint64_t pk[FP_ROWS];
 #pragma unroll
             for (int k = 0; k < FP_ROWS; ++k) {
-                bool p = EDGE ? (base + 64u * k + lane) < n_right : true;
+                uint32_t ok = EDGE ? (uint32_t)((base + 64u * k + lane) < n_right) & alive : alive;
 #pragma unroll
-                for (int j = 0; j < NF; ++j)
-                    if (j < F.n) p = p && cur.f[j][k] >= F.lo[j] && cur.f[j][k] <= F.hi[j];
+                for (int j = 0; j < NF; ++j) ok &= (uint32_t)(((uint32_t)cur.f[j][k] - flo[j]) <= fspan[j]);
                 const uint64_t off = key_offset<KW>(cur.key[k], T.kmin64);
-                // granule index and bit inside it (the window holds <= 2^36 values: < 2^31 granules; 4-byte keys stay in 32-bit arithmetic)
-                const uint32_t g = KW == 4 ? ((uint32_t)off >> 5) : (uint32_t)(off >> 5);
-                d[k] = (uint32_t)off & 31u;
-                // a row the filter dropped, or whose key lies outside the window, reads the all-zero granule behind the map: the
-                // bit test below is then the whole decision — ONE compare, whose lane mask is the ballot (a ballot of an AND of
-                // conditions costs two more vector instructions per row slot)
-                pk[k] = rpack[(p && in_window<KW>(off, T.krange64)) ? g : T.rzero];
+                d[k] = (uint32_t)off;                                                     // (the bit-field extract below reads its low five bits)
+                // a row the filter dropped, or whose key lies outside the window, reads an all-zero granule: the bit test below is
+                // then the whole decision — ONE compare, whose lane mask is the ballot (a ballot of an AND of conditions costs two
+                // more vector instructions per row slot)
+                if constexpr (MAPBUF) {
+                    // byte offset of the granule's word = (off >> 5) * 8; 8-byte keys: offsets beyond 2^32 must not wrap into the map
+                    if (KW == 8) ok &= (uint32_t)((off >> 32) == 0);
+                    const uint32_t voff = ((uint32_t)off >> 2) & ~7u;
+                    typedef unsigned int v2u_t __attribute__((ext_vector_type(2)));
+                    const v2u_t w = __builtin_amdgcn_raw_buffer_load_b64(rmap, (int)(ok ? voff : 0xFFFFFFF8u), 0, 0);
+                    pk[k] = ((uint64_t)w.y << 32) | w.x;
+                } else {
+                    ok &= (uint32_t)in_window<KW>(off, T.krange64);
+                    // granule index (the window holds <= 2^36 values: < 2^31 granules; 4-byte keys stay in 32-bit arithmetic)
+                    const uint32_t g = KW == 4 ? ((uint32_t)off >> 5) : (uint32_t)(off >> 5);
+                    pk[k] = rpack[ok ? g : T.rzero];
+                }
             }
             if (!PERM && !RESID) prefetch();
 #pragma unroll
             for (int k = 0; k < FP_ROWS; ++k) {
-                const uint32_t bits = (uint32_t)pk[k], sh = d[k];
-                live[k] = ((bits >> sh) & 1u) != 0u;
-                m[k] = (uint32_t)(pk[k] >> 32) + (uint32_t)__popc(bits & ((1u << sh) - 1u));
+                const uint32_t bits = (uint32_t)pk[k];
+                lv[k] = __builtin_amdgcn_ubfe(bits, d[k], 1u);    // v_bfe_u32: bit (d & 31) of the key set
+                live[k] = lv[k] != 0u;
+                // the rank: needed at once where another dependent read goes by it (unsorted build side, second key column); else
+                // only by the row slots in which some lane emits (Q3's lineitem probe: 0.5 % of the rows) — computed there
+                if (PERM || RESID) m[k] = (uint32_t)(pk[k] >> 32) + (uint32_t)__popc(__builtin_amdgcn_ubfe(bits, 0u, d[k] & 31u));
             }
             if (PERM) {
 #pragma unroll
@@ -495,11 +546,17 @@ join_rank_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void*
                 const bool emit = live[k];                                                // (inner join: a right join takes the general kernel)
                 const uint64_t wd = __builtin_amdgcn_ballot_w64(emit);
                 my_word = lane == (uint32_t)k ? wd : my_word;
-                if (staged) {                                                             // wave-uniform
+                if (staged && wd != 0ull) {                                               // wave-uniform: a slot without a match costs one scalar test
                     if (emit) {
+                        uint32_t mk;
+                        if (PERM || RESID) mk = m[k];
+                        else {
+                            const uint32_t bits = (uint32_t)pk[k];
+                            mk = (uint32_t)(pk[k] >> 32) + (uint32_t)__popc(__builtin_amdgcn_ubfe(bits, 0u, d[k] & 31u));     // set bits below the key's
+                        }
                         // tile_cnt + (emitting lanes below this one): two mbcnt instructions, the count riding along as their addend
                         const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(wd >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wd, tile_cnt)) & (SEL_TILE - 1);
-                        st_m[at] = m[k];
+                        st_m[at] = mk;
                         st_r[at] = base + 64u * k + lane;
                     }
                 }
@@ -641,17 +698,23 @@ hipError_t launch_join_filter_probe(const LaunchCfg& cfg, const NarrowJoinTable&
     static const int probe_rows = [] { const char* v = getenv("BHIP_PROBE_ROWS"); return v ? atoi(v) : 8; }();      // 8 rows per lane and pass (4-byte keys): profiles/r02_probe_variants_q3_sf100.txt
     // the rank map without NULL probe keys and without a left join: the one-read kernel
     const bool direct = T.rpack != nullptr && rsel == nullptr && matched == nullptr && !right_outer && (staging != nullptr) == (staging_rows != nullptr);
+    // the packed map through a buffer descriptor when its granules fit one (BHIP_PROBE_MAP_FLAT=1: the flat-load variant, the A/B partner)
+    static const bool map_flat = [] { const char* v = getenv("BHIP_PROBE_MAP_FLAT"); return v && atoi(v) != 0; }();
+    const bool map_buf = !map_flat && T.rpack != nullptr && (uint64_t)T.rzero * 8u < 0x7FFFFFF0ull;
+#define BHIP_PROBE_R(KW_, NF_, ROWS_, RESID_, PERM_)                                                                                  \
+    do {                                                                                                                              \
+        if (map_buf)                                                                                                                  \
+            hipLaunchKernelGGL((join_rank_probe_kernel<KW_, NF_, ROWS_, RESID_, PERM_, true>), dim3((unsigned)grid), dim3(BLOCK), 0, cfg.stream, T, F, \
+                               rkeys, n_right, bitmap, tile_counts, staging, resid_probe, staging_rows);                              \
+        else                                                                                                                          \
+            hipLaunchKernelGGL((join_rank_probe_kernel<KW_, NF_, ROWS_, RESID_, PERM_, false>), dim3((unsigned)grid), dim3(BLOCK), 0, cfg.stream, T, F, \
+                               rkeys, n_right, bitmap, tile_counts, staging, resid_probe, staging_rows);                              \
+    } while (0)
 #define BHIP_PROBE_L(KW_, NF_, RESID_)                                                                                                \
     do {                                                                                                                              \
-        if (direct && T.rperm)                                                                                                        \
-            hipLaunchKernelGGL((join_rank_probe_kernel<KW_, NF_, 4, RESID_, true>), dim3((unsigned)grid), dim3(BLOCK), 0, cfg.stream, T, F, rkeys,  \
-                               n_right, bitmap, tile_counts, staging, resid_probe, staging_rows);                \
-        else if (direct && probe_rows == 8 && KW_ == 4)                                                                               \
-            hipLaunchKernelGGL((join_rank_probe_kernel<4, NF_, 8, RESID_, false>), dim3((unsigned)grid), dim3(BLOCK), 0, cfg.stream, T, F, rkeys, \
-                               n_right, bitmap, tile_counts, staging, resid_probe, staging_rows);                \
-        else if (direct)                                                                                                              \
-            hipLaunchKernelGGL((join_rank_probe_kernel<KW_, NF_, 4, RESID_, false>), dim3((unsigned)grid), dim3(BLOCK), 0, cfg.stream, T, F, rkeys, \
-                               n_right, bitmap, tile_counts, staging, resid_probe, staging_rows);                \
+        if (direct && T.rperm) BHIP_PROBE_R(KW_, NF_, 4, RESID_, true);                                                               \
+        else if (direct && probe_rows == 8 && KW_ == 4) BHIP_PROBE_R(4, NF_, 8, RESID_, false);                                       \
+        else if (direct) BHIP_PROBE_R(KW_, NF_, 4, RESID_, false);                                                                    \
         else                                                                                                                          \
             hipLaunchKernelGGL((join_filter_probe_kernel<KW_, NF_, 4, RESID_>), dim3((unsigned)grid), dim3(BLOCK), 0, cfg.stream, T, F, rkeys, \
                                rsel, n_right, right_outer ? 1 : 0, bitmap, tile_counts, staging, matched, resid_probe, staging_rows); \
@@ -672,6 +735,7 @@ hipError_t launch_join_filter_probe(const LaunchCfg& cfg, const NarrowJoinTable&
     }
 #undef BHIP_PROBE
 #undef BHIP_PROBE_L
+#undef BHIP_PROBE_R
     return hipGetLastError();
 }
 

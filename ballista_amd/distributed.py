@@ -338,7 +338,7 @@ class Workload:
             self.local["orders"] = n
             od_cols = ["o_orderkey", "o_custkey", "o_orderdate"] + (["o_shippriority"] if self.query == "q3" else [])
             self.t["orders"] = self._leaf(P.tpch_orders(ctx, self.sf, tpch.SEED, lo, n, key64=self.key64, columns=od_cols))
-            for k, b in tpch.dimension_tables(ctx, self.sf).items():
+            for k, b in tpch.dimension_tables(ctx, self.sf, self.query).items():
                 self.t[k] = self._leaf(b)
         self.plan = rank_plan(self.query, self.group.comm, self.t, self.join_exchange, self.chunk_rows)
         ctx.synchronize()

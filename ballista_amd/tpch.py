@@ -46,37 +46,45 @@ def table_rows(sf: float):
     return dict(lineitem=n_li, orders=int(1_500_000 * sf), customer=int(150_000 * sf), supplier=int(10_000 * sf))
 
 
-def dimension_arrays(sf: float):
+def dimension_arrays(sf: float, segments=True):
     """numpy columns of the small tables (customer, supplier, nation, region): dense keys from 1, uniform nation keys
-    and market segments from fixed seeds — the same on every rank, so the small sides of the joins are replicated."""
+    and market segments from fixed seeds — the same on every rank, so the small sides of the joins are replicated.
+    segments=False skips c_mktsegment (only Q3 reads it; at SF1000 it is 150 M strings)."""
     import numpy as np
     n = table_rows(sf)
     rc, rs = np.random.default_rng(7), np.random.default_rng(11)
-    return dict(
-        customer=dict(c_custkey=np.arange(1, n["customer"] + 1, dtype=np.int32),
-                      c_nationkey=rs.integers(0, 25, n["customer"]).astype(np.int32),
-                      c_mktsegment=rc.integers(0, 5, n["customer"]).astype(np.int32)),      # index into SEGMENTS
-        supplier=dict(s_suppkey=np.arange(1, n["supplier"] + 1, dtype=np.int32),
-                      s_nationkey=rs.integers(0, 25, n["supplier"]).astype(np.int32)))
+    customer = dict(c_custkey=np.arange(1, n["customer"] + 1, dtype=np.int32),
+                    c_nationkey=rs.integers(0, 25, n["customer"]).astype(np.int32))
+    if segments:
+        customer["c_mktsegment"] = rc.integers(0, 5, n["customer"]).astype(np.int32)       # index into SEGMENTS
+    return dict(customer=customer,
+                supplier=dict(s_suppkey=np.arange(1, n["supplier"] + 1, dtype=np.int32),
+                              s_nationkey=rs.integers(0, 25, n["supplier"]).astype(np.int32)))
 
 
-def dimension_tables(ctx, sf: float):
-    """the small tables as device batches (through the Arrow C Data Interface)"""
+def dimension_tables(ctx, sf: float, query=None):
+    """the small tables as device batches (through the Arrow C Data Interface); query "q5": customer without c_mktsegment,
+    "q3": customer only"""
     import numpy as np
     import pyarrow as pa
-    a = dimension_arrays(sf)
+    a = dimension_arrays(sf, segments=query != "q5")
 
     def dev(names, arrays):
         return P.RecordBatch.from_pyarrow(ctx, pa.RecordBatch.from_arrays([x if isinstance(x, pa.Array) else pa.array(x) for x in arrays], names=names))
 
     c, s_ = a["customer"], a["supplier"]
-    seg = pa.DictionaryArray.from_arrays(pa.array(c["c_mktsegment"]), pa.array(SEGMENTS)).cast(pa.string())
-    return dict(
-        customer=dev(["c_custkey", "c_nationkey", "c_mktsegment"], [c["c_custkey"], c["c_nationkey"], seg]),
-        supplier=dev(["s_suppkey", "s_nationkey"], [s_["s_suppkey"], s_["s_nationkey"]]),
-        nation=dev(["n_nationkey", "n_name", "n_regionkey"],
-                   [np.arange(25, dtype=np.int32), [n for n, _ in NATIONS], np.array([r for _, r in NATIONS], np.int32)]),
-        region=dev(["r_regionkey", "r_name"], [np.arange(5, dtype=np.int32), REGIONS]))
+    if query == "q5":
+        out = dict(customer=dev(["c_custkey", "c_nationkey"], [c["c_custkey"], c["c_nationkey"]]))
+    else:
+        seg = pa.DictionaryArray.from_arrays(pa.array(c["c_mktsegment"]), pa.array(SEGMENTS)).cast(pa.string())
+        out = dict(customer=dev(["c_custkey", "c_nationkey", "c_mktsegment"], [c["c_custkey"], c["c_nationkey"], seg]))
+    if query == "q3":
+        return out
+    out.update(supplier=dev(["s_suppkey", "s_nationkey"], [s_["s_suppkey"], s_["s_nationkey"]]),
+               nation=dev(["n_nationkey", "n_name", "n_regionkey"],
+                          [np.arange(25, dtype=np.int32), [n for n, _ in NATIONS], np.array([r for _, r in NATIONS], np.int32)]),
+               region=dev(["r_regionkey", "r_name"], [np.arange(5, dtype=np.int32), REGIONS]))
+    return out
 
 
 def fresh(plan: "P.ExecutionPlan") -> "P.ExecutionPlan":
