@@ -504,9 +504,10 @@ join_rank_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void*
                 // then the whole decision — ONE compare, whose lane mask is the ballot (a ballot of an AND of conditions costs two
                 // more vector instructions per row slot)
                 if constexpr (MAPBUF) {
-                    // byte offset of the granule's word = (off >> 5) * 8; 8-byte keys: offsets beyond 2^32 must not wrap into the map
-                    if (KW == 8) ok &= (uint32_t)((off >> 32) == 0);
-                    const uint32_t voff = ((uint32_t)off >> 2) & ~7u;
+                    // byte offset of the granule's word = (off >> 5) * 8 = (off >> 2) & ~7: 32 bits hold it for offsets below 2^34 (the
+                    // map is shorter than 2 GiB: its window ends below 2^33); 8-byte keys beyond that must not wrap into the map
+                    if (KW == 8) ok &= (uint32_t)((off >> 34) == 0);
+                    const uint32_t voff = (uint32_t)(off >> 2) & ~7u;
                     typedef unsigned int v2u_t __attribute__((ext_vector_type(2)));
                     const v2u_t w = __builtin_amdgcn_raw_buffer_load_b64(rmap, (int)(ok ? voff : 0xFFFFFFF8u), 0, 0);
                     pk[k] = ((uint64_t)w.y << 32) | w.x;

@@ -6,6 +6,7 @@ rust/core/src/serde/physical_plan/from_proto.rs:253-276 — Inner / Left / Right
   late materialisation  probe side = column projection over a filter: only its key columns are gathered before the probe
 
 Row multisets must match exactly (join output order is unspecified)."""
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -230,13 +231,16 @@ def test_rank_map_build_orders(ctx, jt, order, key_type):
 
 @pytest.mark.parametrize("jt", [ba.plan.INNER, ba.plan.LEFT])
 @pytest.mark.parametrize("order", ["sorted", "shuffled"])
-def test_rank_map_window_beyond_2_to_the_30(ctx, jt, order):
+def test_rank_map_window_beyond_2_to_the_30(jt, order, monkeypatch):
     """TPC-H SF1000 order keys: Int64, a window of 6 x 10^9 values (dbgen's sparse layout), far more than 2^30 and more than 2^32
-    — the rank map's granule index is (offset >> 5) of a 64-bit offset (ops_join.cpp: windows up to 2^36).  400 K build keys
+    — the rank map's granule index is (offset >> 5) of a 64-bit offset (ops_join.cpp: windows up to 2^36).  1.6 M build keys
     over [base, base + 6e9): ~1 KiB of map per build row, the sparsest a rank map is built for; probe keys inside, at both ends
     of and outside the window, and 2^32 apart from build keys (an offset truncated to 32 bits would match them)."""
+    monkeypatch.setenv("BHIP_KERNEL_TIMING", "1")             # (read when a context is created: this test names the kernels that ran)
+    ctx = ba.Context(0)
     rng = np.random.default_rng(33)
-    n_left, n_right, span, base = 400_000, 700_000, 6_000_000_000, 7_000_000_123
+    # (a rank map is built when the window is not sparser than 4096 key values per build row: 6e9 / 4096 = 1.47 M rows)
+    n_left, n_right, span, base = 1_600_000, 2_000_000, 6_000_000_000, 7_000_000_123
     lk = np.unique(rng.integers(0, span, n_left + 4096))[:n_left] + base
     lk[0], lk[-1] = base, base + span - 1
     if order == "shuffled":
@@ -253,6 +257,8 @@ def test_rank_map_window_beyond_2_to_the_30(ctx, jt, order):
     lm, rm = helpers.memory_exec(ctx, [[left]]), helpers.memory_exec(ctx, [[right]])
     ctx.kernel_stats(reset=True)
     check(ba.HashJoinExec(lm, rm, [("lk", "rk")], jt), ["lk", "rk", "ry", "lx"])
+    ks = ctx.kernel_stats(reset=True)                         # the rank map it is, not the CAS table
+    assert any(k.startswith("rank_bits") for k in ks) and "join_build_narrow" not in ks, ks
     flt = ba.FilterExec(E.coerce((col("rd") >= E.date32("1995-01-01")).and_(col("rd") < E.date32("1996-06-01")), {"rk": "Int64", "ry": "Int64", "rd": "Date32"}), rm)
     check(ba.HashJoinExec(lm, flt, [("lk", "rk")], jt), ["lk", "rk", "ry", "lx"])
 
