@@ -75,7 +75,10 @@ hipError_t launch_scan_agg_hash(const LaunchCfg& cfg, const ScanParams& P, const
 // runs_before = exclusive scan of flags -> rowslot[i] = run of row i, head[run] = its first row;
 // launch_run_groups: rowslot[i] = the run that owns row i's key, owner[run] = head row + 1 for owning runs, 0 otherwise
 // (table: 2 x n entries zeroed, min_head: as many entries set to 0xFFFFFFFF; *n_runs_dev = the scan's total)
-hipError_t launch_run_heads(const LaunchCfg& cfg, const uint64_t* keys128, uint32_t n, uint32_t* flags);
+// *not_ascending (zeroed by the caller) is set when the first key part (k0 & first_mask) does not strictly increase from one run to
+// the next; while it stays 0 every run is a distinct group (launch_run_compact instead of launch_run_groups + flags + scan + compact)
+hipError_t launch_run_heads(const LaunchCfg& cfg, const uint64_t* keys128, uint32_t n, uint32_t* flags, uint64_t first_mask, uint64_t* not_ascending);
+hipError_t launch_run_compact(const LaunchCfg& cfg, const HashAggTable& T, const uint32_t* head, uint32_t n_runs, bool nulls, GroupRec* out);
 hipError_t launch_run_slots(const LaunchCfg& cfg, const uint32_t* flags, const uint32_t* runs_before, uint32_t n, uint32_t* rowslot, uint32_t* head);
 hipError_t launch_run_groups(const LaunchCfg& cfg, const uint64_t* keys128, uint32_t n, const uint32_t* head, const uint64_t* n_runs_dev, uint32_t* table,
                              uint64_t mask, uint32_t* min_head, uint32_t* slot_of_run, uint32_t* winner, uint32_t* owner, uint32_t* rowslot);

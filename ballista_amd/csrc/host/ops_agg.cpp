@@ -231,42 +231,61 @@ GroupRec* hash_aggregate(const Exec& ex, Temp& tmp, const ScanParams& P0, const 
     // Decided on the leading rows: at most half as many runs as rows.  Not with a fused predicate (a filtered-out row would
     // have to leave its run).  The operator remembers what it found.
     static const bool no_runs = [] { const char* v = getenv("BHIP_NO_RUN_AGG"); return v && atoi(v) != 0; }();
-    bool runs = false;
+    bool runs = false, distinct_runs = false;
+    uint32_t* run_head = nullptr;
+    uint64_t n_runs_host = 0;
     if (!no_runs && P0.pred_slot < 0 && total_rows >= 4096 && clustered_hint->load() >= 0) {
         uint32_t* flags = tmp.get<uint32_t>((size_t)total_rows + 1);
         uint32_t* before = tmp.get<uint32_t>((size_t)total_rows + 1);
-        uint64_t* n_runs_dev = tmp.get<uint64_t>(1);
+        uint64_t* n_runs_dev = tmp.get<uint64_t>(2);               // [0] runs, [1] "first key part not ascending" (read together)
         void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes(total_rows));
+        // the first key part's bytes in the packed key (parts are laid out from byte 0: ProgramBuilder::finish)
+        const int w0 = P0.n_keyparts > 0 ? P0.keyparts[0].width : 0;
+        const uint64_t first_mask = w0 >= 8 ? ~0ull : w0 > 0 ? ((1ull << (8 * w0)) - 1ull) : 0ull;
+        static const bool no_distinct = [] { const char* v = getenv("BHIP_NO_DISTINCT_RUNS"); return v && atoi(v) != 0; }();      // A/B: always the run table
         const int64_t sample = std::min<int64_t>(total_rows, 1 << 20);
-        TIMED_LAUNCH_N(ex, "run_heads", sample, launch_run_heads(cfg, keys, (uint32_t)sample, flags));
+        HIP_CHECK(hipMemsetAsync(n_runs_dev, 0, 16, ex.stream));
+        TIMED_LAUNCH_N(ex, "run_heads", sample, launch_run_heads(cfg, keys, (uint32_t)sample, flags, first_mask, n_runs_dev + 1));
         HIP_CHECK(exclusive_scan_u32_u32(ex.stream, flags, sample, before, false, n_runs_dev, scan_tmp));
-        runs = clustered_hint->load() == 1 || 2 * read_device(ex, n_runs_dev) <= (uint64_t)sample;
+        struct RunInfo { uint64_t n_runs, not_ascending; };
+        RunInfo ri = read_device(ex, reinterpret_cast<const RunInfo*>(n_runs_dev));
+        runs = clustered_hint->load() == 1 || 2 * ri.n_runs <= (uint64_t)sample;
         clustered_hint->store(runs ? 1 : -1);
         if (runs) {
             if (sample < total_rows) {
-                TIMED_LAUNCH_N(ex, "run_heads", total_rows, launch_run_heads(cfg, keys, (uint32_t)total_rows, flags));
+                TIMED_LAUNCH_N(ex, "run_heads", total_rows, launch_run_heads(cfg, keys, (uint32_t)total_rows, flags, first_mask, n_runs_dev + 1));
                 HIP_CHECK(exclusive_scan_u32_u32(ex.stream, flags, total_rows, before, false, n_runs_dev, scan_tmp));
+                // one more (short) wait: with the run count on the host every table below is sized by the runs, not by the rows, and
+                // when the runs turn out distinct the run table, the slot flags, their scan and the slot compaction are not run at all
+                if (!ri.not_ascending && !no_distinct) ri = read_device(ex, reinterpret_cast<const RunInfo*>(n_runs_dev));
+                else ri.not_ascending = 1;
             }
-            uint64_t tcap = 1024;
-            while (tcap < 2ull * (uint64_t)total_rows) tcap <<= 1;
-            uint32_t* table = tmp.get<uint32_t>(tcap);
-            uint32_t* min_head = tmp.get<uint32_t>(tcap);
+            distinct_runs = !ri.not_ascending && !no_distinct && first_mask != 0;
+            n_runs_host = ri.n_runs;
             uint32_t* head = tmp.get<uint32_t>((size_t)total_rows + 1);
-            uint32_t* slot_of_run = tmp.get<uint32_t>((size_t)total_rows + 1);
-            uint32_t* winner = tmp.get<uint32_t>((size_t)total_rows + 1);
-            T.owner = tmp.get<uint32_t>((size_t)total_rows + 1);
-            HIP_CHECK(hipMemsetAsync(table, 0, tcap * 4, ex.stream));
-            HIP_CHECK(hipMemsetAsync(min_head, 0xFF, tcap * 4, ex.stream));
-            HIP_CHECK(hipMemsetAsync(T.owner, 0, ((size_t)total_rows + 1) * 4, ex.stream));
+            run_head = head;
             TIMED_LAUNCH_N(ex, "run_slots", total_rows, launch_run_slots(cfg, flags, before, (uint32_t)total_rows, T.rowslot, head));
-            TIMED_LAUNCH_N(ex, "run_groups", total_rows, launch_run_groups(cfg, keys, (uint32_t)total_rows, head, n_runs_dev, table, tcap - 1, min_head, slot_of_run,
-                                                                            winner, T.owner, T.rowslot));
+            if (!distinct_runs) {
+                uint64_t tcap = 1024;
+                while (tcap < 2ull * (uint64_t)total_rows) tcap <<= 1;
+                uint32_t* table = tmp.get<uint32_t>(tcap);
+                uint32_t* min_head = tmp.get<uint32_t>(tcap);
+                uint32_t* slot_of_run = tmp.get<uint32_t>((size_t)total_rows + 1);
+                uint32_t* winner = tmp.get<uint32_t>((size_t)total_rows + 1);
+                T.owner = tmp.get<uint32_t>((size_t)total_rows + 1);
+                HIP_CHECK(hipMemsetAsync(table, 0, tcap * 4, ex.stream));
+                HIP_CHECK(hipMemsetAsync(min_head, 0xFF, tcap * 4, ex.stream));
+                HIP_CHECK(hipMemsetAsync(T.owner, 0, ((size_t)total_rows + 1) * 4, ex.stream));
+                TIMED_LAUNCH_N(ex, "run_groups", total_rows, launch_run_groups(cfg, keys, (uint32_t)total_rows, head, n_runs_dev, table, tcap - 1, min_head, slot_of_run,
+                                                                                winner, T.owner, T.rowslot));
+            }
         }
     }
 
     uint64_t cap;
     if (runs) {
-        cap = (uint64_t)total_rows;                  // the slot space is the space of runs: at most one per row; unused ones stay empty
+        // the slot space is the space of runs: at most one per row (unused ones stay empty); exactly the runs when they are distinct
+        cap = distinct_runs ? std::max<uint64_t>(n_runs_host, 1) : (uint64_t)total_rows;
         T.slots_given = 1;
         T.mask = cap - 1;
     } else {
@@ -322,16 +341,18 @@ GroupRec* hash_aggregate(const Exec& ex, Temp& tmp, const ScanParams& P0, const 
         // read together with the group count below (ONE host wait for the whole tail of the aggregate)
         TIMED_LAUNCH_N(ex, "det_spill_lists", total_rows, launch_det_spill_lists(cfg, D));
     }
-    // used slots -> dense records (slot order: deterministic for a given input)
-    uint32_t* flags = tmp.get<uint32_t>(cap);
-    uint64_t* dense = tmp.get<uint64_t>(cap + 1);
-    uint64_t* total = tail;
-    void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes((int64_t)cap));
-    TIMED_LAUNCH_N(ex, "hash_agg_flags", cap, launch_hash_agg_flags(cfg, T, flags));
-    HIP_CHECK(exclusive_scan_u32_u64(ex.stream, flags, (int64_t)cap, dense, false, total, scan_tmp));
+    // used slots -> dense records (slot order: deterministic for a given input); distinct runs ARE the dense records
+    uint64_t* dense = nullptr;
+    if (!distinct_runs) {
+        uint32_t* flags = tmp.get<uint32_t>(cap);
+        dense = tmp.get<uint64_t>(cap + 1);
+        void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes((int64_t)cap));
+        TIMED_LAUNCH_N(ex, "hash_agg_flags", cap, launch_hash_agg_flags(cfg, T, flags));
+        HIP_CHECK(exclusive_scan_u32_u64(ex.stream, flags, (int64_t)cap, dense, false, tail, scan_tmp));
+    }
     struct Tail { uint64_t n_groups; uint32_t n_spill, lists_too_long; };
     const Tail tl = read_device(ex, reinterpret_cast<const Tail*>(tail));
-    const uint64_t ng = tl.n_groups;
+    const uint64_t ng = distinct_runs ? n_runs_host : tl.n_groups;
     if (T.n_fsum && tl.lists_too_long) {
         // some group has many runs (unclustered input): the whole list ordered by (slot, first row), then added up left to right
         const uint32_t n_spill = tl.n_spill;
@@ -341,7 +362,8 @@ GroupRec* hash_aggregate(const Exec& ex, Temp& tmp, const ScanParams& P0, const 
     }
     check_scan_status(ex, status);                   // after the one wait above: the stream is idle, this read is immediate
     GroupRec* table = tmp.get<GroupRec>(ng ? ng : 1);
-    if (ng) TIMED_LAUNCH_N(ex, "hash_agg_compact", cap, launch_hash_agg_compact(cfg, T, dense, nullable, table));
+    if (ng && distinct_runs) TIMED_LAUNCH_N(ex, "run_compact", ng, launch_run_compact(cfg, T, run_head, (uint32_t)ng, nullable, table));
+    else if (ng) TIMED_LAUNCH_N(ex, "hash_agg_compact", cap, launch_hash_agg_compact(cfg, T, dense, nullable, table));
     *n_groups = (int64_t)ng;
     return table;
 }

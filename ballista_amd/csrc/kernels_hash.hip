@@ -125,15 +125,34 @@ scan_agg_hash_kernel(const ScanParams P, const HashAggTable T, uint32_t row_base
 // after which the scan adds into slot rowslot[i] (scan_agg_hash_kernel with slots_given) and the compaction runs over the run
 // space.  The group of every row is decided by key equality alone; deterministic whatever the schedule (the minimum).
 __global__ void __launch_bounds__(BLOCK)
-run_heads_kernel(const uint64_t* keys128, uint32_t n, uint32_t* flags) {
+run_heads_kernel(const uint64_t* keys128, uint32_t n, uint32_t* flags, uint64_t first_mask, unsigned long long* not_ascending) {
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
         const ulonglong2 k = reinterpret_cast<const ulonglong2*>(keys128)[i];
         uint32_t head = 1;
         if (i > 0) {
             const ulonglong2 p = reinterpret_cast<const ulonglong2*>(keys128)[i - 1];
             head = (k.x != p.x || k.y != p.y) ? 1u : 0u;
+            // first key part (the low bytes of the packed key) strictly increasing from run to run => no key comes back in a later run:
+            // every run is a group of its own and no table has to be consulted (lineitem rows of a join arrive in order-key order)
+            if (head && (k.x & first_mask) <= (p.x & first_mask)) *not_ascending = 1ull;
         }
         flags[i] = head;
+    }
+}
+
+// distinct runs (run_heads found the first key part ascending): the group records straight from the runs — slot r IS group r
+__global__ void __launch_bounds__(BLOCK)
+run_compact_kernel(HashAggTable T, const uint32_t* head, uint32_t n_runs, int nulls, GroupRec* out) {
+    for (uint32_t r = blockIdx.x * BLOCK + threadIdx.x; r < n_runs; r += gridDim.x * BLOCK) {
+        const uint32_t o = head[r];
+        GroupRec& g = out[r];
+        g.k0 = T.keys128[2ull * o];
+        g.k1 = T.keys128[2ull * o + 1];
+        g.rows = T.rows[r];
+        for (int a = 0; a < T.n_acc; ++a) {
+            g.acc[a] = T.acc[(size_t)r * T.n_acc + a];
+            g.nvalid[a] = nulls ? T.nvalid[(size_t)r * T.n_acc + a] : g.rows;
+        }
     }
 }
 __global__ void __launch_bounds__(BLOCK)
@@ -591,9 +610,14 @@ static unsigned run_grid(const LaunchCfg& cfg, size_t n) {
     if (g > (size_t)cfg.device_cus * 16) g = (size_t)cfg.device_cus * 16;
     return (unsigned)(g < 1 ? 1 : g);
 }
-hipError_t launch_run_heads(const LaunchCfg& cfg, const uint64_t* keys128, uint32_t n, uint32_t* flags) {
+hipError_t launch_run_heads(const LaunchCfg& cfg, const uint64_t* keys128, uint32_t n, uint32_t* flags, uint64_t first_mask, uint64_t* not_ascending) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(run_heads_kernel, dim3(run_grid(cfg, n)), dim3(BLOCK), 0, cfg.stream, keys128, n, flags);
+    hipLaunchKernelGGL(run_heads_kernel, dim3(run_grid(cfg, n)), dim3(BLOCK), 0, cfg.stream, keys128, n, flags, first_mask, (unsigned long long*)not_ascending);
+    return hipGetLastError();
+}
+hipError_t launch_run_compact(const LaunchCfg& cfg, const HashAggTable& T, const uint32_t* head, uint32_t n_runs, bool nulls, GroupRec* out) {
+    if (n_runs == 0) return hipSuccess;
+    hipLaunchKernelGGL(run_compact_kernel, dim3(run_grid(cfg, n_runs)), dim3(BLOCK), 0, cfg.stream, T, head, n_runs, nulls ? 1 : 0, out);
     return hipGetLastError();
 }
 hipError_t launch_run_slots(const LaunchCfg& cfg, const uint32_t* flags, const uint32_t* runs_before, uint32_t n, uint32_t* rowslot, uint32_t* head) {

@@ -213,7 +213,7 @@ def test_hash_aggregate_group_by(ctx, gi):
     run_both(fin, ordered=False, float_rtol=1e-9, key_cols=[n for _, n in names])
 
 
-@pytest.mark.parametrize("shape", ["clustered", "clustered_two_keys", "comes_back", "descending", "with_predicate"])
+@pytest.mark.parametrize("shape", ["clustered", "clustered_two_keys", "comes_back", "descending", "with_predicate", "clustered_1.3M", "comes_back_1.3M"])
 def test_hash_aggregate_over_input_clustered_by_group(ctx, shape):
     """many groups whose rows are consecutive (lineitem joined to orders, grouped by the order key): every run of equal keys is a
     group and no table is needed — IF no key comes back later, which the same pass checks (every key change an increase of the
@@ -221,7 +221,10 @@ def test_hash_aggregate_over_input_clustered_by_group(ctx, shape):
     batches, NULLs in the summed column, runs that straddle 1024-row tiles and batch boundaries."""
     from collections import OrderedDict
     rng = np.random.default_rng(7)
-    n = 40_000
+    # (beyond 2^20 rows the run structure is decided on the leading rows and confirmed — run count, "first key part ascending" — by
+    # a second read after the full pass: ops_agg.cpp hash_aggregate)
+    n = 1_300_000 if shape.endswith("1.3M") else 40_000
+    shape = shape.split("_1.3M")[0]
     sizes = rng.integers(1, 9, n)
     sizes[100] = 5000                                               # one run longer than several tiles
     key = np.repeat(np.arange(len(sizes), dtype=np.int64) * 3 + 10, sizes)[:n]
