@@ -554,18 +554,47 @@ public:
         for (auto& c : in->cols) fixed = fixed && !c.validity && !c.is_view() && c.dtype != DT_UTF8 && c.dtype != DT_BOOLEAN;
         static const bool no_stream = [] { const char* v = getenv("BHIP_NO_STREAMING_SHUFFLE"); return v && atoi(v) != 0; }();
         const auto t0 = std::chrono::steady_clock::now();
-        // every rank must take the same path: the schema decides it (NULL-ability of a column is part of what is gathered below)
-        std::vector<int64_t> me = {in->n_rows, fixed && !no_stream ? 1 : 0};
-        std::vector<int64_t> everyone;
+        // ONE gather tells every rank everything: each rank chunks its OWN rows (at most MAXC chunks: the matrix has a common size),
+        // counts them per destination on the device and publishes [rows, "streams", chunks, counts[MAXC][world]].  Every rank must
+        // take the same path: if any rank cannot stream (a NULL-able column there), all take the general one.
+        constexpr int64_t MAXC = 64;
+        const int64_t quantum = partition_chunk_quantum();
+        const int64_t n = in->n_rows;
+        const bool stream_me = fixed && !no_stream;
+        if (chunk_rows <= 0) chunk_rows = 64ll << 20;                                  // 64 Mi rows: 1.8 GB of Q5's 28-byte lineitem rows per staging buffer
+        chunk_rows = std::max(chunk_rows, (n + MAXC - 1) / MAXC);
+        chunk_rows = (chunk_rows + quantum - 1) / quantum * quantum;
+        if (chunk_rows > n) chunk_rows = std::max<int64_t>(quantum, (n + quantum - 1) / quantum * quantum);
+        const int64_t C_me = (n + chunk_rows - 1) / chunk_rows;
+        const size_t W = 3 + (size_t)MAXC * world_;
+        std::vector<int64_t> me(W, 0);
+        me[0] = n; me[1] = stream_me ? 1 : 0; me[2] = C_me;
+        std::vector<int64_t> all;
+        double ms_count = 0;
         {
             std::lock_guard<std::mutex> g(mu_);
             ctx_->set_device();
-            everyone = world_ == 1 ? me : gather_words(me);
+            Exec ex{ctx_, stream_};
+            // ---- count pass: counts[c][d] = rows of my chunk c that go to rank d ----------------------------------------------
+            if (stream_me && n > 0) {
+                Temp tmp(ex);
+                uint64_t* dev = tmp.get<uint64_t>((size_t)MAXC * world_);
+                HIP_CHECK(hipMemsetAsync(dev, 0, (size_t)MAXC * world_ * 8, stream_));
+                TIMED_LAUNCH_B(ex, "partition_count", n, (uint64_t)n * kw, partition_count(ex.cfg(), kc.data->ptr(), kw, n, (uint32_t)world_, chunk_rows, dev));
+                HIP_CHECK(hipMemcpyAsync(&me[3], dev, (size_t)MAXC * world_ * 8, hipMemcpyDeviceToHost, stream_));
+                HIP_CHECK(hipStreamSynchronize(stream_));
+            }
+            ms_count = ms_since(t0);
+            all = world_ == 1 ? me : gather_words(me);                                   // [src][3 + chunk * world + dst]
         }
-        bool all_fixed = true;
-        for (int r = 0; r < world_; ++r) all_fixed = all_fixed && everyone[(size_t)r * 2 + 1] != 0;
-        if (!all_fixed) {
-            // general path: any column type, NULLs, expressions' worth of keys
+        bool all_stream = true;
+        int64_t C = 0;                                                                   // chunk rounds every rank walks (its own chunks may run out earlier)
+        for (int r = 0; r < world_; ++r) {
+            all_stream = all_stream && all[(size_t)r * W + 1] != 0;
+            C = std::max(C, all[(size_t)r * W + 2]);
+        }
+        if (!all_stream) {
+            // general path: any column type, NULLs
             ctx_->set_device();
             Exec ex{ctx_, stream_};
             std::vector<ExprPtr> exprs = {make_column(key)};
@@ -591,28 +620,7 @@ public:
         std::lock_guard<std::mutex> g(mu_);
         ctx_->set_device();
         Exec ex{ctx_, stream_}, ax{ctx_, aux_};
-        const int64_t quantum = partition_chunk_quantum();
-        if (chunk_rows <= 0) chunk_rows = 64ll << 20;                                  // 64 Mi rows: 1.8 GB of Q5's 28-byte lineitem rows per staging buffer
-        chunk_rows = (chunk_rows + quantum - 1) / quantum * quantum;
-        const int64_t n = in->n_rows;
-        int64_t max_rows = 0;
-        for (int r = 0; r < world_; ++r) max_rows = std::max(max_rows, everyone[(size_t)r * 2]);
-        if (chunk_rows > max_rows) chunk_rows = std::max<int64_t>(quantum, (max_rows + quantum - 1) / quantum * quantum);
-        const int64_t C = (max_rows + chunk_rows - 1) / chunk_rows;                     // chunks every rank walks (its own may run out earlier)
-        const int64_t C_me = (n + chunk_rows - 1) / chunk_rows;
-        // ---- count pass: counts[c][d] = rows of my chunk c that go to rank d --------------------------------------------------
-        std::vector<int64_t> counts((size_t)std::max<int64_t>(C, 1) * world_, 0);
-        if (n > 0) {
-            Temp tmp(ex);
-            uint64_t* dev = tmp.get<uint64_t>(counts.size());
-            HIP_CHECK(hipMemsetAsync(dev, 0, counts.size() * 8, stream_));
-            TIMED_LAUNCH_B(ex, "partition_count", n, (uint64_t)n * kw, partition_count(ex.cfg(), kc.data->ptr(), kw, n, (uint32_t)world_, chunk_rows, dev));
-            HIP_CHECK(hipMemcpyAsync(counts.data(), dev, counts.size() * 8, hipMemcpyDeviceToHost, stream_));
-            HIP_CHECK(hipStreamSynchronize(stream_));
-        }
-        const double ms_count = ms_since(t0);
-        const std::vector<int64_t> all = world_ == 1 ? counts : gather_words(counts);   // [src][chunk][dst]
-        auto cnt = [&](int src, int64_t c, int dst) { return all[((size_t)src * C + (size_t)c) * world_ + dst]; };
+        auto cnt = [&](int src, int64_t c, int dst) { return all[(size_t)src * W + 3 + (size_t)c * world_ + dst]; };
         // rows I receive from each source, where each source's rows start in the result
         std::vector<int64_t> from((size_t)world_, 0), start((size_t)world_ + 1, 0);
         for (int s = 0; s < world_; ++s) {

@@ -18,6 +18,8 @@
 #include <cstring>
 #include <fstream>
 #include <future>
+#include <map>
+#include <set>
 #include <thread>
 
 #include "../util_kernels.h"
@@ -29,6 +31,67 @@ namespace bhip {
 using namespace pq;
 
 namespace {
+
+// ---- pinned host blocks for what the walk produces (parquet_host.hpp: HostVec) ---------------------------------------------------
+// Power-of-two size classes from 64 KiB up, kept for the life of the process (bounded: BHIP_PINNED_POOL_MB, default 16 GiB);
+// smaller requests are plain malloc.  A block is faulted in and registered with the device once; the async copies from it do
+// not go through the runtime's staging buffers.
+class PinnedPool {
+public:
+    static PinnedPool& get() { static PinnedPool p; return p; }
+    void* alloc(size_t bytes) {
+        if (bytes < MIN) return malloc(bytes ? bytes : 1);
+        const size_t cls = class_of(bytes);
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            auto it = free_.find(cls);
+            if (it != free_.end() && !it->second.empty()) {
+                void* p = it->second.back();
+                it->second.pop_back();
+                pooled_ -= cls;
+                return p;
+            }
+        }
+        void* p = nullptr;
+        if (hipHostMalloc(&p, cls, hipHostMallocPortable) == hipSuccess && p) {
+            std::lock_guard<std::mutex> g(mu_);
+            pinned_.insert(p);
+            return p;
+        }
+        (void)hipGetLastError();
+        return malloc(bytes);                                       // no pinned memory left: pageable (slower copies, still correct)
+    }
+    void release(void* p, size_t bytes) {
+        if (!p) return;
+        if (bytes < MIN) { free(p); return; }
+        const size_t cls = class_of(bytes);
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            if (!pinned_.count(p)) { free(p); return; }
+            if (pooled_ + cls <= cap_) { free_[cls].push_back(p); pooled_ += cls; return; }
+            pinned_.erase(p);
+        }
+        hipHostFree(p);
+    }
+private:
+    static constexpr size_t MIN = 1u << 16;
+    static size_t class_of(size_t bytes) { size_t c = MIN; while (c < bytes) c <<= 1; return c; }
+    PinnedPool() {
+        const char* v = getenv("BHIP_PINNED_POOL_MB");
+        cap_ = (size_t)(v ? atoll(v) : 16384) << 20;
+    }
+    std::mutex mu_;
+    std::map<size_t, std::vector<void*>> free_;
+    std::set<void*> pinned_;
+    size_t pooled_ = 0, cap_;
+};
+void* pinned_alloc(size_t bytes) { return PinnedPool::get().alloc(bytes); }
+void pinned_free(void* p, size_t bytes) { PinnedPool::get().release(p, bytes); }
+void install_pinned_allocator() {
+    static const bool off = [] { const char* v = getenv("BHIP_PARQUET_PAGEABLE"); return v && atoi(v) != 0; }();       // A/B: plain malloc
+    static std::once_flag once;
+    if (!off) std::call_once(once, [] { pq::set_host_allocator(pinned_alloc, pinned_free); });
+}
 
 BufferPtr upload(const Exec& ex, const void* host, size_t bytes) {
     BufferPtr b = make_buffer(ex, bytes + 16);
@@ -198,6 +261,7 @@ public:
                     if (g.num_rows > 0xFFFFFFF0ll) fail(BHIP_ENOTIMPL, "Parquet: row group of more than 2^32 rows");
                     units.push_back(Unit{&self->files_[fi], &g});
                 }
+            install_pinned_allocator();
             auto gate = std::make_shared<Gate>(decode_threads());
             using Parsed = std::vector<std::future<HostChunk>>;
             auto start = [&](const Unit& u) {

@@ -9,6 +9,19 @@
 namespace bhip {
 namespace pq {
 
+static HostAllocFn g_alloc = nullptr;
+static HostFreeFn g_free = nullptr;
+void set_host_allocator(HostAllocFn alloc, HostFreeFn free_fn) { g_alloc = alloc; g_free = free_fn; }
+void* host_alloc(size_t bytes) {
+    void* p = g_alloc ? g_alloc(bytes) : malloc(bytes ? bytes : 1);
+    if (!p) throw std::bad_alloc();
+    return p;
+}
+void host_free(void* p, size_t bytes) {
+    if (g_free) g_free(p, bytes);
+    else free(p);
+}
+
 namespace {
 
 // ---- Thrift compact protocol ---------------------------------------------------------------------------------------------
@@ -359,7 +372,8 @@ void parse_runs(const uint8_t* base, const uint8_t* p, const uint8_t* end, int b
 }
 
 // definition levels of a flat optional column (bit width 1) -> validity bits; returns the number of valid values
-int64_t decode_def_levels(const uint8_t* p, const uint8_t* end, int64_t n, std::vector<uint8_t>& validity) {
+template <class Vec>
+int64_t decode_def_levels(const uint8_t* p, const uint8_t* end, int64_t n, Vec& validity) {
     validity.assign((size_t)((n + 63) / 64) * 8 + 8, 0);
     if (n > 0 && (!p || p >= end)) fail(BHIP_EEXEC, "Parquet: an optional column's page without definition levels");
     int64_t out = 0, valid = 0;

@@ -34,25 +34,46 @@ PqFile read_footer(const std::string& path);
 // the bytes of one column chunk (dictionary page first when there is one); bounds checked against the file size
 std::vector<uint8_t> read_chunk_bytes(const PqFile& F, const PqChunk& ch, const std::string& column_name);
 
+// Storage of what the walk produces.  The big buffers (value bytes, offsets, validity) come from an allocator the device half
+// installs: a pool of PINNED host blocks, so that the copies to the device are truly asynchronous and a block's pages are
+// faulted in once per process, not once per row group (with plain std::vector the scan spent more time in first-touch page
+// faults of its ~5 GB of decoded pages than in its kernels).  Default: malloc / free — what the sanitizer harness runs on.
+typedef void* (*HostAllocFn)(size_t bytes);
+typedef void (*HostFreeFn)(void* p, size_t bytes);
+void set_host_allocator(HostAllocFn alloc, HostFreeFn free_fn);
+void* host_alloc(size_t bytes);
+void host_free(void* p, size_t bytes);
+template <class T>
+struct HostAlloc {
+    using value_type = T;
+    HostAlloc() = default;
+    template <class U> HostAlloc(const HostAlloc<U>&) {}
+    T* allocate(size_t n) { return static_cast<T*>(host_alloc(n * sizeof(T))); }
+    void deallocate(T* p, size_t n) { host_free(p, n * sizeof(T)); }
+    template <class U> bool operator==(const HostAlloc<U>&) const { return true; }
+    template <class U> bool operator!=(const HostAlloc<U>&) const { return false; }
+};
+template <class T> using HostVec = std::vector<T, HostAlloc<T>>;
+
 // what the host walk leaves of one data page for the device
 enum PageKind { PG_DICT = 0, PG_FIXED = 1, PG_STRINGS = 2, PG_BOOL = 3 };
 struct HostPage {
     int64_t n = 0, n_valid = 0;
     bool has_nulls = false;
-    std::vector<uint8_t> validity;      // LSB-first, padded to 64-bit words (+ 8), when the column is optional
+    HostVec<uint8_t> validity;          // LSB-first, padded to 64-bit words (+ 8), when the column is optional
     std::vector<uint32_t> prefix;       // set bits before each validity word, when has_nulls
     int kind = PG_FIXED;
     int bit_width = 0;                  // PG_DICT
     std::vector<PqRun> runs;            // PG_DICT: the run table of the n_valid indices; `value` of a packed run = byte offset in `bytes`
-    std::vector<uint8_t> bytes;         // PG_DICT: the index bytes; PG_FIXED: n_valid dense values; PG_STRINGS: value bytes;
+    HostVec<uint8_t> bytes;             // PG_DICT: the index bytes; PG_FIXED: n_valid dense values; PG_STRINGS: value bytes;
                                         // PG_BOOL: n bits (NULLs re-inserted as 0), padded to 64-bit words
-    std::vector<int32_t> offsets;       // PG_STRINGS: n + 1 (a NULL row repeats the running offset)
+    HostVec<int32_t> offsets;           // PG_STRINGS: n + 1 (a NULL row repeats the running offset)
 };
 struct HostDict {
     bool present = false;
     int64_t n = 0;
-    std::vector<int32_t> offsets;       // BYTE_ARRAY dictionaries: n + 1
-    std::vector<uint8_t> bytes;         // value bytes (strings) or n fixed-width values
+    HostVec<int32_t> offsets;           // BYTE_ARRAY dictionaries: n + 1
+    HostVec<uint8_t> bytes;             // value bytes (strings) or n fixed-width values
 };
 struct HostChunk {
     HostDict dict;
