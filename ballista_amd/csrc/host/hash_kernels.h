@@ -75,8 +75,13 @@ hipError_t launch_scan_agg_hash(const LaunchCfg& cfg, const ScanParams& P, const
 // runs_before = exclusive scan of flags -> rowslot[i] = run of row i, head[run] = its first row;
 // launch_run_groups: rowslot[i] = the run that owns row i's key, owner[run] = head row + 1 for owning runs, 0 otherwise
 // (table: 2 x n entries zeroed, min_head: as many entries set to 0xFFFFFFFF; *n_runs_dev = the scan's total)
-// *not_ascending (zeroed by the caller) is set when the first key part (k0 & first_mask) does not strictly increase from one run to
-// the next; while it stays 0 every run is a distinct group (launch_run_compact instead of launch_run_groups + flags + scan + compact)
+// not_ascending[0] (zeroed by the caller) counts the places where the first key part (k0 & first_mask) does not strictly increase
+// from one run to the next, not_ascending[1] (set to ~0 by the caller) = the first such row.  0 places: every run is a distinct group
+// (launch_run_compact instead of launch_run_groups + flags + scan + compact); 1 place: launch_run_tail_* (kernels_hash.hip)
+hipError_t launch_run_tail_resolve(const LaunchCfg& cfg, const uint64_t* keys128, const uint32_t* head, const uint64_t* n_runs_dev, const uint32_t* rowslot,
+                                   uint32_t n_rows, uint32_t split_row, uint64_t first_mask, uint32_t* head2, uint32_t* match, uint32_t* fresh);
+hipError_t launch_run_tail_remap(const LaunchCfg& cfg, const uint32_t* head, const uint64_t* n_runs_dev, uint32_t n_rows, uint32_t split_row, const uint32_t* match,
+                                 const uint32_t* fresh_before, uint32_t* rowslot, uint32_t* head2, uint64_t* n_groups_out);
 hipError_t launch_run_heads(const LaunchCfg& cfg, const uint64_t* keys128, uint32_t n, uint32_t* flags, uint64_t first_mask, uint64_t* not_ascending);
 hipError_t launch_run_compact(const LaunchCfg& cfg, const HashAggTable& T, const uint32_t* head, uint32_t n_runs, bool nulls, GroupRec* out);
 hipError_t launch_run_slots(const LaunchCfg& cfg, const uint32_t* flags, const uint32_t* runs_before, uint32_t n, uint32_t* rowslot, uint32_t* head);

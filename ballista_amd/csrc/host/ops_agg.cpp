@@ -231,41 +231,65 @@ GroupRec* hash_aggregate(const Exec& ex, Temp& tmp, const ScanParams& P0, const 
     // Decided on the leading rows: at most half as many runs as rows.  Not with a fused predicate (a filtered-out row would
     // have to leave its run).  The operator remembers what it found.
     static const bool no_runs = [] { const char* v = getenv("BHIP_NO_RUN_AGG"); return v && atoi(v) != 0; }();
-    bool runs = false, distinct_runs = false;
+    // clustered input: 0 = look every run up in the run table; 1 = the runs are distinct groups (first key part ascending);
+    // 2 = two ascending stretches (one place where it does not ascend): the second stretch is matched against the first by binary search
+    bool runs = false;
+    int distinct_runs = 0;
     uint32_t* run_head = nullptr;
     uint64_t n_runs_host = 0;
+    uint64_t* tail = tmp.get<uint64_t>(2);          // [0] the group count, [1] the spill list's entry count | "lists too long" << 32: read in one piece
+    HIP_CHECK(hipMemsetAsync(tail, 0, 16, ex.stream));
     if (!no_runs && P0.pred_slot < 0 && total_rows >= 4096 && clustered_hint->load() >= 0) {
         uint32_t* flags = tmp.get<uint32_t>((size_t)total_rows + 1);
         uint32_t* before = tmp.get<uint32_t>((size_t)total_rows + 1);
-        uint64_t* n_runs_dev = tmp.get<uint64_t>(2);               // [0] runs, [1] "first key part not ascending" (read together)
+        uint64_t* n_runs_dev = tmp.get<uint64_t>(3);               // [0] runs, [1] places where the first key part does not ascend, [2] the first of them
         void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes(total_rows));
         // the first key part's bytes in the packed key (parts are laid out from byte 0: ProgramBuilder::finish)
         const int w0 = P0.n_keyparts > 0 ? P0.keyparts[0].width : 0;
         const uint64_t first_mask = w0 >= 8 ? ~0ull : w0 > 0 ? ((1ull << (8 * w0)) - 1ull) : 0ull;
         static const bool no_distinct = [] { const char* v = getenv("BHIP_NO_DISTINCT_RUNS"); return v && atoi(v) != 0; }();      // A/B: always the run table
         const int64_t sample = std::min<int64_t>(total_rows, 1 << 20);
-        HIP_CHECK(hipMemsetAsync(n_runs_dev, 0, 16, ex.stream));
+        const uint64_t info0[3] = {0, 0, ~0ull};
+        HIP_CHECK(hipMemcpyAsync(n_runs_dev, info0, sizeof(info0), hipMemcpyHostToDevice, ex.stream));
         TIMED_LAUNCH_N(ex, "run_heads", sample, launch_run_heads(cfg, keys, (uint32_t)sample, flags, first_mask, n_runs_dev + 1));
         HIP_CHECK(exclusive_scan_u32_u32(ex.stream, flags, sample, before, false, n_runs_dev, scan_tmp));
-        struct RunInfo { uint64_t n_runs, not_ascending; };
+        struct RunInfo { uint64_t n_runs, breaks, first_break; };
         RunInfo ri = read_device(ex, reinterpret_cast<const RunInfo*>(n_runs_dev));
         runs = clustered_hint->load() == 1 || 2 * ri.n_runs <= (uint64_t)sample;
         clustered_hint->store(runs ? 1 : -1);
         if (runs) {
             if (sample < total_rows) {
+                HIP_CHECK(hipMemcpyAsync(n_runs_dev, info0, sizeof(info0), hipMemcpyHostToDevice, ex.stream));
                 TIMED_LAUNCH_N(ex, "run_heads", total_rows, launch_run_heads(cfg, keys, (uint32_t)total_rows, flags, first_mask, n_runs_dev + 1));
                 HIP_CHECK(exclusive_scan_u32_u32(ex.stream, flags, total_rows, before, false, n_runs_dev, scan_tmp));
                 // one more (short) wait: with the run count on the host every table below is sized by the runs, not by the rows, and
                 // when the runs turn out distinct the run table, the slot flags, their scan and the slot compaction are not run at all
-                if (!ri.not_ascending && !no_distinct) ri = read_device(ex, reinterpret_cast<const RunInfo*>(n_runs_dev));
-                else ri.not_ascending = 1;
+                if (ri.breaks <= 1 && !no_distinct) ri = read_device(ex, reinterpret_cast<const RunInfo*>(n_runs_dev));
+                else ri.breaks = 2;
             }
-            distinct_runs = !ri.not_ascending && !no_distinct && first_mask != 0;
+            distinct_runs = (no_distinct || first_mask == 0 || ri.breaks > 1) ? 0 : ri.breaks == 0 ? 1 : 2;
             n_runs_host = ri.n_runs;
             uint32_t* head = tmp.get<uint32_t>((size_t)total_rows + 1);
             run_head = head;
             TIMED_LAUNCH_N(ex, "run_slots", total_rows, launch_run_slots(cfg, flags, before, (uint32_t)total_rows, T.rowslot, head));
-            if (!distinct_runs) {
+            if (distinct_runs == 2) {
+                // the runs from the break on: matched against the first stretch, new groups numbered behind it
+                const uint32_t split_row = (uint32_t)ri.first_break;
+                uint32_t* head2 = tmp.get<uint32_t>((size_t)n_runs_host + 1);
+                uint32_t* match = tmp.get<uint32_t>((size_t)n_runs_host + 1);
+                uint32_t* fresh = tmp.get<uint32_t>((size_t)n_runs_host + 1);
+                uint32_t* fresh_before = tmp.get<uint32_t>((size_t)n_runs_host + 2);
+                // (the second stretch's length is only known on the device: sized by the runs; entries past it are never read)
+                HIP_CHECK(hipMemsetAsync(fresh, 0, ((size_t)n_runs_host + 1) * 4, ex.stream));
+                TIMED_LAUNCH_N(ex, "run_tail_resolve", total_rows, launch_run_tail_resolve(cfg, keys, head, n_runs_dev, T.rowslot, (uint32_t)total_rows, split_row, first_mask,
+                                                                                          head2, match, fresh));
+                // the scan runs over all `n_runs` entries of `fresh` (zeros past the second stretch): fresh_before[t] for t < tail length,
+                // and fresh_before[tail length] = the number of new groups, whatever the tail length is
+                HIP_CHECK(exclusive_scan_u32_u32(ex.stream, fresh, (int64_t)n_runs_host + 1, fresh_before, false, nullptr, scan_tmp));
+                TIMED_LAUNCH_N(ex, "run_tail_remap", total_rows, launch_run_tail_remap(cfg, head, n_runs_dev, (uint32_t)total_rows, split_row, match, fresh_before, T.rowslot,
+                                                                                      head2, tail));
+                run_head = head2;
+            } else if (!distinct_runs) {
                 uint64_t tcap = 1024;
                 while (tcap < 2ull * (uint64_t)total_rows) tcap <<= 1;
                 uint32_t* table = tmp.get<uint32_t>(tcap);
@@ -310,9 +334,6 @@ GroupRec* hash_aggregate(const Exec& ex, Temp& tmp, const ScanParams& P0, const 
         TIMED_LAUNCH_N(ex, "scan_agg_hash", b->n_rows, launch_scan_agg_hash(cfg, P, T, row_base, status));
         row_base += (uint32_t)b->n_rows;
     }
-    // [0] the group count (the scan below), [1] the spill list's entry count | "lists too long" << 32: read in one piece
-    uint64_t* tail = tmp.get<uint64_t>(2);
-    HIP_CHECK(hipMemsetAsync(tail, 0, 16, ex.stream));
     if (T.n_fsum) {
         const size_t n_tiles = ((size_t)total_rows + 1023) / 1024, stage_n = n_tiles * 1024;
         D.rowslot = T.rowslot;
@@ -352,7 +373,7 @@ GroupRec* hash_aggregate(const Exec& ex, Temp& tmp, const ScanParams& P0, const 
     }
     struct Tail { uint64_t n_groups; uint32_t n_spill, lists_too_long; };
     const Tail tl = read_device(ex, reinterpret_cast<const Tail*>(tail));
-    const uint64_t ng = distinct_runs ? n_runs_host : tl.n_groups;
+    const uint64_t ng = distinct_runs == 1 ? n_runs_host : tl.n_groups;           // (two stretches: written by run_tail_remap)
     if (T.n_fsum && tl.lists_too_long) {
         // some group has many runs (unclustered input): the whole list ordered by (slot, first row), then added up left to right
         const uint32_t n_spill = tl.n_spill;

@@ -13,6 +13,7 @@
 // Supported: flat schemas; INT32 (Int32 / Date32), INT64, DOUBLE, BOOLEAN, BYTE_ARRAY (Utf8); required and optional fields;
 // PLAIN, PLAIN_DICTIONARY / RLE_DICTIONARY; data pages V1 and V2; UNCOMPRESSED and SNAPPY.  Anything else is BHIP_ENOTIMPL at
 // plan time (types, nesting) or at the page that needs it (codec, encoding): the caller keeps its CPU ParquetExec.
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
@@ -283,6 +284,10 @@ public:
             };
             std::vector<BatchPtr> out;
             Parsed next;
+            // BHIP_PARQUET_TRACE=1: where the calling thread's time goes, per partition (stderr)
+            static const bool trace = [] { const char* v = getenv("BHIP_PARQUET_TRACE"); return v && atoi(v) != 0; }();
+            double t_walk = 0, t_issue = 0, t_dev = 0;
+            auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
             if (!units.empty()) next = start(units[0]);
             for (size_t k = 0; k < units.size(); ++k) {
                 Parsed cur = std::move(next);
@@ -298,8 +303,12 @@ public:
                 try {
                     for (size_t j = 0; j < cur.size(); ++j) {
                         const PqColumn& pc = u.F->cols[self->proj_[j]];
+                        double t0 = now();
                         held.push_back(cur[j].get());
+                        double t1 = now();
+                        t_walk += t1 - t0;
                         Column col = upload_chunk(ex, pc, held.back(), keep);
+                        t_issue += now() - t1;
                         if (pc.out_dtype != pc.dtype) {                                   // Int32 values of an INT_8 .. UINT_16 column
                             Column narrow = col;
                             narrow.dtype = pc.out_dtype;
@@ -316,9 +325,15 @@ public:
                     hipStreamSynchronize(ex.stream);
                     throw;
                 }
-                stream_wait(ex);                             // the copies have left `held`
+                {
+                    const double t0 = now();
+                    stream_wait(ex);                         // the copies have left `held`
+                    t_dev += now() - t0;
+                }
                 out.push_back(b);
             }
+            if (trace) fprintf(stderr, "[bhip-parquet] partition %d: %zu row groups; calling thread waited %.1f ms for host walks, %.1f ms issuing copies and launches, %.1f ms for the device\n",
+                               partition, units.size(), t_walk, t_issue, t_dev);
             return out;
         }));
     }

@@ -133,10 +133,64 @@ run_heads_kernel(const uint64_t* keys128, uint32_t n, uint32_t* flags, uint64_t 
             const ulonglong2 p = reinterpret_cast<const ulonglong2*>(keys128)[i - 1];
             head = (k.x != p.x || k.y != p.y) ? 1u : 0u;
             // first key part (the low bytes of the packed key) strictly increasing from run to run => no key comes back in a later run:
-            // every run is a group of its own and no table has to be consulted (lineitem rows of a join arrive in order-key order)
-            if (head && (k.x & first_mask) <= (p.x & first_mask)) *not_ascending = 1ull;
+            // every run is a group of its own and no table has to be consulted (lineitem rows of a join arrive in order-key order).
+            // info[1] counts the places where it does not increase, info[2] = the first such row: ONE such place (a table whose
+            // tail wraps around, two sorted batches back to back) still needs no table — launch_run_tail below
+            if (head && (k.x & first_mask) <= (p.x & first_mask)) {
+                atomicAdd(&not_ascending[0], 1ull);
+                atomicMin(&not_ascending[1], (unsigned long long)i);
+            }
         }
         flags[i] = head;
+    }
+}
+
+// TWO ascending stretches of runs (exactly one place where the first key part does not increase, at row `split_row`): the runs
+// before it are distinct, the runs from it on are distinct among themselves, and a later run can only repeat a key of the first
+// stretch — found by binary search over the first stretch's head keys (they ascend), no table.
+//   resolve  head2[r] = head[r] for the first stretch; a later run r: match[r - t0] = the run of the first stretch with its key
+//            (0xFFFFFFFF: none), fresh[r - t0] = 1 when it is a new group                      (t0 = the run of split_row)
+//   (an exclusive scan of `fresh` by the caller)
+//   remap    rows from split_row on: rowslot = the matched run, or t0 + (new groups before the row's run); head2 of the new groups;
+//            *n_groups_out = t0 + new groups
+__global__ void __launch_bounds__(BLOCK)
+run_tail_resolve_kernel(const uint64_t* keys128, const uint32_t* head, const uint64_t* n_runs_dev, const uint32_t* rowslot, uint32_t split_row,
+                        uint64_t first_mask, uint32_t* head2, uint32_t* match, uint32_t* fresh) {
+    const uint32_t n_runs = (uint32_t)*n_runs_dev, t0 = rowslot[split_row];
+    for (uint32_t r = blockIdx.x * BLOCK + threadIdx.x; r < n_runs; r += gridDim.x * BLOCK) {
+        if (r < t0) { head2[r] = head[r]; continue; }
+        const uint32_t h = head[r];
+        const uint64_t k0 = keys128[2ull * h], k1 = keys128[2ull * h + 1], want = k0 & first_mask;
+        uint32_t lo = 0, hi = t0;                                       // first run of the first stretch whose first part is >= want
+        while (lo < hi) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if ((keys128[2ull * head[mid]] & first_mask) < want) lo = mid + 1;
+            else hi = mid;
+        }
+        uint32_t m = 0xFFFFFFFFu;
+        if (lo < t0) {
+            const uint32_t hm = head[lo];
+            if (keys128[2ull * hm] == k0 && keys128[2ull * hm + 1] == k1) m = lo;
+        }
+        match[r - t0] = m;
+        fresh[r - t0] = m == 0xFFFFFFFFu ? 1u : 0u;
+    }
+}
+__global__ void __launch_bounds__(BLOCK)
+run_tail_remap_kernel(const uint32_t* head, const uint64_t* n_runs_dev, uint32_t n_rows, uint32_t split_row, const uint32_t* match,
+                      const uint32_t* fresh_before, uint32_t* rowslot, uint32_t* head2, unsigned long long* n_groups_out) {
+    const uint32_t n_runs = (uint32_t)*n_runs_dev;
+    // (rowslot[split_row] is rewritten below: every thread takes t0 from the run index of the row in front of it)
+    const uint32_t t0 = split_row > 0 ? rowslot[split_row - 1] + 1u : 0u;
+    for (uint32_t i = split_row + blockIdx.x * BLOCK + threadIdx.x; i < n_rows; i += gridDim.x * BLOCK) {
+        const uint32_t r = rowslot[i], t = r - t0, m = match[t];
+        const uint32_t g = m != 0xFFFFFFFFu ? m : t0 + fresh_before[t];
+        rowslot[i] = g;
+        if (m == 0xFFFFFFFFu && head[r] == i) head2[g] = i;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint32_t n_tail = n_runs - t0;
+        *n_groups_out = (unsigned long long)t0 + (n_tail ? fresh_before[n_tail] : 0u);
     }
 }
 
@@ -613,6 +667,18 @@ static unsigned run_grid(const LaunchCfg& cfg, size_t n) {
 hipError_t launch_run_heads(const LaunchCfg& cfg, const uint64_t* keys128, uint32_t n, uint32_t* flags, uint64_t first_mask, uint64_t* not_ascending) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(run_heads_kernel, dim3(run_grid(cfg, n)), dim3(BLOCK), 0, cfg.stream, keys128, n, flags, first_mask, (unsigned long long*)not_ascending);
+    return hipGetLastError();
+}
+hipError_t launch_run_tail_resolve(const LaunchCfg& cfg, const uint64_t* keys128, const uint32_t* head, const uint64_t* n_runs_dev, const uint32_t* rowslot,
+                                   uint32_t n_rows, uint32_t split_row, uint64_t first_mask, uint32_t* head2, uint32_t* match, uint32_t* fresh) {
+    hipLaunchKernelGGL(run_tail_resolve_kernel, dim3(run_grid(cfg, n_rows)), dim3(BLOCK), 0, cfg.stream, keys128, head, n_runs_dev, rowslot, split_row, first_mask,
+                       head2, match, fresh);
+    return hipGetLastError();
+}
+hipError_t launch_run_tail_remap(const LaunchCfg& cfg, const uint32_t* head, const uint64_t* n_runs_dev, uint32_t n_rows, uint32_t split_row, const uint32_t* match,
+                                 const uint32_t* fresh_before, uint32_t* rowslot, uint32_t* head2, uint64_t* n_groups_out) {
+    hipLaunchKernelGGL(run_tail_remap_kernel, dim3(run_grid(cfg, n_rows - split_row)), dim3(BLOCK), 0, cfg.stream, head, n_runs_dev, n_rows, split_row, match,
+                       fresh_before, rowslot, head2, (unsigned long long*)n_groups_out);
     return hipGetLastError();
 }
 hipError_t launch_run_compact(const LaunchCfg& cfg, const HashAggTable& T, const uint32_t* head, uint32_t n_runs, bool nulls, GroupRec* out) {

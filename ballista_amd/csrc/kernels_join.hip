@@ -118,7 +118,10 @@ join_key_stats_kernel(const void* __restrict__ keys_v, const uint64_t* __restric
     }
 }
 
-// sorted, unique build keys -> the key-set bits (32-bit pieces: piece = key offset >> 5)
+// sorted, unique build keys: lanes whose keys fall into the same 32-bit piece of the bitmap are neighbours; the last lane of each
+// run writes the combined bits — with a plain store when the run lies strictly inside the wave (then no other wave holds a key
+// of that piece), with an atomicOr when it touches the wave's first or last lane.  (32-bit pieces: the segmented scan moves two
+// 32-bit values per step instead of two 64-bit ones, and the kernel is bound by those instructions.)
 template <int KW>
 __global__ void __launch_bounds__(BLOCK)
 rank_bits_sorted_kernel(const void* __restrict__ keys_v, uint32_t n, uint64_t kmin, unsigned long long* __restrict__ bits64) {
@@ -127,37 +130,20 @@ rank_bits_sorted_kernel(const void* __restrict__ keys_v, uint32_t n, uint64_t km
     uint32_t* __restrict__ bits = reinterpret_cast<uint32_t*>(bits64);        // little-endian: piece 2w / 2w + 1 = low / high half of word w
     const int lane = threadIdx.x & 63;
     const uint32_t n_round = (n + 63u) & ~63u;
-    // The keys increase strictly: the keys of one 32-bit piece are neighbours.  A key whose two neighbours fall into OTHER pieces is
-    // alone in its piece and writes it with a plain store (a build side that is a filtered dimension table: ~1 key per piece — Q3's
-    // 14.6 M order keys over a 600 M window); a key with a neighbour in its piece ORs its bit in.  Neighbours come from the adjacent
-    // lanes (two shuffles), the wave's edge lanes load theirs.  (r02 combined the bits of a piece with a six-step segmented shuffle
-    // scan — twelve shuffles and as many selects per key — and was bound by exactly those instructions: 125 us for Q3's build side.)
     for (uint32_t row = blockIdx.x * BLOCK + threadIdx.x; row < n_round; row += gridDim.x * BLOCK) {
         const bool in = row < n;
         const uint64_t d = in ? key_offset<KW>(keys[row], kmin) : 0;
         const uint32_t wi = in ? (uint32_t)(d >> 5) : 0xFFFFFFFFu;              // (the window holds <= 2^36 values)
-        uint32_t prev_wi = __shfl_up(wi, 1, 64), next_wi = __shfl_down(wi, 1, 64);
-        if (lane == 0) prev_wi = (in && row > 0) ? (uint32_t)(key_offset<KW>(keys[row - 1], kmin) >> 5) : 0xFFFFFFFFu;
-        if (lane == 63) next_wi = (in && row + 1 < n) ? (uint32_t)(key_offset<KW>(keys[row + 1], kmin) >> 5) : 0xFFFFFFFFu;
         uint32_t m = in ? (1u << (d & 31)) : 0u;
-        const bool shares = in && (prev_wi == wi || next_wi == wi);
-        if (__popcll(__ballot(shares)) <= 48) {                                 // wave-uniform: sparse — most keys alone in their piece
-            if (in) {
-                if (!shares) bits[wi] = m;
-                else atomicOr(&bits[wi], m);
-            }
-            continue;
-        }
-        // dense keys (an unfiltered table: up to 32 keys per piece): combine the bits of a piece inside the wave first — an inclusive
-        // segmented OR over runs of equal wi (runs are contiguous: the keys increase) — and let the last lane of each run write
-        uint32_t wi_s = in ? wi : 0xFFFFFFFEu;
+        // inclusive segmented OR over runs of equal wi (runs are contiguous: the keys increase)
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t pm = __shfl_up(m, off, 64);
-            const uint32_t pw = __shfl_up(wi_s, off, 64);
-            if (lane >= off && pw == wi_s) m |= pm;
+            const uint32_t pw = __shfl_up(wi, off, 64);
+            if (lane >= off && pw == wi) m |= pm;
         }
-        const uint32_t first_wi = __shfl(wi_s, 0, 64);     // outside the branch: every lane takes part in a shuffle
+        const uint32_t next_wi = __shfl_down(wi, 1, 64);
+        const uint32_t first_wi = __shfl(wi, 0, 64);     // outside the branch: every lane takes part in a shuffle
         const bool last_of_run = in && (lane == 63 || next_wi != wi);
         if (last_of_run) {
             const bool touches_edge = lane == 63 || first_wi == wi || row + 1 >= n;
@@ -167,6 +153,9 @@ rank_bits_sorted_kernel(const void* __restrict__ keys_v, uint32_t n, uint64_t km
     }
 }
 
+// (r03 tried "a key whose two neighbours fall into other pieces stores its bit plainly, the others atomicOr" — two shuffles instead of
+// twelve: SLOWER, 0.154 -> 0.207 ms for Q3's 14.6 M keys, 0.085 -> 0.139 ms for Q5's builds: at ~0.8 keys per piece half the keys
+// share a piece and their atomics cost more than the scan saves.  Reverted.)
 // any order: one atomicOr per key; a bit that was already set is a duplicate key
 template <int KW>
 __global__ void __launch_bounds__(BLOCK)

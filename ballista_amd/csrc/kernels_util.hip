@@ -179,39 +179,88 @@ hipError_t exclusive_scan_u32_u32(hipStream_t st, const uint32_t* in, int64_t n,
 // the popcount taken on the fly and the packed word written by the last one: a probe reads ONE 8-byte word per row and has both
 // the membership bit and the rank.
 // =============================================================================================
+// Large maps: a workgroup takes RP_CHUNK granules in rounds of 1024 — every lane one 16-byte load of four consecutive
+// granules, so a wave's load covers 1 KiB contiguous (and its two 16-byte stores of four packed words 2 KiB) — with a running
+// carry; the ranks inside a round come from a 32-bit block scan (a chunk holds < 2^20 keys).  The first version gave every
+// thread 16 consecutive granules: each of its load and store instructions then touched 64 different cache lines, and the
+// 1.5 GB map of an SF1000 order-key build (187 M granules) took 1.44 ms — a third of the rank's whole join leg.
+constexpr int RP_ROUND = SCAN_BLOCK * 4;                 // 1024 granules per round
+constexpr int RP_ROUNDS = 16;
+constexpr int RP_CHUNK = RP_ROUND * RP_ROUNDS;           // 16384 granules = 64 KiB of key-set bits per workgroup
+
+__device__ inline uint32_t block_exclusive_scan_u32(uint32_t v, uint32_t* s_wave, uint32_t* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) s_wave[wave] = x;
+    __syncthreads();
+    uint32_t wave_off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_BLOCK / 64; ++w) {
+        const uint32_t sw = s_wave[w];
+        if (w < wave) wave_off += sw;
+        tot += sw;
+    }
+    __syncthreads();
+    *total = tot;
+    return wave_off + x - v;
+}
+
+__device__ inline uint4 rp_load4(const uint32_t* __restrict__ bits32, int64_t j, int64_t n) {
+    // (the bits buffer is allocated in 64-bit words + 1: a 16-byte load that starts below n may read up to 12 bytes of padding
+    // only when n is not a multiple of 4 — guarded element-wise there)
+    if (j + 4 <= n) return *reinterpret_cast<const uint4*>(bits32 + j);
+    uint4 x = make_uint4(0, 0, 0, 0);
+    if (j < n) x.x = bits32[j];
+    if (j + 1 < n) x.y = bits32[j + 1];
+    if (j + 2 < n) x.z = bits32[j + 2];
+    return x;
+}
+
 __global__ void __launch_bounds__(SCAN_BLOCK)
 rank_pack_sums_kernel(const uint32_t* __restrict__ bits32, int64_t n, uint64_t* __restrict__ chunk_sums) {
-    __shared__ uint64_t s_wave[4];
-    const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK;
-    uint64_t v = 0;
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
-        const int64_t j = base + i * SCAN_BLOCK + threadIdx.x;
-        if (j < n) v += (uint32_t)__popc(bits32[j]);
+    __shared__ uint32_t s_wave[4];
+    const int64_t base = (int64_t)blockIdx.x * RP_CHUNK;
+    uint32_t v = 0;
+#pragma unroll 4
+    for (int r = 0; r < RP_ROUNDS; ++r) {
+        const int64_t j = base + (int64_t)r * RP_ROUND + (int64_t)threadIdx.x * 4;
+        const uint4 x = rp_load4(bits32, j, n);
+        v += (uint32_t)(__popc(x.x) + __popc(x.y) + __popc(x.z) + __popc(x.w));
     }
-    uint64_t tot;
-    block_exclusive_scan(v, s_wave, &tot);
+    uint32_t tot;
+    block_exclusive_scan_u32(v, s_wave, &tot);
     if (threadIdx.x == 0) chunk_sums[blockIdx.x] = tot;
 }
 
 __global__ void __launch_bounds__(SCAN_BLOCK)
 rank_pack_apply_kernel(const uint32_t* __restrict__ bits32, int64_t n, const uint64_t* __restrict__ chunk_offsets, uint64_t* __restrict__ pack) {
-    __shared__ uint64_t s_wave[4];
-    const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK;
-    uint32_t x[SCAN_ITEMS];
-    uint64_t sum = 0;
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
-        const int64_t j = base + (int64_t)threadIdx.x * SCAN_ITEMS + i;
-        x[i] = j < n ? bits32[j] : 0;
-        sum += (uint32_t)__popc(x[i]);
-    }
-    uint64_t run = chunk_offsets[blockIdx.x] + block_exclusive_scan(sum, s_wave, nullptr);
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
-        const int64_t j = base + (int64_t)threadIdx.x * SCAN_ITEMS + i;
-        if (j < n) pack[j] = (uint64_t)x[i] | (run << 32);
-        run += (uint32_t)__popc(x[i]);
+    __shared__ uint32_t s_wave[4];
+    const int64_t base = (int64_t)blockIdx.x * RP_CHUNK;
+    uint64_t carry = chunk_offsets[blockIdx.x];
+    for (int r = 0; r < RP_ROUNDS; ++r) {
+        const int64_t j = base + (int64_t)r * RP_ROUND + (int64_t)threadIdx.x * 4;
+        if (base + (int64_t)r * RP_ROUND >= n) break;                                   // workgroup-uniform
+        const uint4 x = rp_load4(bits32, j, n);
+        const uint32_t c0 = (uint32_t)__popc(x.x), c1 = (uint32_t)__popc(x.y), c2 = (uint32_t)__popc(x.z), c3 = (uint32_t)__popc(x.w);
+        uint32_t tot;
+        const uint64_t run = carry + block_exclusive_scan_u32(c0 + c1 + c2 + c3, s_wave, &tot);
+        const uint64_t p0 = (uint64_t)x.x | (run << 32), p1 = (uint64_t)x.y | ((run + c0) << 32), p2 = (uint64_t)x.z | ((run + c0 + c1) << 32),
+                       p3 = (uint64_t)x.w | ((run + c0 + c1 + c2) << 32);
+        if (j + 4 <= n) {
+            ulonglong2* o = reinterpret_cast<ulonglong2*>(pack + j);
+            o[0] = make_ulonglong2(p0, p1);
+            o[1] = make_ulonglong2(p2, p3);
+        } else {
+            if (j < n) pack[j] = p0;
+            if (j + 1 < n) pack[j + 1] = p1;
+            if (j + 2 < n) pack[j + 2] = p2;
+        }
+        carry += tot;
     }
 }
 
@@ -248,8 +297,8 @@ hipError_t launch_rank_pack(hipStream_t st, const uint32_t* bits32, int64_t n, u
         hipLaunchKernelGGL(rank_pack_one_kernel, dim3(1), dim3(SCAN_BLOCK), 0, st, bits32, n, pack, total_out);
         return hipGetLastError();
     }
-    uint64_t* sums = reinterpret_cast<uint64_t*>(temp);
-    const int64_t n_chunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    uint64_t* sums = reinterpret_cast<uint64_t*>(temp);                   // (exclusive_scan_temp_bytes(n) words: sized for the smaller SCAN_CHUNK)
+    const int64_t n_chunks = (n + RP_CHUNK - 1) / RP_CHUNK;
     hipLaunchKernelGGL(rank_pack_sums_kernel, dim3((unsigned)n_chunks), dim3(SCAN_BLOCK), 0, st, bits32, n, sums);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, st, sums, n_chunks, total_out);
     hipLaunchKernelGGL(rank_pack_apply_kernel, dim3((unsigned)n_chunks), dim3(SCAN_BLOCK), 0, st, bits32, n, (const uint64_t*)sums, pack);

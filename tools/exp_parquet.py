@@ -118,6 +118,9 @@ def main():
                                 "--child", json.dumps(cols or [])], env=env, capture_output=True, text=True)
             if r.returncode != 0:
                 raise SystemExit(r.stdout + r.stderr)
+            for ln in r.stderr.splitlines():
+                if "bhip-parquet" in ln:
+                    print(f"  [{th} threads] {ln}", flush=True)
             d = json.loads(r.stdout.strip().splitlines()[-1])
             d["rows_per_s"] = d["rows"] / d["seconds"]
             d["file_gbs"] = size / d["seconds"] / 1e9 if cols is None else None
