@@ -33,6 +33,11 @@ using namespace pq;
 
 namespace {
 
+// BHIP_PARQUET_TRACE=1: the calling thread's time inside upload_chunk, by kind of work (ms)
+struct UploadTrace { double copies = 0, dict = 0, concat = 0, alloc = 0; };
+static thread_local UploadTrace g_trace;
+static inline double trace_now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 // ---- pinned host blocks for what the walk produces (parquet_host.hpp: HostVec) ---------------------------------------------------
 // Power-of-two size classes from 64 KiB up, kept for the life of the process (bounded: BHIP_PINNED_POOL_MB, default 16 GiB);
 // smaller requests are plain malloc.  A block is faulted in and registered with the device once; the async copies from it do
@@ -95,14 +100,19 @@ void install_pinned_allocator() {
 }
 
 BufferPtr upload(const Exec& ex, const void* host, size_t bytes) {
+    const double t0 = trace_now();
     BufferPtr b = make_buffer(ex, bytes + 16);
+    const double t1 = trace_now();
     if (bytes) HIP_CHECK(hipMemcpyAsync(b->ptr(), host, bytes, hipMemcpyHostToDevice, ex.stream));
+    g_trace.alloc += t1 - t0;
+    g_trace.copies += trace_now() - t1;
     return b;
 }
 
 // the device half: one parsed column chunk -> one device column.  `hc` must stay alive until the stream has caught up
 // (the caller waits once per row group).
-Column upload_chunk(const Exec& ex, const PqColumn& pc, const HostChunk& hc, std::vector<BufferPtr>& keep) {
+Column upload_chunk(const Exec& ex, const PqColumn& pc, const HostChunk& hc, std::vector<BufferPtr>& keep,
+                    std::vector<std::shared_ptr<HostVec<PqRun>>>& held_runs) {
     const bool optional = pc.repetition == 1;
     const size_t width = (pc.phys == PQ_INT32 || pc.phys == PQ_FLOAT) ? 4 : (pc.phys == PQ_INT64 || pc.phys == PQ_DOUBLE) ? 8 : 0;
     const LaunchCfg cfg = ex.cfg();
@@ -117,6 +127,71 @@ Column upload_chunk(const Exec& ex, const PqColumn& pc, const HostChunk& hc, std
         } else {
             dict.data = upload(ex, hc.dict.bytes.data(), hc.dict.bytes.size());
         }
+    }
+    // ---- the whole chunk at once (the common case: no NULLs, every page of one kind) --------------------------------------------------
+    // One page at a time, a lineitem row group costs ~100 pages x (2-4 copy calls + 2-3 launches + a host wait for every string page)
+    // and a concatenation pass per column: the calling thread spent 0.9 s issuing for 0.4 s of kernels (profiles/r03_parquet_scan.txt).
+    // Here a chunk is one set of buffers: page bytes copied behind each other, ONE run table (out_start and byte offsets re-based,
+    // the bit width travels with each run), ONE expansion, ONE gather — one host wait per string column chunk — and PLAIN pages are
+    // copied straight to their rows of the column.
+    bool any_nulls = false, all_dict = !hc.pages.empty(), all_fixed = !hc.pages.empty();
+    int64_t rows_total = 0;
+    size_t bytes_total = 0, runs_total = 0;
+    for (const HostPage& pg : hc.pages) {
+        any_nulls = any_nulls || pg.has_nulls;
+        all_dict = all_dict && pg.kind == PG_DICT;
+        all_fixed = all_fixed && pg.kind == PG_FIXED;
+        rows_total += pg.n;
+        bytes_total += pg.bytes.size();
+        runs_total += pg.runs.size();
+    }
+    static const bool per_page = [] { const char* v = getenv("BHIP_PARQUET_PER_PAGE"); return v && atoi(v) != 0; }();           // A/B: the page-at-a-time path
+    if (!per_page && !any_nulls && hc.pages.size() > 1 && all_fixed && width) {
+        Column c;
+        c.dtype = pc.dtype;
+        c.length = rows_total;
+        const double t0 = trace_now();
+        c.data = make_buffer(ex, width * (size_t)rows_total + 16);
+        int64_t row = 0;
+        for (const HostPage& pg : hc.pages) {
+            if (pg.n) HIP_CHECK(hipMemcpyAsync(c.data->as<uint8_t>() + width * (size_t)row, pg.bytes.data(), width * (size_t)pg.n, hipMemcpyHostToDevice, ex.stream));
+            row += pg.n;
+        }
+        g_trace.copies += trace_now() - t0;
+        return c;
+    }
+    if (!per_page && !any_nulls && hc.pages.size() > 1 && all_dict && bytes_total < 0xFFFFFFF0u && rows_total < 0xFFFFFFF0ll) {
+        const double t0 = trace_now();
+        BufferPtr dbytes = make_buffer(ex, bytes_total + 16);
+        // the run tables, re-based: `runs_all` is pinned (the copy is asynchronous) and kept by the caller's `held_runs` until the stream caught up
+        auto runs_all = std::make_shared<HostVec<PqRun>>();
+        runs_all->reserve(runs_total);
+        size_t byte_base = 0;
+        int64_t row = 0;
+        for (const HostPage& pg : hc.pages) {
+            if (!pg.bytes.empty()) HIP_CHECK(hipMemcpyAsync(dbytes->as<uint8_t>() + byte_base, pg.bytes.data(), pg.bytes.size(), hipMemcpyHostToDevice, ex.stream));
+            for (PqRun r : pg.runs) {
+                r.out_start += (uint32_t)row;
+                if (r.packed) r.value += (uint32_t)byte_base;
+                runs_all->push_back(r);
+            }
+            byte_base += pg.bytes.size();
+            row += pg.n;
+        }
+        held_runs.push_back(runs_all);
+        BufferPtr druns = upload(ex, runs_all->data(), runs_all->size() * sizeof(PqRun));
+        BufferPtr dense = make_buffer(ex, (size_t)rows_total * 4 + 16);
+        keep.push_back(dbytes); keep.push_back(druns); keep.push_back(dense);
+        g_trace.copies += trace_now() - t0;
+        const double t1 = trace_now();
+        TIMED_LAUNCH_N(ex, "pq_expand_runs", rows_total, launch_pq_expand_runs(cfg, druns->as<PqRun>(), (uint32_t)runs_all->size(), dbytes->as<uint8_t>(), 0,
+                                                                               (uint32_t)rows_total, (uint32_t)dict.length, dense->as<uint32_t>()));
+        Column g = take_column(ex, dict, dense->as<uint32_t>(), rows_total);
+        g.dtype = pc.dtype;
+        g.validity = nullptr;
+        g.length = rows_total;
+        g_trace.dict += trace_now() - t1;
+        return g;
     }
     std::vector<Column> pieces;
     for (const HostPage& pg : hc.pages) {
@@ -133,6 +208,7 @@ Column upload_chunk(const Exec& ex, const PqColumn& pc, const HostChunk& hc, std
         if (pg.has_nulls) c.validity = dvalid;
         if (pg.kind == PG_DICT) {
             BufferPtr dbytes = upload(ex, pg.bytes.data(), pg.bytes.size()), druns = upload(ex, pg.runs.data(), pg.runs.size() * sizeof(PqRun));
+            const double td0 = trace_now();
             BufferPtr dense = make_buffer(ex, (size_t)n_valid * 4 + 16);
             keep.push_back(dbytes); keep.push_back(druns); keep.push_back(dense);
             if (n_valid) TIMED_LAUNCH_N(ex, "pq_expand_runs", n_valid, launch_pq_expand_runs(cfg, druns->as<PqRun>(), (uint32_t)pg.runs.size(), dbytes->as<uint8_t>(), pg.bit_width,
@@ -150,6 +226,7 @@ Column upload_chunk(const Exec& ex, const PqColumn& pc, const HostChunk& hc, std
             else g.validity = nullptr;
             c = g;
             c.length = n;
+            g_trace.dict += trace_now() - td0;
         } else if (pg.kind == PG_STRINGS) {
             c.offsets = upload(ex, pg.offsets.data(), pg.offsets.size() * 4);
             c.data = upload(ex, pg.bytes.data(), pg.bytes.size());
@@ -182,7 +259,10 @@ Column upload_chunk(const Exec& ex, const PqColumn& pc, const HostChunk& hc, std
         b->cols.push_back(c);
         parts.push_back(b);
     }
-    return concat_batches(ex, s, parts)->cols[0];
+    const double tc0 = trace_now();
+    Column out = concat_batches(ex, s, parts)->cols[0];
+    g_trace.concat += trace_now() - tc0;
+    return out;
 }
 
 // at most `limit` host walks at once (a row group's chunks + the next row group's, each on its own std::async thread)
@@ -298,6 +378,7 @@ public:
                 b->ctx = ex.ctx;
                 b->n_rows = u.g->num_rows;
                 std::vector<HostChunk> held;                 // host bytes the queued copies read from
+                std::vector<std::shared_ptr<HostVec<PqRun>>> held_runs;
                 std::vector<BufferPtr> keep;                 // device scratch that must outlive the kernels of this row group
                 held.reserve(cur.size());
                 try {
@@ -307,7 +388,7 @@ public:
                         held.push_back(cur[j].get());
                         double t1 = now();
                         t_walk += t1 - t0;
-                        Column col = upload_chunk(ex, pc, held.back(), keep);
+                        Column col = upload_chunk(ex, pc, held.back(), keep, held_runs);
                         t_issue += now() - t1;
                         if (pc.out_dtype != pc.dtype) {                                   // Int32 values of an INT_8 .. UINT_16 column
                             Column narrow = col;
@@ -332,8 +413,12 @@ public:
                 }
                 out.push_back(b);
             }
-            if (trace) fprintf(stderr, "[bhip-parquet] partition %d: %zu row groups; calling thread waited %.1f ms for host walks, %.1f ms issuing copies and launches, %.1f ms for the device\n",
-                               partition, units.size(), t_walk, t_issue, t_dev);
+            if (trace) {
+                fprintf(stderr, "[bhip-parquet] partition %d: %zu row groups; calling thread waited %.1f ms for host walks, %.1f ms issuing copies and launches "
+                                "(buffer allocation %.1f, copy calls %.1f, dictionary expand + gather %.1f, page concatenation %.1f), %.1f ms for the device\n",
+                        partition, units.size(), t_walk, t_issue, g_trace.alloc, g_trace.copies, g_trace.dict, g_trace.concat, t_dev);
+                g_trace = UploadTrace{};
+            }
             return out;
         }));
     }

@@ -352,8 +352,9 @@ void parse_runs(const uint8_t* base, const uint8_t* p, const uint8_t* end, int b
             // the last group of a page may be cut short by the writer, but never inside the values the page still needs
             const int64_t needed = ((int64_t)r.count * bit_width + 7) / 8;
             if ((int64_t)(end - p) < needed) fail(BHIP_EEXEC, "Parquet: truncated bit-packed run");
-            r.packed = 1;
+            r.packed = (uint32_t)bit_width;              // (width 0 — a one-entry dictionary — is an RLE run of index 0: below)
             r.value = (uint32_t)(p - base);              // byte offset of the run's bits
+            if (bit_width == 0) r.value = 0;
             p += std::min<int64_t>(bytes, end - p);
         } else {
             const int64_t cnt = (int64_t)(h >> 1);

@@ -870,7 +870,7 @@ pack_buffers_kernel(PackDesc d, uint8_t* out) {
 }
 // ---- Parquet value decode -------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(BLOCK)
-pq_expand_runs_kernel(const PqRun* __restrict__ runs, uint32_t n_runs, const uint8_t* __restrict__ page, int bw, uint32_t n_values,
+pq_expand_runs_kernel(const PqRun* __restrict__ runs, uint32_t n_runs, const uint8_t* __restrict__ page, int /*bit width: per run*/, uint32_t n_values,
                       uint32_t limit, uint32_t* __restrict__ out) {
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n_values; i += gridDim.x * BLOCK) {
         uint32_t lo = 0, hi = n_runs;                   // last run with out_start <= i
@@ -882,6 +882,7 @@ pq_expand_runs_kernel(const PqRun* __restrict__ runs, uint32_t n_runs, const uin
         uint32_t v;
         if (!r.packed) v = r.value;
         else {
+            const int bw = (int)r.packed;                 // the run's own width (pages of one chunk differ as the dictionary grows)
             const uint64_t bit = (uint64_t)(i - r.out_start) * (uint64_t)bw;
             const uint8_t* p = page + r.value + (bit >> 3);
             uint64_t w = 0;                              // up to 32 + 7 bits

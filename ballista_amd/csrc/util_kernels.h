@@ -84,10 +84,11 @@ struct PackDesc {
 struct PqRun {
     uint32_t out_start;     // index of the run's first value in the page
     uint32_t count;
-    uint32_t packed;        // 1: bit-packed, `value` = byte offset of the run's bits in the page; 0: RLE, `value` = the repeated value
+    uint32_t packed;        // > 0: bit-packed at `packed` bits per value, `value` = byte offset of the run's bits in the page bytes; 0: RLE, `value` = the repeated value
     uint32_t value;
 };
-// out[i] = i-th value of the page (one thread per value: binary search of its run, bit extraction); values >= limit
+// out[i] = i-th value of the run table (one thread per value: binary search of its run, bit extraction at the run's own width — the
+// pages of a column chunk go through ONE launch even though the index width grows with the dictionary); values >= limit
 // (a dictionary index outside the dictionary: a corrupt page) are clamped to 0xFFFFFFFF
 hipError_t launch_pq_expand_runs(const LaunchCfg& cfg, const PqRun* runs, uint32_t n_runs, const uint8_t* page, int bit_width, uint32_t n_values,
                                  uint32_t limit, uint32_t* out);

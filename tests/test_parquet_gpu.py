@@ -71,6 +71,26 @@ def test_writer_variants(ctx, tmp_path, compression, use_dictionary, page_versio
     same(got, t)
 
 
+@pytest.mark.parametrize("compression", ["NONE", "SNAPPY"])
+@pytest.mark.parametrize("page_version", ["1.0", "2.0"])
+def test_many_pages_per_chunk_without_nulls_go_through_one_launch(ctx, tmp_path, compression, page_version):
+    """a NULL-free column chunk of many pages is decoded as ONE set of buffers (parquet.cpp upload_chunk): the pages' run tables are
+    re-based into one, every run carries its own bit width — `grow`'s dictionary grows from page to page, so its index width does —
+    PLAIN pages (the dictionary of `f64` and `u` overflows) are copied to their rows of the column, a string column waits for the
+    host once per chunk"""
+    n = 60_000
+    t = table(n, seed=21, nulls=False)
+    t = t.append_column("grow", pa.array((np.arange(n) // 7).astype(np.int32)))           # distinct values keep appearing: widths 1 .. 14 bits
+    t = t.append_column("one", pa.array(np.full(n, 42, np.int64)))                        # a one-entry dictionary: index width 0
+    path = str(tmp_path / "t.parquet")
+    pq.write_table(t, path, compression=compression, use_dictionary=True, data_page_version=page_version, row_group_size=25_000, data_page_size=8 * 1024,
+                   dictionary_pagesize_limit=64 * 1024)
+    md = pq.ParquetFile(path).metadata
+    assert md.num_row_groups == 3
+    plan, got = read_back(ctx, [path])
+    same(got, t)
+
+
 def test_projection_partitions_and_no_nulls(ctx, tmp_path):
     paths = []
     parts = []

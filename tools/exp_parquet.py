@@ -22,7 +22,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("BHIP_KERNEL_TIMING", "2")
+os.environ.setdefault("BHIP_KERNEL_TIMING", os.environ.get("EXP_PARQUET_TIMING", "2"))
 
 Q1_COLS = ["l_quantity", "l_extendedprice", "l_discount", "l_tax", "l_returnflag", "l_linestatus", "l_shipdate"]
 
