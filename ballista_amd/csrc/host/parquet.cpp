@@ -17,6 +17,7 @@
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <fstream>
 #include <future>
 #include <map>
@@ -363,15 +364,20 @@ public:
                 return fs;
             };
             std::vector<BatchPtr> out;
-            Parsed next;
             // BHIP_PARQUET_TRACE=1: where the calling thread's time goes, per partition (stderr)
             static const bool trace = [] { const char* v = getenv("BHIP_PARQUET_TRACE"); return v && atoi(v) != 0; }();
             double t_walk = 0, t_issue = 0, t_dev = 0;
             auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-            if (!units.empty()) next = start(units[0]);
+            // the host walks run AHEAD row groups in front of the device half (default 2: a row group has about as many chunks as
+            // columns, and two of them keep sixteen walkers busy; every group in flight holds its decoded pages in pinned memory)
+            static const size_t ahead = [] { const char* v = getenv("BHIP_PARQUET_AHEAD"); const int a = v ? atoi(v) : 2; return (size_t)(a < 1 ? 1 : a > 8 ? 8 : a); }();
+            std::deque<Parsed> inflight;
+            size_t started = 0;
+            for (; started < units.size() && started < ahead; ++started) inflight.push_back(start(units[started]));
             for (size_t k = 0; k < units.size(); ++k) {
-                Parsed cur = std::move(next);
-                if (k + 1 < units.size()) next = start(units[k + 1]);
+                Parsed cur = std::move(inflight.front());
+                inflight.pop_front();
+                if (started < units.size()) inflight.push_back(start(units[started++]));
                 const Unit& u = units[k];
                 auto b = std::make_shared<Batch>();
                 b->schema = self->schema_;
@@ -402,7 +408,7 @@ public:
                 } catch (...) {
                     // the walks still running hold pointers into this partition's footers: let them finish before unwinding
                     for (auto& f : cur) if (f.valid()) f.wait();
-                    for (auto& f : next) if (f.valid()) f.wait();
+                    for (auto& fs : inflight) for (auto& f : fs) if (f.valid()) f.wait();
                     hipStreamSynchronize(ex.stream);
                     throw;
                 }
