@@ -135,6 +135,8 @@ struct NarrowJoinTable {
     // low half) | the number of build keys before the granule (high half): ONE 8-byte read gives a probe row its membership bit and
     // its rank; rank -> build row through rperm (null: the build side is sorted by key, rank = row)
     const uint64_t* rpack;
+    // the key-set words alone, rbits[g] = low half of rpack[g] (null: not kept — a window beyond 2^31 values): what a semi-join reads
+    const uint32_t* rbits;
     uint32_t rzero;           // index of an all-zero granule behind the map (rows that need no lookup read it)
     const uint32_t* rperm;
     // two-column join whose build side is unique on the first column: second key of every build row (null: one-column join)

@@ -201,7 +201,14 @@ GroupRec* hash_aggregate(const Exec& ex, Temp& tmp, const ScanParams& P0, const 
     T.keys128 = keys;
     MergeAccKinds kinds;
     for (int i = 0; i < VM_MAX_ACC; ++i) kinds.kind[i] = i < P0.n_acc ? P0.acc[i].kind : (uint8_t)ACC_COUNT_ROWS;
-    HIP_CHECK(hipMemsetAsync(status, 0, sizeof(ScanStatus), ex.stream));
+    uint64_t* tail = tmp.get<uint64_t>(2);          // [0] the group count, [1] the spill list's entry count | "lists too long" << 32: read in one piece
+    {
+        FillMany fm;
+        static_assert(sizeof(ScanStatus) % 4 == 0, "cleared word-wise");
+        fm.add(status, sizeof(ScanStatus));
+        fm.add(tail, 16);
+        TIMED_LAUNCH(ex, "fill_many", launch_fill_many(cfg, fm));
+    }
     // SUM(Float64) accumulators are summed in row order after the scan (kernels_dagg.hip); BHIP_AGG_ATOMIC=1: atomic adds
     // (order of addition left to the scheduler: the same sums to ~1e-16 relative, not bit for bit)
     static const bool atomic_sums = [] { const char* v = getenv("BHIP_AGG_ATOMIC"); return v && atoi(v) != 0; }();
@@ -237,8 +244,6 @@ GroupRec* hash_aggregate(const Exec& ex, Temp& tmp, const ScanParams& P0, const 
     int distinct_runs = 0;
     uint32_t* run_head = nullptr;
     uint64_t n_runs_host = 0;
-    uint64_t* tail = tmp.get<uint64_t>(2);          // [0] the group count, [1] the spill list's entry count | "lists too long" << 32: read in one piece
-    HIP_CHECK(hipMemsetAsync(tail, 0, 16, ex.stream));
     if (!no_runs && P0.pred_slot < 0 && total_rows >= 4096 && clustered_hint->load() >= 0) {
         uint32_t* flags = tmp.get<uint32_t>((size_t)total_rows + 1);
         uint32_t* before = tmp.get<uint32_t>((size_t)total_rows + 1);
@@ -307,6 +312,7 @@ GroupRec* hash_aggregate(const Exec& ex, Temp& tmp, const ScanParams& P0, const 
     }
 
     uint64_t cap;
+    bool table_owner = false;
     if (runs) {
         // the slot space is the space of runs: at most one per row (unused ones stay empty); exactly the runs when they are distinct
         cap = distinct_runs ? std::max<uint64_t>(n_runs_host, 1) : (uint64_t)total_rows;
@@ -318,13 +324,26 @@ GroupRec* hash_aggregate(const Exec& ex, Temp& tmp, const ScanParams& P0, const 
         while (cap < 2ull * (uint64_t)total_rows) cap <<= 1;
         T.mask = cap - 1;
         T.owner = tmp.get<uint32_t>(cap);
-        HIP_CHECK(hipMemsetAsync(T.owner, 0, cap * 4, ex.stream));
+        table_owner = true;
     }
     T.acc = tmp.get<uint64_t>(cap * n_acc);
     T.rows = tmp.get<uint64_t>(cap);
     if (nullable) T.nvalid = tmp.get<uint64_t>(cap * n_acc);
-    HIP_CHECK(hipMemsetAsync(T.rows, 0, cap * 8, ex.stream));
-    if (nullable) HIP_CHECK(hipMemsetAsync(T.nvalid, 0, cap * n_acc * 8, ex.stream));
+    if (T.n_fsum) {
+        D.runs = tmp.get<uint32_t>(cap);
+        D.spill_head = tmp.get<uint32_t>(cap);
+    }
+    {
+        FillMany fm;                                 // everything the scan and the ordered sums expect cleared, one launch
+        if (table_owner) fm.add(T.owner, cap * 4);       // (the run paths filled theirs)
+        fm.add(T.rows, cap * 8);
+        if (nullable) fm.add(T.nvalid, cap * n_acc * 8);
+        if (T.n_fsum) {
+            fm.add(D.runs, cap * 4);
+            fm.add(D.spill_head, cap * 4, 0xFFFFFFFFu);
+        }
+        TIMED_LAUNCH(ex, "fill_many", launch_fill_many(cfg, fm));
+    }
     if (P0.n_acc > 0) TIMED_LAUNCH(ex, "hash_agg_init", launch_hash_agg_init(cfg, T, kinds));
 
     uint32_t row_base = 0;
@@ -345,17 +364,13 @@ GroupRec* hash_aggregate(const Exec& ex, Temp& tmp, const ScanParams& P0, const 
         D.seg_first = tmp.get<uint32_t>(stage_n);
         D.seg_sum = tmp.get<double>(stage_n * T.n_fsum);
         D.tile_nseg = tmp.get<uint32_t>(n_tiles);
-        D.runs = tmp.get<uint32_t>(cap);
         D.acc = T.acc;
         D.rows = T.rows;
         D.spill_key = tmp.get<uint64_t>(stage_n);
         D.spill_seg = tmp.get<uint32_t>(stage_n);
         D.spill_count = reinterpret_cast<uint32_t*>(tail + 1);
         D.spill_next = tmp.get<uint32_t>(stage_n);
-        D.spill_head = tmp.get<uint32_t>(cap);
-        HIP_CHECK(hipMemsetAsync(D.runs, 0, cap * 4, ex.stream));
-        HIP_CHECK(hipMemsetAsync(D.spill_head, 0xFF, cap * 4, ex.stream));
-        HIP_CHECK(hipMemsetAsync(D.spill_count, 0, 8, ex.stream));
+        // (D.runs, D.spill_head and the spill count — the second word of `tail` — were cleared above)
         TIMED_LAUNCH_N(ex, "det_segments", total_rows, launch_det_segments(cfg, D));
         TIMED_LAUNCH_N(ex, "det_apply", total_rows, launch_det_apply(cfg, D));
         // groups with several runs: combined through their lists right here; the entry count and the "lists too long" flag are

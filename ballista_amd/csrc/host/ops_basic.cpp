@@ -350,8 +350,31 @@ int64_t filter_indices(const Exec& ex, const Batch& in, const ExprPtr& predicate
     // AND of column-vs-literal comparisons over NULL-free numeric columns: the wide-load range kernel
     // (kernels_range.hip) writes the same bitmap + tile counts as the expression VM
     static const bool range_disabled = [] { const char* v = getenv("BHIP_NO_RANGE_FILTER"); return v && atoi(v) != 0; }();
+    // Utf8 column = / != literal (Q3's c_mktsegment = 'BUILDING'): offsets, the length test, the bytes — no interpreter
+    static const bool utf8_eq_disabled = [] { const char* v = getenv("BHIP_NO_UTF8_EQ_FILTER"); return v && atoi(v) != 0; }();
+    const Column* str_col = nullptr;
+    Utf8Literal str_lit;
+    bool str_negate = false;
+    if (!utf8_eq_disabled && predicate->kind == BHIP_EXPR_BINARY && (predicate->name == "Eq" || predicate->name == "NotEq") && predicate->args.size() == 2) {
+        ExprPtr a = predicate->args[0], b = predicate->args[1];
+        if (a->kind == BHIP_EXPR_LITERAL) std::swap(a, b);
+        if (a->kind == BHIP_EXPR_COLUMN && b->kind == BHIP_EXPR_LITERAL && b->dtype == DT_UTF8 && !b->is_null && b->name.size() <= sizeof(str_lit.bytes)) {
+            const int ci = in.schema->index_of(a->name);
+            if (ci >= 0 && in.cols[ci].dtype == DT_UTF8 && !in.cols[ci].is_view()) {
+                str_col = &in.cols[ci];
+                memset(&str_lit, 0, sizeof(str_lit));
+                memcpy(str_lit.bytes, b->name.data(), b->name.size());
+                str_lit.len = (int32_t)b->name.size();
+                str_negate = predicate->name == "NotEq";
+            }
+        }
+    }
     SopPlan rp;
-    if (!range_disabled && build_sop(*in.schema, predicate, {}, {}, rp) && rp.prog.n_ranges >= 1 && sop_columns_bindable(rp, in, true) &&
+    if (str_col) {
+        TIMED_LAUNCH_N(ex, "utf8_eq_bitmap", n, launch_utf8_eq_bitmap(ex.cfg(), str_col->offsets->as<int32_t>(), str_col->data->ptr(),
+                                                                    str_col->validity ? str_col->validity->as<uint64_t>() : nullptr, n, str_lit, str_negate,
+                                                                    bitmap, tile_counts));
+    } else if (!range_disabled && build_sop(*in.schema, predicate, {}, {}, rp) && rp.prog.n_ranges >= 1 && sop_columns_bindable(rp, in, true) &&
         lean_bindable(rp, in)) {
         bind_sop(rp, in);
         TIMED_LAUNCH_N(ex, "range_bitmap", n, launch_range_bitmap(ex.cfg(), rp.prog, tmp.get<SopProgram>(1), bitmap, tile_counts));

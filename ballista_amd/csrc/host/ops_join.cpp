@@ -24,7 +24,7 @@ struct JoinBuildSide {
     bool unique = false;            // no two build rows share a key: probe rows have at most one partner
     bool narrow = false;            // ONE integer key, unique: NarrowJoinTable instead of JoinTable
     int narrow_width = 0;           // its key bytes (4: Int32 / Date32, 8: Int64 / UInt64)
-    BufferPtr slots, present, rpack, rperm;
+    BufferPtr slots, present, rpack, rbits, rperm;
     NarrowJoinTable ntable;
     Column key_holder;              // two-column join: the key column built for it (packed pair, or the first key with both validities)
     bool resid = false;             // two-column join by the first key; the second is compared on every match (ntable.resid_build)
@@ -264,13 +264,17 @@ std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) co
         memset(&bs->ntable, 0, sizeof(bs->ntable));
         bs->narrow_width = nkw;
         bs->dup = make_buffer(ex, 8);
-        HIP_CHECK(hipMemsetAsync(bs->dup->ptr(), 0, 8, ex.stream));
         // one pass: min / max / "strictly increasing"
         Temp tmp(ex);
         uint64_t* stats = tmp.get<uint64_t>(3);
-        const uint64_t seed[3] = {~0ull, 0ull, 0ull};
         struct Stats3 { uint64_t v[3]; };
-        HIP_CHECK(hipMemcpyAsync(stats, seed, sizeof(seed), hipMemcpyHostToDevice, ex.stream));
+        {
+            FillMany fm;                                         // the duplicate flag and the seed {~0, 0, 0} of the statistics: one launch
+            fm.add(bs->dup->ptr(), 8);
+            fm.add(stats, 8, 0xFFFFFFFFu);
+            fm.add(stats + 1, 16);
+            TIMED_LAUNCH(ex, "fill_many", launch_fill_many(ex.cfg(), fm));
+        }
         TIMED_LAUNCH_N(ex, "join_key_stats", n, launch_join_key_stats(ex.cfg(), kc.data->ptr(), nkw, ksel, (uint32_t)n, stats));
         const Stats3 back = read_device(ex, reinterpret_cast<const Stats3*>(stats));        // one pinned-slot read, no staged copy
         const uint64_t* host_stats = back.v;
@@ -289,10 +293,17 @@ std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) co
         if (window_ok && !force_table) {
             // ---- rank map ----------------------------------------------------------------------------------------------
             const int64_t n_words = (int64_t)(range >> 6) + 1, n_gran = 2 * n_words;
-            uint64_t* bits = tmp.get<uint64_t>((size_t)n_words + 1);
+            // the key-set words outlive the build when they are small (<= 256 MiB: windows up to 2^31 values): semi-joins probe them
+            const bool keep_bits = (size_t)n_words * 8 <= ((size_t)256 << 20);
+            if (keep_bits) bs->rbits = make_buffer(ex, ((size_t)n_words + 2) * 8);
+            uint64_t* bits = keep_bits ? bs->rbits->as<uint64_t>() : tmp.get<uint64_t>((size_t)n_words + 2);
             bs->rpack = make_buffer(ex, (size_t)n_gran * 8 + 16);
-            HIP_CHECK(hipMemsetAsync(bs->rpack->as<uint64_t>() + n_gran, 0, 8, ex.stream));        // NarrowJoinTable::rzero
-            HIP_CHECK(hipMemsetAsync(bits, 0, (size_t)n_words * 8, ex.stream));
+            {
+                FillMany fm;
+                fm.add(bs->rpack->as<uint64_t>() + n_gran, 8);         // NarrowJoinTable::rzero
+                fm.add(bits, ((size_t)n_words + 2) * 8);               // the key set, and the granules at and behind `rzero`
+                TIMED_LAUNCH(ex, "fill_many", launch_fill_many(ex.cfg(), fm));
+            }
             TIMED_LAUNCH_N(ex, sorted ? "rank_bits_sorted" : "rank_bits_any", n,
                            launch_rank_bits(ex.cfg(), kc.data->ptr(), nkw, ksel, (uint32_t)n, kmin, sorted, bits, bs->dup->as<uint32_t>()));
             void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes(n_gran));
@@ -310,6 +321,7 @@ std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) co
             if (!dup) {
                 stream_wait(ex);                 // other tasks (other streams) read the map: complete before it is published
                 bs->ntable.rpack = bs->rpack->as<uint64_t>();
+                bs->ntable.rbits = bs->rbits ? bs->rbits->as<uint32_t>() : nullptr;
                 bs->ntable.rzero = (uint32_t)n_gran;
                 bs->ntable.rperm = bs->rperm ? bs->rperm->as<uint32_t>() : nullptr;
                 bs->ntable.krange64 = range;
@@ -325,6 +337,7 @@ std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) co
                 return true;
             }
             bs->rpack.reset();
+            bs->rbits.reset();
         } else {
             // ---- CAS table (sparse keys), with the key set as a bitmap in front of it when the window allows -------------
             const size_t slot_bytes = nkw == 4 ? 8 : 16;

@@ -136,6 +136,36 @@ BufferPtr sort_permutation(const Exec& ex, const Batch& batch, const std::vector
     const Batch* in = &batch;
     const int64_t n = batch.n_rows;
     const LaunchCfg cfg = ex.cfg();
+    // mid-sized inputs under fixed-width keys: one split + ranks inside the bins (kernels_sort.hip: bucket_sort); a bin that overflows
+    // (the leading differing bits repeat heavily) falls through to the LSD passes below, which are few exactly then
+    static const bool no_bucket = [] { const char* v = getenv("BHIP_NO_BUCKET_SORT"); return v && atoi(v) != 0; }();
+    if (!no_bucket && n > small_sort_max() && n <= bucket_sort_max_rows()) {
+        BucketSortKeys K;
+        memset(&K, 0, sizeof(K));
+        std::vector<Column> key_cols;                          // keeps computed key columns alive until the launches are queued
+        bool fits = true;
+        for (const SortDesc& sd : exprs) {
+            key_cols.push_back(evaluate_column(ex, *in, sd.expr));
+            const Column& col = key_cols.back();
+            const int words = col.validity ? 2 : 1;
+            if (col.dtype == DT_UTF8 || K.n_words + words > BSORT_MAX_WORDS) { fits = false; break; }
+            if (col.validity) {
+                K.col[K.n_words] = col.ref(); K.null_rank[K.n_words] = 1; K.nulls_first[K.n_words] = sd.nulls_first ? 1 : 0;
+                ++K.n_words;
+            }
+            K.col[K.n_words] = col.ref(); K.desc[K.n_words] = sd.descending ? 1 : 0;
+            ++K.n_words;
+        }
+        if (fits) {
+            BufferPtr perm = make_buffer(ex, (size_t)n * 4 + 8);
+            Temp tmp(ex);
+            void* temp = tmp.get<uint8_t>(bucket_sort_temp_bytes(n, K.n_words));
+            uint32_t* status_dev = nullptr;
+            TIMED_LAUNCH_N(ex, "bucket_sort", n, bucket_sort(cfg, K, n, temp, perm->as<uint32_t>(), &status_dev));
+            if (read_device(ex, status_dev) == 0) return perm;
+            trace_point("sort: a bucket overflowed, LSD passes instead");
+        }
+    }
     {
         BufferPtr perm = make_buffer(ex, (size_t)n * 4 + 8);
         BufferPtr keys = make_buffer(ex, (size_t)n * 8 + 8);

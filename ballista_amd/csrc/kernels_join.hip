@@ -399,7 +399,10 @@ join_filter_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const voi
 // MAPBUF: the packed map is shorter than 2 GiB (windows up to 2^33 key values: every join of TPC-H up to SF1000 with dense keys,
 // SF300 with dbgen's sparse ones): it is read through a buffer descriptor too, and the descriptor's range check IS the window
 // test and the "dropped rows read zeros" rule — an offset past the map's last granule returns 0 without touching memory.
-template <int KW, int NF, int FP_ROWS, bool RESID, bool PERM, bool MAPBUF>
+// BITS: a semi-join (no build column is read: nothing is staged, no rank is ever computed) against a sorted one-column build side reads
+// the key-set words themselves (NarrowJoinTable::rbits, 4 bytes per 32 key values) — half the packed map: Q3's customers, 15 M key
+// values, are 1.9 MB instead of 3.75 MB against the 4 MB of L2 an XCD has, under 150 M random lookups.
+template <int KW, int NF, int FP_ROWS, bool RESID, bool PERM, bool MAPBUF, bool BITS = false>
 __global__ void __launch_bounds__(BLOCK)
 join_rank_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void* __restrict__ rkeys_v, uint32_t n_right,
                        uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts, uint32_t* __restrict__ staging,
@@ -471,7 +474,8 @@ join_rank_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void*
         if (have && F.hi[j] < F.lo[j]) alive = 0u;
     }
     // granules [0, rzero) of the map (the host only picks MAPBUF when rzero * 8 < 2^31)
-    const auto rmap = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(rpack), 0, MAPBUF ? (int)(T.rzero * 8u) : 0, 0x00020000);
+    const auto rmap = BITS ? __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(T.rbits), 0, (int)(T.rzero * 4u), 0x00020000)
+                           : __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(rpack), 0, MAPBUF ? (int)(T.rzero * 8u) : 0, 0x00020000);
     Regs cur, nxt;
     if (wave_id < n_tiles) load_any(wave_id * SEL_TILE, cur);
     for (uint32_t t = wave_id; t < n_tiles; t += n_waves) {
@@ -506,7 +510,11 @@ join_rank_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void*
                 // a row the filter dropped, or whose key lies outside the window, reads an all-zero granule: the bit test below is
                 // then the whole decision — ONE compare, whose lane mask is the ballot (a ballot of an AND of conditions costs two
                 // more vector instructions per row slot)
-                if constexpr (MAPBUF) {
+                if constexpr (BITS) {
+                    if (KW == 8) ok &= (uint32_t)((off >> 34) == 0);
+                    const uint32_t voff = (uint32_t)(off >> 3) & ~3u;                  // (off >> 5) * 4
+                    pk[k] = __builtin_amdgcn_raw_buffer_load_b32(rmap, (int)(ok ? voff : 0xFFFFFFFCu), 0, 0);
+                } else if constexpr (MAPBUF) {
                     // byte offset of the granule's word = (off >> 5) * 8 = (off >> 2) & ~7: 32 bits hold it for offsets below 2^34 (the
                     // map is shorter than 2 GiB: its window ends below 2^33); 8-byte keys beyond that must not wrap into the map
                     if (KW == 8) ok &= (uint32_t)((off >> 34) == 0);
@@ -688,6 +696,25 @@ hipError_t launch_rank_perm(const LaunchCfg& cfg, const void* keys, int key_widt
     return hipGetLastError();
 }
 
+template <int KW, int NF, int ROWS, bool RESID, bool PERM>
+static void launch_rank_probe(hipStream_t st, unsigned grid, bool map_buf, bool bits_only, const NarrowJoinTable& T, const ProbeFilter& F, const void* rkeys,
+                              uint32_t n_right, uint64_t* bitmap, uint32_t* tile_counts, uint32_t* staging, const uint32_t* resid_probe,
+                              uint32_t* staging_rows) {
+    if constexpr (!RESID && !PERM) {
+        if (bits_only) {
+            hipLaunchKernelGGL((join_rank_probe_kernel<KW, NF, ROWS, false, false, true, true>), dim3(grid), dim3(BLOCK), 0, st, T, F, rkeys, n_right, bitmap,
+                               tile_counts, staging, resid_probe, staging_rows);
+            return;
+        }
+    }
+    if (map_buf)
+        hipLaunchKernelGGL((join_rank_probe_kernel<KW, NF, ROWS, RESID, PERM, true>), dim3(grid), dim3(BLOCK), 0, st, T, F, rkeys, n_right, bitmap, tile_counts,
+                           staging, resid_probe, staging_rows);
+    else
+        hipLaunchKernelGGL((join_rank_probe_kernel<KW, NF, ROWS, RESID, PERM, false>), dim3(grid), dim3(BLOCK), 0, st, T, F, rkeys, n_right, bitmap, tile_counts,
+                           staging, resid_probe, staging_rows);
+}
+
 hipError_t launch_join_filter_probe(const LaunchCfg& cfg, const NarrowJoinTable& T, const ProbeFilter& F, const void* rkeys, int key_width,
                                     const uint64_t* rsel, uint32_t n_right, bool right_outer, uint64_t* bitmap, uint32_t* tile_counts,
                                     uint32_t* staging, uint32_t* matched, const uint32_t* resid_probe, uint32_t* staging_rows) {
@@ -705,15 +732,12 @@ hipError_t launch_join_filter_probe(const LaunchCfg& cfg, const NarrowJoinTable&
     // the packed map through a buffer descriptor when its granules fit one (BHIP_PROBE_MAP_FLAT=1: the flat-load variant, the A/B partner)
     static const bool map_flat = [] { const char* v = getenv("BHIP_PROBE_MAP_FLAT"); return v && atoi(v) != 0; }();
     const bool map_buf = !map_flat && T.rpack != nullptr && (uint64_t)T.rzero * 8u < 0x7FFFFFF0ull;
+    // nothing staged (a semi-join), sorted one-column build side: the key-set words alone (BHIP_PROBE_NO_BITS=1: the packed map, the A/B partner)
+    static const bool no_bits = [] { const char* v = getenv("BHIP_PROBE_NO_BITS"); return v && atoi(v) != 0; }();
+    const bool bits_only = !no_bits && map_buf && T.rbits != nullptr && staging == nullptr && T.rperm == nullptr && resid_probe == nullptr;
 #define BHIP_PROBE_R(KW_, NF_, ROWS_, RESID_, PERM_)                                                                                  \
-    do {                                                                                                                              \
-        if (map_buf)                                                                                                                  \
-            hipLaunchKernelGGL((join_rank_probe_kernel<KW_, NF_, ROWS_, RESID_, PERM_, true>), dim3((unsigned)grid), dim3(BLOCK), 0, cfg.stream, T, F, \
-                               rkeys, n_right, bitmap, tile_counts, staging, resid_probe, staging_rows);                              \
-        else                                                                                                                          \
-            hipLaunchKernelGGL((join_rank_probe_kernel<KW_, NF_, ROWS_, RESID_, PERM_, false>), dim3((unsigned)grid), dim3(BLOCK), 0, cfg.stream, T, F, \
-                               rkeys, n_right, bitmap, tile_counts, staging, resid_probe, staging_rows);                              \
-    } while (0)
+    launch_rank_probe<KW_, NF_, ROWS_, RESID_, PERM_>(cfg.stream, (unsigned)grid, map_buf, bits_only, T, F, rkeys, n_right, bitmap, tile_counts, staging, \
+                                                      resid_probe, staging_rows)
 #define BHIP_PROBE_L(KW_, NF_, RESID_)                                                                                                \
     do {                                                                                                                              \
         if (direct && T.rperm) BHIP_PROBE_R(KW_, NF_, 4, RESID_, true);                                                               \

@@ -362,6 +362,224 @@ sort_key_fixed_kernel(ColumnRef c, const uint32_t* perm, int64_t n, int descendi
     }
 }
 
+static int sgrid(const LaunchCfg& cfg, int64_t n);
+
+// ---- mid-sized inputs: ONE split on the most significant DIFFERING bits of the composite key, then ranks inside the (tiny) bins -----
+// (the result of a high-cardinality aggregate — TPC-H Q3 sorts 1.13 M groups by revenue DESC, o_orderdate: the LSD path is 15 passes
+// x 5 launches for them, ~40 us each however few rows there are.)  The composite key of a row = its WORDS, most significant first:
+// per sort expression an optional NULL-rank word (the column has a validity bitmap) and the value's order-preserving image
+// (sort_key_fixed_kernel's, 0 for NULL rows) — unsigned lexicographic order of the words, ties by row number, IS the order the
+// stable LSD passes produce.  Bits that are the same in every row carry no order, so the split digit is made of the highest
+// bits that differ somewhere (log2(n) of them, 12 .. 20: about one bin per row, since images of floats leave most exponent patterns
+// unused — Q3's revenues spend 5 of the bits on exponents, a third of the rows sit in one octave; a low-cardinality first key gives
+// its few bits and the digit continues at the top of the next word).  Rows are dropped into their digit's bin through an atomic
+// cursor (any order: the row number in the comparison makes the result unique); a row's place inside its bin = the number of the
+// bin's rows that sort before it, counted by comparing with each (bins hold a handful of rows; a first version sorted segments of
+// bins with a bitonic network in LDS: 0.48 ms for Q3's groups, all of it LDS traffic of 28-byte records through 66 exchange steps).
+// A bin larger than BSORT_BIN_MAX rows (heavily repeated leading bits: NULLs, a few distinct values) raises `status` and the caller
+// falls back to the LSD passes, which are short exactly then.
+constexpr int BSORT_MIN_BITS = 12, BSORT_MAX_BITS = 20;
+constexpr int BSORT_BIN_MAX = 512;
+
+__device__ inline uint64_t bsort_word(const BucketSortKeys& K, int w, uint32_t row) {
+    const ColumnRef& c = K.col[w];
+    const bool valid = row_valid(c.validity, row);
+    if (K.null_rank[w]) return K.nulls_first[w] ? (valid ? 1u : 0u) : (valid ? 0u : 1u);
+    uint64_t k = valid ? fixed_key_image(c, row) : 0ull;     // ties among NULLs
+    return K.desc[w] ? ~k : k;
+}
+
+// words[w * n + i] = word w of row i; diff[w] |= bits of word w that differ from row 0's
+template <int W>
+__global__ void __launch_bounds__(SORT_BLOCK)
+bsort_words_kernel(BucketSortKeys K, int64_t n, uint64_t* words, unsigned long long* diff) {
+    uint64_t first[W], acc[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) { first[w] = bsort_word(K, w, 0u); acc[w] = 0; }
+    for (int64_t i = (int64_t)blockIdx.x * SORT_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * SORT_BLOCK) {
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const uint64_t x = bsort_word(K, w, (uint32_t)i);
+            words[(size_t)w * n + i] = x;
+            acc[w] |= x ^ first[w];
+        }
+    }
+    __shared__ uint64_t s_acc[SORT_BLOCK / 64][W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        uint64_t a = acc[w];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const uint32_t lo = __shfl_down((uint32_t)a, d, 64), hi = __shfl_down((uint32_t)(a >> 32), d, 64);
+            a |= ((uint64_t)hi << 32) | lo;
+        }
+        if ((threadIdx.x & 63) == 0) s_acc[threadIdx.x >> 6][w] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < W) {
+        uint64_t all = 0;
+        for (int v = 0; v < SORT_BLOCK / 64; ++v) all |= s_acc[v][threadIdx.x];
+        // thousands of same-address atomics serialise (55 us for Q3's 1.13 M rows before): only a workgroup that adds a bit sends one
+        // (a stale read costs a redundant atomic, never a missing bit)
+        if (all & ~__hip_atomic_load(&diff[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&diff[threadIdx.x], (unsigned long long)all);
+    }
+}
+
+// mask[w] = the bits of word w that belong to the split digit: the `bits` most significant set bits of diff[0..W)
+template <int W>
+__device__ inline void bsort_digit_masks(const unsigned long long* diff, uint64_t* s_mask, int bits) {
+    if (threadIdx.x == 0) {
+        int left = bits;
+        for (int w = 0; w < W; ++w) {
+            uint64_t d = diff[w], m = 0;
+            while (d && left > 0) {
+                const int b = 63 - __clzll((long long)d);
+                m |= 1ull << b;
+                d &= ~(1ull << b);
+                --left;
+            }
+            s_mask[w] = m;
+        }
+    }
+    __syncthreads();
+}
+template <int W>
+__device__ inline uint32_t bsort_digit(const uint64_t* x, const uint64_t* s_mask) {
+    uint32_t digit = 0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        uint64_t m = s_mask[w];                       // the same in every lane: a scalar loop
+        while (m) {
+            const int b = 63 - __clzll((long long)m);
+            digit = (digit << 1) | (uint32_t)((x[w] >> b) & 1ull);
+            m &= ~(1ull << b);
+        }
+    }
+    return digit;
+}
+
+template <int W>
+__global__ void __launch_bounds__(SORT_BLOCK)
+bsort_hist_kernel(const uint64_t* words, int64_t n, const unsigned long long* diff, int bits, uint32_t* bins, uint32_t* digits) {
+    __shared__ uint64_t s_mask[W];
+    bsort_digit_masks<W>(diff, s_mask, bits);
+    for (int64_t i = (int64_t)blockIdx.x * SORT_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * SORT_BLOCK) {
+        uint64_t x[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) x[w] = words[(size_t)w * n + i];
+        const uint32_t d = bsort_digit<W>(x, s_mask);
+        digits[i] = d;
+        atomicAdd(&bins[d], 1u);
+    }
+}
+
+// row i -> position first[digit] + (rows of the bin that arrived before it): ONE record of W + 1 words {words, row | digit << 32} per row
+// (five separate scattered 4- and 8-byte stores per row, each a partial line, were 98 us for Q3's 1.13 M rows)
+template <int W>
+__global__ void __launch_bounds__(SORT_BLOCK)
+bsort_scatter_kernel(const uint64_t* words, const uint32_t* digits, int64_t n, const uint32_t* first, uint32_t* fill, uint64_t* records) {
+    for (int64_t i = (int64_t)blockIdx.x * SORT_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * SORT_BLOCK) {
+        const uint32_t d = digits[i];
+        const uint32_t pos = first[d] + atomicAdd(&fill[d], 1u);
+        uint64_t* r = records + (size_t)pos * (W + 1);
+#pragma unroll
+        for (int w = 0; w < W; ++w) r[w] = words[(size_t)w * n + i];
+        r[W] = (uint64_t)(uint32_t)i | ((uint64_t)d << 32);
+    }
+}
+
+// the row at position p of the binned order goes to first[bin] + (rows of its bin that sort before it)
+template <int W>
+__global__ void __launch_bounds__(SORT_BLOCK)
+bsort_rank_kernel(const uint64_t* records, int64_t n, const uint32_t* first, const uint32_t* bins, uint32_t* perm, uint32_t* status) {
+    for (int64_t p = (int64_t)blockIdx.x * SORT_BLOCK + threadIdx.x; p < n; p += (int64_t)gridDim.x * SORT_BLOCK) {
+        const uint64_t* mine = records + (size_t)p * (W + 1);
+        const uint64_t tag = mine[W];
+        const uint32_t d = (uint32_t)(tag >> 32), me = (uint32_t)tag, s = first[d], c = bins[d];
+        if (c == 1) { perm[s] = me; continue; }
+        if (c > (uint32_t)BSORT_BIN_MAX) { status[0] = 1u; continue; }
+        uint64_t x[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) x[w] = mine[w];
+        uint32_t before = 0;
+        for (uint32_t q = s; q < s + c; ++q) {
+            const uint64_t* other = records + (size_t)q * (W + 1);
+            bool lt = (uint32_t)other[W] < me;             // ties keep input order
+#pragma unroll
+            for (int w = W - 1; w >= 0; --w) {
+                const uint64_t y = other[w];
+                lt = y != x[w] ? y < x[w] : lt;
+            }
+            before += lt ? 1u : 0u;
+        }
+        perm[s + before] = me;
+    }
+}
+
+int64_t bucket_sort_max_rows() { return 1ll << 22; }
+static int bsort_bits_for(int64_t n) {
+    int bits = BSORT_MIN_BITS;
+    while (bits < BSORT_MAX_BITS && (1ll << bits) < n) ++bits;
+    return bits;
+}
+size_t bucket_sort_temp_bytes(int64_t n, int n_words) {
+    const size_t words = ((size_t)n_words * n * 8 + 63) & ~(size_t)63, records = ((size_t)(n_words + 1) * n * 8 + 63) & ~(size_t)63;
+    const size_t n_bins = (size_t)1 << bsort_bits_for(n);
+    return words + records + (((size_t)n * 4 + 63) & ~(size_t)63)                             // words, records, digits
+           + n_bins * 4 * 3 + exclusive_scan_temp_bytes((int64_t)n_bins) + 512;               // first, bins, fill, scan, diff + status
+}
+
+// perm[i] = the row at position i of the sorted order.  *status_dev (device, 4 bytes inside temp) != 0 afterwards: a bin overflowed, `perm`
+// is incomplete and the caller must sort some other way.  Only enqueues.
+hipError_t bucket_sort(const LaunchCfg& cfg, const BucketSortKeys& K, int64_t n, void* temp, uint32_t* perm, uint32_t** status_dev) {
+    if (K.n_words < 1 || K.n_words > BSORT_MAX_WORDS || n < 2 || n > bucket_sort_max_rows()) return hipErrorInvalidValue;
+    const int W = K.n_words, bits = bsort_bits_for(n);
+    const uint32_t n_bins = 1u << bits;
+    uint8_t* p = reinterpret_cast<uint8_t*>(temp);
+    auto carve = [&](size_t bytes) { uint8_t* q = p; p += (bytes + 63) & ~(size_t)63; return q; };
+    uint64_t* words = reinterpret_cast<uint64_t*>(carve((size_t)W * n * 8));
+    uint64_t* records = reinterpret_cast<uint64_t*>(carve((size_t)(W + 1) * n * 8));
+    uint32_t* digits = reinterpret_cast<uint32_t*>(carve((size_t)n * 4));
+    uint32_t* first = reinterpret_cast<uint32_t*>(carve((size_t)n_bins * 4));
+    void* scan_tmp = carve(exclusive_scan_temp_bytes((int64_t)n_bins));
+    // zeroed together: bins, fill, diff, status
+    uint8_t* zero0 = p;
+    uint32_t* bins = reinterpret_cast<uint32_t*>(carve((size_t)n_bins * 4));
+    uint32_t* fill = reinterpret_cast<uint32_t*>(carve((size_t)n_bins * 4));
+    unsigned long long* diff = reinterpret_cast<unsigned long long*>(carve(BSORT_MAX_WORDS * 8));
+    uint32_t* status = reinterpret_cast<uint32_t*>(carve(4));
+    hipError_t e = hipMemsetAsync(zero0, 0, (size_t)(p - zero0), cfg.stream);
+    if (e != hipSuccess) return e;
+    *status_dev = status;
+    const int g = sgrid(cfg, n);
+#define BSORT_HEAD(W_)                                                                                                                 \
+    {                                                                                                                                  \
+        hipLaunchKernelGGL(bsort_words_kernel<W_>, dim3(g), dim3(SORT_BLOCK), 0, cfg.stream, K, n, words, diff);                       \
+        hipLaunchKernelGGL(bsort_hist_kernel<W_>, dim3(g), dim3(SORT_BLOCK), 0, cfg.stream, words, n, diff, bits, bins, digits);       \
+    }
+#define BSORT_TAIL(W_)                                                                                                                 \
+    {                                                                                                                                  \
+        hipLaunchKernelGGL(bsort_scatter_kernel<W_>, dim3(g), dim3(SORT_BLOCK), 0, cfg.stream, words, digits, n, first, fill, records);  \
+        hipLaunchKernelGGL(bsort_rank_kernel<W_>, dim3(g), dim3(SORT_BLOCK), 0, cfg.stream, records, n, first, bins, perm, status);      \
+    }
+    switch (W) {
+        case 1: BSORT_HEAD(1) break;
+        case 2: BSORT_HEAD(2) break;
+        case 3: BSORT_HEAD(3) break;
+        default: BSORT_HEAD(4) break;
+    }
+    if ((e = exclusive_scan_u32_u32(cfg.stream, bins, (int64_t)n_bins, first, false, nullptr, scan_tmp)) != hipSuccess) return e;
+    switch (W) {
+        case 1: BSORT_TAIL(1) break;
+        case 2: BSORT_TAIL(2) break;
+        case 3: BSORT_TAIL(3) break;
+        default: BSORT_TAIL(4) break;
+    }
+#undef BSORT_HEAD
+#undef BSORT_TAIL
+    return hipGetLastError();
+}
+
 // ---- a whole SortExec over at most ROWSORT_MAX_ROWS rows in ONE launch of one workgroup -------------------------------
 // (the result of a low-cardinality aggregate: TPC-H Q1 sorts 4 rows, Q5 5 — the general path is ~20 launches for them).
 // Thread i owns input row i: its output position is the number of rows that sort before it under the lexicographic

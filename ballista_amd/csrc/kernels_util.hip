@@ -100,6 +100,39 @@ scan_apply_kernel(const uint32_t* in, int64_t n, const uint64_t* chunk_offsets, 
     }
 }
 
+// up to SCAN_TWO_LAUNCH_CHUNKS chunks: no scan_sums launch — every workgroup adds up the RAW sums of the chunks before its own (a few KB
+// from L2) and the last one writes the grand total: two launches instead of three (a Q3 step runs eight scans of this size: the tile
+// counts of a probe, the rank map's granules, the run flags of the aggregate, the bins of the bucket sort)
+constexpr int64_t SCAN_TWO_LAUNCH_CHUNKS = 2048;
+template <class OutT>
+__global__ void __launch_bounds__(SCAN_BLOCK)
+scan_apply_raw_kernel(const uint32_t* in, int64_t n, const uint64_t* chunk_sums, OutT* out, int write_total, uint64_t* total_out) {
+    __shared__ uint64_t s_wave[4];
+    uint64_t before = 0;
+    for (int64_t j = threadIdx.x; j < (int64_t)blockIdx.x; j += SCAN_BLOCK) before += chunk_sums[j];
+    uint64_t chunk_off;
+    block_exclusive_scan(before, s_wave, &chunk_off);
+    const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK;
+    uint32_t x[SCAN_ITEMS];
+    uint64_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        const int64_t j = base + (int64_t)threadIdx.x * SCAN_ITEMS + i;
+        x[i] = j < n ? in[j] : 0;
+        sum += x[i];
+    }
+    uint64_t tot;
+    uint64_t run = chunk_off + block_exclusive_scan(sum, s_wave, &tot);
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        const int64_t j = base + (int64_t)threadIdx.x * SCAN_ITEMS + i;
+        if (j < n) out[j] = (OutT)run;
+        run += x[i];
+        if (write_total && j == n - 1) out[n] = (OutT)run;
+    }
+    if (total_out && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_out = chunk_off + tot;
+}
+
 // n <= SCAN_ONE_LAUNCH_MAX: the whole scan by ONE workgroup in one launch, chunk after chunk with a running carry (group
 // tables, small gathers: three launches cost more than the serial walk)
 constexpr int64_t SCAN_ONE_LAUNCH_MAX = 8 * (int64_t)SCAN_CHUNK;    // ~3 us per serial chunk against ~10 us per extra launch
@@ -154,6 +187,10 @@ static hipError_t exclusive_scan_t(hipStream_t st, const uint32_t* in, int64_t n
         return hipGetLastError();
     }
     hipLaunchKernelGGL(scan_chunk_sums_kernel, dim3((unsigned)n_chunks), dim3(SCAN_BLOCK), 0, st, in, n, sums);
+    if (n_chunks <= SCAN_TWO_LAUNCH_CHUNKS) {
+        hipLaunchKernelGGL((scan_apply_raw_kernel<OutT>), dim3((unsigned)n_chunks), dim3(SCAN_BLOCK), 0, st, in, n, sums, out, write_total ? 1 : 0, total_out);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, st, sums, n_chunks, total_out);
     hipLaunchKernelGGL((scan_apply_kernel<OutT>), dim3((unsigned)n_chunks), dim3(SCAN_BLOCK), 0, st, in, n, sums, out,
                        write_total ? 1 : 0);
@@ -237,11 +274,24 @@ rank_pack_sums_kernel(const uint32_t* __restrict__ bits32, int64_t n, uint64_t* 
     if (threadIdx.x == 0) chunk_sums[blockIdx.x] = tot;
 }
 
+// RAW: chunk_offsets holds the chunks' own sums (no scan_sums launch in between): the workgroup adds up those before its own, the last
+// one writes the grand total
+template <bool RAW>
 __global__ void __launch_bounds__(SCAN_BLOCK)
-rank_pack_apply_kernel(const uint32_t* __restrict__ bits32, int64_t n, const uint64_t* __restrict__ chunk_offsets, uint64_t* __restrict__ pack) {
+rank_pack_apply_kernel(const uint32_t* __restrict__ bits32, int64_t n, const uint64_t* __restrict__ chunk_offsets, uint64_t* __restrict__ pack,
+                       uint64_t* __restrict__ total_out) {
     __shared__ uint32_t s_wave[4];
     const int64_t base = (int64_t)blockIdx.x * RP_CHUNK;
-    uint64_t carry = chunk_offsets[blockIdx.x];
+    uint64_t carry;
+    if (RAW) {
+        __shared__ uint64_t s_wave64[4];
+        uint64_t before = 0;
+        for (int64_t j = threadIdx.x; j < (int64_t)blockIdx.x; j += SCAN_BLOCK) before += chunk_offsets[j];
+        block_exclusive_scan(before, s_wave64, &carry);
+        if (total_out && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_out = carry + chunk_offsets[blockIdx.x];
+    } else {
+        carry = chunk_offsets[blockIdx.x];
+    }
     for (int r = 0; r < RP_ROUNDS; ++r) {
         const int64_t j = base + (int64_t)r * RP_ROUND + (int64_t)threadIdx.x * 4;
         if (base + (int64_t)r * RP_ROUND >= n) break;                                   // workgroup-uniform
@@ -300,8 +350,12 @@ hipError_t launch_rank_pack(hipStream_t st, const uint32_t* bits32, int64_t n, u
     uint64_t* sums = reinterpret_cast<uint64_t*>(temp);                   // (exclusive_scan_temp_bytes(n) words: sized for the smaller SCAN_CHUNK)
     const int64_t n_chunks = (n + RP_CHUNK - 1) / RP_CHUNK;
     hipLaunchKernelGGL(rank_pack_sums_kernel, dim3((unsigned)n_chunks), dim3(SCAN_BLOCK), 0, st, bits32, n, sums);
+    if (n_chunks <= SCAN_TWO_LAUNCH_CHUNKS) {
+        hipLaunchKernelGGL(rank_pack_apply_kernel<true>, dim3((unsigned)n_chunks), dim3(SCAN_BLOCK), 0, st, bits32, n, (const uint64_t*)sums, pack, total_out);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, st, sums, n_chunks, total_out);
-    hipLaunchKernelGGL(rank_pack_apply_kernel, dim3((unsigned)n_chunks), dim3(SCAN_BLOCK), 0, st, bits32, n, (const uint64_t*)sums, pack);
+    hipLaunchKernelGGL(rank_pack_apply_kernel<false>, dim3((unsigned)n_chunks), dim3(SCAN_BLOCK), 0, st, bits32, n, (const uint64_t*)sums, pack, (uint64_t*)nullptr);
     return hipGetLastError();
 }
 
@@ -570,6 +624,40 @@ hipError_t launch_take_utf8_copy(const LaunchCfg& cfg, const int32_t* src_off, c
 // =============================================================================================
 // small helpers
 // =============================================================================================
+// several regions set to a 32-bit pattern each in ONE launch (a join build or a hash aggregate clears 4-6 small buffers in a row: a
+// hipMemsetAsync is a launch of its own, ~4 us on the stream plus the gap before the next)
+__global__ void __launch_bounds__(BLOCK)
+fill_many_kernel(FillMany F) {
+    const int64_t gtid = (int64_t)blockIdx.x * BLOCK + threadIdx.x, gsize = (int64_t)gridDim.x * BLOCK;
+    for (int r = 0; r < F.n; ++r) {
+        uint32_t* p = static_cast<uint32_t*>(F.ptr[r]);
+        const int64_t words = (int64_t)(F.bytes[r] >> 2);
+        const uint32_t v = F.value[r];
+        if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+            const uint4 v4 = make_uint4(v, v, v, v);
+            const int64_t quads = words >> 2;
+            for (int64_t i = gtid; i < quads; i += gsize) reinterpret_cast<uint4*>(p)[i] = v4;
+            for (int64_t i = (quads << 2) + gtid; i < words; i += gsize) p[i] = v;
+        } else {
+            for (int64_t i = gtid; i < words; i += gsize) p[i] = v;
+        }
+    }
+}
+hipError_t launch_fill_many(const LaunchCfg& cfg, const FillMany& F) {
+    if (F.n < 0 || F.n > FILL_MANY_MAX) return hipErrorInvalidValue;
+    uint64_t most = 0;
+    for (int r = 0; r < F.n; ++r) {
+        if ((F.bytes[r] & 3) || (reinterpret_cast<uintptr_t>(F.ptr[r]) & 3)) return hipErrorInvalidValue;
+        most = F.bytes[r] > most ? F.bytes[r] : most;
+    }
+    if (most == 0) return hipSuccess;
+    int64_t g = (int64_t)((most / 16 + BLOCK - 1) / BLOCK);
+    const int64_t cap = (int64_t)cfg.device_cus * 8;
+    g = g < 1 ? 1 : (g > cap ? cap : g);
+    hipLaunchKernelGGL(fill_many_kernel, dim3((unsigned)g), dim3(BLOCK), 0, cfg.stream, F);
+    return hipGetLastError();
+}
+
 __global__ void __launch_bounds__(BLOCK)
 iota_u32_kernel(uint32_t* out, int64_t n, uint32_t start) {
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK)

@@ -73,5 +73,9 @@ hipError_t launch_scan_agg_lean(const LaunchCfg& cfg, const SopProgram& S, SopPr
 // FilterExec's predicate pass for AND-of-ranges predicates (kernels_range.hip): selection bitmap + kept rows per
 // 1024-row tile, the interface of launch_scan_pred_bitmap
 hipError_t launch_range_bitmap(const LaunchCfg& cfg, const SopProgram& S, SopProgram* dprog, uint64_t* bitmap, uint32_t* tile_counts);
+// Utf8 column = literal (negate: !=), NULL rows dropped: the same bitmap + tile counts (kernels_range.hip)
+struct Utf8Literal { uint8_t bytes[64]; int32_t len; };
+hipError_t launch_utf8_eq_bitmap(const LaunchCfg& cfg, const int32_t* offsets, const void* data, const uint64_t* validity, int64_t n, const Utf8Literal& lit,
+                                 bool negate, uint64_t* bitmap, uint32_t* tile_counts);
 
 }  // namespace bhip

@@ -43,6 +43,16 @@ hipError_t launch_take_utf8_copy(const LaunchCfg& cfg, const int32_t* src_off, c
                                  int64_t n, const int32_t* dst_off, uint8_t* dst);
 
 hipError_t launch_iota_u32(const LaunchCfg& cfg, uint32_t* out, int64_t n, uint32_t start);
+// up to FILL_MANY_MAX regions (4-byte aligned, a multiple of 4 bytes long), each set to its own 32-bit pattern, one launch
+constexpr int FILL_MANY_MAX = 8;
+struct FillMany {
+    int n = 0;
+    void* ptr[FILL_MANY_MAX];
+    uint64_t bytes[FILL_MANY_MAX];
+    uint32_t value[FILL_MANY_MAX];
+    void add(void* p, uint64_t nbytes, uint32_t v = 0) { ptr[n] = p; bytes[n] = nbytes; value[n] = v; ++n; }
+};
+hipError_t launch_fill_many(const LaunchCfg& cfg, const FillMany& F);
 hipError_t launch_rebase_offsets(const LaunchCfg& cfg, const int32_t* src_off, int64_t n_plus_1, int32_t add, int32_t* dst_off);
 hipError_t launch_copy_bits(const LaunchCfg& cfg, const uint64_t* src, int64_t src_bit0, uint64_t* dst, int64_t dst_bit0,
                             int64_t n_bits);

@@ -442,6 +442,44 @@ def test_sort_mid_size(ctx, n):
     run_both(ba.SortExec([E.PhysicalSortExpr(col("s")), E.PhysicalSortExpr(col("i"), descending=True)], m), ordered=True)
 
 
+@pytest.mark.parametrize("n", [1025, 4097, 150_000, 600_000])
+def test_sort_bucket_path(n, monkeypatch):
+    """1 K - 4 M rows under fixed-width keys: one split on the 16 highest differing bits of the composite key + an LDS sort per
+    segment (kernels_sort.hip: bucket_sort).  The Q3 shape (Float64 DESC with NULLs, then a date), a low-cardinality first key
+    (the digit takes its few bits and continues in the next word), two nullable keys (four words); the kernel list says the
+    bucket path ran.  Heavily repeated keys overflow a bin and all-equal keys have no differing bit: both take the LSD passes."""
+    from collections import OrderedDict
+    monkeypatch.setenv("BHIP_KERNEL_TIMING", "2")             # every launch, however small (read when a context is created)
+    ctx = ba.Context(0)
+    rng = np.random.default_rng(n)
+    b = OrderedDict([("f", OCol("Float64", np.round(rng.lognormal(10, 1, n), 2), rng.random(n) > 0.05)),
+                     ("r", OCol("Float64", np.round(rng.lognormal(10, 1, n), 2))),
+                     ("d", OCol("Date32", rng.integers(8000, 10400, n))),
+                     ("g", OCol("Int32", rng.integers(0, 5, n))),
+                     ("u", OCol("Float64", rng.random(n))),
+                     ("i", OCol("Int64", rng.integers(-2**40, 2**40, n), rng.random(n) > 0.5)),
+                     ("few", OCol("Int64", rng.integers(0, 3, n) * 1000)),
+                     ("one", OCol("Int32", np.full(n, 7)))])
+    m = helpers.memory_exec(ctx, [[b]])
+    small = n <= 4097              # the NULL rows of a key are one bin: more than 512 of them overflow it
+    cases = [
+        ([E.PhysicalSortExpr(col("r"), descending=True, nulls_first=False), E.PhysicalSortExpr(col("d"))], True),
+        ([E.PhysicalSortExpr(col("g")), E.PhysicalSortExpr(col("u"), descending=True)], True),
+        ([E.PhysicalSortExpr(col("one")), E.PhysicalSortExpr(col("u"))], True),
+        ([E.PhysicalSortExpr(col("f"), descending=True, nulls_first=False), E.PhysicalSortExpr(col("d"))], small),
+        ([E.PhysicalSortExpr(col("f"), nulls_first=True), E.PhysicalSortExpr(col("i"), descending=True, nulls_first=False)], small),
+        ([E.PhysicalSortExpr(col("few")), E.PhysicalSortExpr(col("g"))], small),                        # fifteen value pairs: a fifteenth of the rows per bin
+        ([E.PhysicalSortExpr(col("one"))], False),                                                      # no differing bit at all
+        ([E.PhysicalSortExpr(col("g")), E.PhysicalSortExpr(col("f")), E.PhysicalSortExpr(col("i"))], None),   # five words: not eligible
+    ]
+    for keys, buckets in cases:
+        ctx.kernel_stats(reset=True)
+        run_both(ba.SortExec(keys, m), ordered=True)
+        ks = ctx.kernel_stats(reset=True)
+        assert ("bucket_sort" in ks) == (buckets is not None), (keys, ks)
+        assert ("sort_key_fixed" in ks) == (not buckets), (keys, ks)      # the LSD passes ran iff the bucket path did not, or gave up
+
+
 @pytest.mark.parametrize("n", [700, 5000])
 def test_sort_by_long_strings(ctx, n):
     """Utf8 sort keys of any length (here up to 90 bytes, sharing long prefixes, with NULLs and empty strings): one
