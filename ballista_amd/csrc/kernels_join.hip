@@ -29,6 +29,9 @@ namespace {
 
 __device__ inline bool jbit_at(const uint64_t* bm, uint64_t i) { return bm == nullptr || ((bm[i >> 6] >> (i & 63)) & 1ull); }
 
+#ifndef BHIP_PROBE_WAVES
+#define BHIP_PROBE_WAVES
+#endif
 template <int KW> struct KeyT;
 template <> struct KeyT<4> { using type = uint32_t; };
 template <> struct KeyT<8> { using type = uint64_t; };
@@ -403,7 +406,7 @@ join_filter_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const voi
 // the key-set words themselves (NarrowJoinTable::rbits, 4 bytes per 32 key values) — half the packed map: Q3's customers, 15 M key
 // values, are 1.9 MB instead of 3.75 MB against the 4 MB of L2 an XCD has, under 150 M random lookups.
 template <int KW, int NF, int FP_ROWS, bool RESID, bool PERM, bool MAPBUF, bool BITS = false>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(BLOCK) BHIP_PROBE_WAVES
 join_rank_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void* __restrict__ rkeys_v, uint32_t n_right,
                        uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts, uint32_t* __restrict__ staging,
                        const uint32_t* __restrict__ resid_probe, uint32_t* __restrict__ staging_rows) {
@@ -476,25 +479,52 @@ join_rank_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void*
     // granules [0, rzero) of the map (the host only picks MAPBUF when rzero * 8 < 2^31)
     const auto rmap = BITS ? __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(T.rbits), 0, (int)(T.rzero * 4u), 0x00020000)
                            : __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(rpack), 0, MAPBUF ? (int)(T.rzero * 8u) : 0, 0x00020000);
-    Regs cur, nxt;
-    if (wave_id < n_tiles) load_any(wave_id * SEL_TILE, cur);
+    // Emitted (build row, probe row) pairs collect in a wave-private LDS strip and go out in whole-wave stores when the strip fills up
+    // and at the end of the tile: two scattered global stores per row SLOT with a match (a handful of active lanes each, 16 store
+    // instructions per pass when most slots hold one — Q5's lineitem probe: 3 % of the rows match, 86 % of the slots) become one LDS
+    // write per slot and two coalesced stores per tile.
+    constexpr uint32_t STRIP = 192;                                   // >= 64 more than the flush threshold
+    __shared__ uint2 s_strip[BLOCK / 64][STRIP];
+    uint2* __restrict__ strip = s_strip[threadIdx.x >> 6];
+    // The streamed rows are loaded TWO passes ahead: even passes live in one register set, odd passes in the other, and a pass
+    // refills its own set — for the pass after next — as soon as its keys have become map offsets.  (One pass ahead, a wave had its
+    // next 512 rows in flight only while it waited for its dependent map reads: a pass took one full memory round trip with the
+    // SIMD a quarter busy — rocprofv3 on Q5's lineitem launch: 4 waves per SIMD, 188 SIMD cycles per 64-row slot for ~33 instructions.)
+    static_assert(PASSES % 2 == 0, "even and odd passes alternate between the two register sets");
+    Regs set_a, set_b;
+    if (wave_id < n_tiles) {
+        load_any(wave_id * SEL_TILE, set_a);
+        load_any(wave_id * SEL_TILE + FP_CHUNK, set_b);
+    }
     for (uint32_t t = wave_id; t < n_tiles; t += n_waves) {
         const uint32_t tile_base = t * SEL_TILE;
         uint32_t* __restrict__ st_m = staging + tile_base;            // (null + offset when not staged: never dereferenced)
         uint32_t* __restrict__ st_r = staging_rows + tile_base;
         uint32_t tile_cnt = 0;
-        auto pass_body = [&](int c, auto edge) {
+        uint32_t strip_cnt = 0, flushed = 0;                          // wave-uniform: entries in the strip, entries of this tile already stored
+        auto flush = [&]() {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+            for (uint32_t i = lane; i < strip_cnt; i += 64u) {                            // (inlined at every row slot: keep it small)
+                const uint2 e = strip[i];
+                st_m[flushed + i] = e.x;
+                st_r[flushed + i] = e.y;
+            }
+            __builtin_amdgcn_wave_barrier();
+            flushed += strip_cnt;
+            strip_cnt = 0;
+        };
+        auto pass_body = [&](int c, Regs& cur, auto edge) {
             constexpr bool EDGE = decltype(edge)::value;
             const uint32_t base = tile_base + (uint32_t)c * FP_CHUNK;
-            // The next pass's streamed loads go out BEHIND this pass's last dependent load and nothing of this pass waits on a
-            // load issued after them: loads return in issue order, so the streamed rows stay in flight until the next pass
-            // picks them up.
+            // The refill goes out BEHIND this pass's last dependent load and nothing of this pass waits on a load issued after it:
+            // loads return in issue order, so the streamed rows stay in flight until the pass after next picks them up.
             auto prefetch = [&]() {
                 __builtin_amdgcn_sched_barrier(0);
-                const bool last = c == PASSES - 1;
                 // (after the wave's last tile the prefetch re-reads the final rows: harmless, and no branch around the loads)
                 const uint32_t nt = t + n_waves < n_tiles ? t + n_waves : n_tiles - 1;
-                load_any(last ? nt * SEL_TILE : base + FP_CHUNK, nxt);
+                const bool wraps = c + 2 >= PASSES;
+                load_any((wraps ? nt * SEL_TILE : tile_base) + (uint32_t)(wraps ? c + 2 - PASSES : c + 2) * FP_CHUNK, cur);
                 __builtin_amdgcn_sched_barrier(0);
             };
             bool live[FP_ROWS];
@@ -545,12 +575,12 @@ join_rank_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void*
                 if (!RESID) prefetch();
             }
             if (RESID) {
-                uint32_t second[FP_ROWS];
+                uint32_t second[FP_ROWS], mine[FP_ROWS];
 #pragma unroll
-                for (int k = 0; k < FP_ROWS; ++k) second[k] = T.resid_build[live[k] ? m[k] : 0u];
-                prefetch();
+                for (int k = 0; k < FP_ROWS; ++k) { second[k] = T.resid_build[live[k] ? m[k] : 0u]; mine[k] = cur.g[RESID ? k : 0]; }
+                prefetch();                                     // (refills `cur`: this pass's second keys were copied out above)
 #pragma unroll
-                for (int k = 0; k < FP_ROWS; ++k) live[k] = live[k] && second[k] == cur.g[RESID ? k : 0];
+                for (int k = 0; k < FP_ROWS; ++k) live[k] = live[k] && second[k] == mine[k];
             }
             uint64_t my_word = 0;
 #pragma unroll
@@ -558,7 +588,9 @@ join_rank_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void*
                 const bool emit = live[k];                                                // (inner join: a right join takes the general kernel)
                 const uint64_t wd = __builtin_amdgcn_ballot_w64(emit);
                 my_word = lane == (uint32_t)k ? wd : my_word;
+                const uint32_t n_emit = (uint32_t)__popcll(wd);
                 if (staged && wd != 0ull) {                                               // wave-uniform: a slot without a match costs one scalar test
+                    if (__builtin_expect(strip_cnt + n_emit > STRIP, 0)) flush();         // wave-uniform, rare: laid out of line
                     if (emit) {
                         uint32_t mk;
                         if (PERM || RESID) mk = m[k];
@@ -566,25 +598,25 @@ join_rank_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void*
                             const uint32_t bits = (uint32_t)pk[k];
                             mk = (uint32_t)(pk[k] >> 32) + (uint32_t)__popc(__builtin_amdgcn_ubfe(bits, 0u, d[k] & 31u));     // set bits below the key's
                         }
-                        // tile_cnt + (emitting lanes below this one): two mbcnt instructions, the count riding along as their addend
-                        const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(wd >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wd, tile_cnt)) & (SEL_TILE - 1);
-                        st_m[at] = mk;
-                        st_r[at] = base + 64u * k + lane;
+                        // strip_cnt + (emitting lanes below this one): two mbcnt instructions, the count riding along as their addend
+                        const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(wd >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wd, strip_cnt));
+                        strip[at] = make_uint2(mk, base + 64u * k + lane);
                     }
+                    strip_cnt += n_emit;
                 }
-                tile_cnt += (uint32_t)__popcll(wd);
+                tile_cnt += n_emit;
             }
             // the pass's FP_ROWS selection words in one store (bitmap words past the last row's word exist: whole tiles)
             if (lane < FP_ROWS) (bitmap + (base >> 6))[lane] = my_word;
-            cur = nxt;
         };
         if (t < full_tiles) {                                                             // wave-uniform
 #pragma unroll 1
-            for (int c = 0; c < PASSES; ++c) pass_body(c, std::false_type{});
+            for (int c = 0; c < PASSES; c += 2) { pass_body(c, set_a, std::false_type{}); pass_body(c + 1, set_b, std::false_type{}); }
         } else {
 #pragma unroll 1
-            for (int c = 0; c < PASSES; ++c) pass_body(c, std::true_type{});
+            for (int c = 0; c < PASSES; c += 2) { pass_body(c, set_a, std::true_type{}); pass_body(c + 1, set_b, std::true_type{}); }
         }
+        if (staged && strip_cnt != 0u) flush();
         if (lane == 0) tile_counts[t] = tile_cnt;
     }
 }

@@ -10,10 +10,10 @@ f=glob.glob("gpurun_out/$TAG/*/*counter_collection.csv")[0]
 rows=list(csv.DictReader(open(f)))
 agg=collections.defaultdict(lambda: collections.defaultdict(float)); disp=collections.defaultdict(set)
 for r in rows:
-    k=r['Kernel_Name'][:48]; agg[k][r['Counter_Name']]+=float(r['Counter_Value']); disp[k].add(r['Dispatch_Id'])
+    k=r['Kernel_Name'][:int('${PMC_NAME_CHARS:-48}')]; agg[k][r['Counter_Name']]+=float(r['Counter_Value']); disp[k].add(r['Dispatch_Id'])
 kt=list(csv.DictReader(open(glob.glob("gpurun_out/$TAG/*/*kernel_trace.csv")[0])))
 d=collections.defaultdict(list)
-for r in kt: d[r['Kernel_Name'][:48]].append((int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e6)
+for r in kt: d[r['Kernel_Name'][:int('${PMC_NAME_CHARS:-48}')]].append((int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e6)
 for k,v in agg.items():
     n=len(disp[k])
     if sum(d[k])/len(d[k]) < 0.05: continue
