@@ -137,6 +137,7 @@ struct NarrowJoinTable {
     const uint64_t* rpack;
     // the key-set words alone, rbits[g] = low half of rpack[g] (null: not kept — a window beyond 2^31 values): what a semi-join reads
     const uint32_t* rbits;
+    uint32_t scalar_map;      // probe kernel: slots whose rows fall into two neighbouring granules read them through the scalar cache
     uint32_t rzero;           // index of an all-zero granule behind the map (rows that need no lookup read it)
     const uint32_t* rperm;
     // two-column join whose build side is unique on the first column: second key of every build row (null: one-column join)

@@ -322,6 +322,8 @@ std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) co
                 stream_wait(ex);                 // other tasks (other streams) read the map: complete before it is published
                 bs->ntable.rpack = bs->rpack->as<uint64_t>();
                 bs->ntable.rbits = bs->rbits ? bs->rbits->as<uint32_t>() : nullptr;
+                static const bool no_scalar_map = [] { const char* v = getenv("BHIP_PROBE_NO_SCALAR_MAP"); return v && atoi(v) != 0; }();
+                bs->ntable.scalar_map = no_scalar_map ? 0u : 1u;
                 bs->ntable.rzero = (uint32_t)n_gran;
                 bs->ntable.rperm = bs->rperm ? bs->rperm->as<uint32_t>() : nullptr;
                 bs->ntable.krange64 = range;

@@ -424,6 +424,7 @@ join_rank_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void*
     const uint32_t n_waves = gridDim.x * (BLOCK / 64);
     const uint64_t* __restrict__ rpack = T.rpack;
     const bool staged = staging != nullptr;            // (staging and staging_rows come together: host/ops_join.cpp process_fused)
+    const bool scalar_map = T.scalar_map != 0;         // (BHIP_PROBE_NO_SCALAR_MAP=1 clears it: the A/B partner)
 
     struct Regs { K key[FP_ROWS]; int32_t f[NFR][FP_ROWS]; uint32_t g[RESID ? FP_ROWS : 1]; };
     // rows [base, base + FP_CHUNK) of the streamed columns, as BUFFER loads: a 128-bit descriptor over [column + base, end of the
@@ -528,8 +529,9 @@ join_rank_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void*
                 __builtin_amdgcn_sched_barrier(0);
             };
             bool live[FP_ROWS];
-            uint32_t d[FP_ROWS], m[FP_ROWS], lv[FP_ROWS];
+            uint32_t d[FP_ROWS], m[FP_ROWS], lv[FP_ROWS], vo[FP_ROWS];
             uint64_t pk[FP_ROWS];
+            constexpr uint32_t MAP_WORD = BITS ? 4u : 8u, DROPPED = 0u - MAP_WORD;
 #pragma unroll
             for (int k = 0; k < FP_ROWS; ++k) {
                 uint32_t ok = EDGE ? (uint32_t)((base + 64u * k + lane) < n_right) & alive : alive;
@@ -540,18 +542,13 @@ join_rank_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void*
                 // a row the filter dropped, or whose key lies outside the window, reads an all-zero granule: the bit test below is
                 // then the whole decision — ONE compare, whose lane mask is the ballot (a ballot of an AND of conditions costs two
                 // more vector instructions per row slot)
-                if constexpr (BITS) {
+                if constexpr (BITS || MAPBUF) {
+                    // byte offset of the granule's word = (off >> 5) * 8 = (off >> 2) & ~7 (key-set words alone: (off >> 5) * 4): 32 bits hold
+                    // it for offsets below 2^34 (the map is shorter than 2 GiB: its window ends below 2^33); 8-byte keys beyond that must
+                    // not wrap into the map.  A dropped row gets the offset of the last word a 32-bit offset can name: out of range, reads 0.
                     if (KW == 8) ok &= (uint32_t)((off >> 34) == 0);
-                    const uint32_t voff = (uint32_t)(off >> 3) & ~3u;                  // (off >> 5) * 4
-                    pk[k] = __builtin_amdgcn_raw_buffer_load_b32(rmap, (int)(ok ? voff : 0xFFFFFFFCu), 0, 0);
-                } else if constexpr (MAPBUF) {
-                    // byte offset of the granule's word = (off >> 5) * 8 = (off >> 2) & ~7: 32 bits hold it for offsets below 2^34 (the
-                    // map is shorter than 2 GiB: its window ends below 2^33); 8-byte keys beyond that must not wrap into the map
-                    if (KW == 8) ok &= (uint32_t)((off >> 34) == 0);
-                    const uint32_t voff = (uint32_t)(off >> 2) & ~7u;
-                    typedef unsigned int v2u_t __attribute__((ext_vector_type(2)));
-                    const v2u_t w = __builtin_amdgcn_raw_buffer_load_b64(rmap, (int)(ok ? voff : 0xFFFFFFF8u), 0, 0);
-                    pk[k] = ((uint64_t)w.y << 32) | w.x;
+                    const uint32_t voff = BITS ? ((uint32_t)(off >> 3) & ~3u) : ((uint32_t)(off >> 2) & ~7u);
+                    vo[k] = ok ? voff : DROPPED;
                 } else {
                     ok &= (uint32_t)in_window<KW>(off, T.krange64);
                     // granule index (the window holds <= 2^36 values: < 2^31 granules; 4-byte keys stay in 32-bit arithmetic)
@@ -559,7 +556,55 @@ join_rank_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void*
                     pk[k] = rpack[ok ? g : T.rzero];
                 }
             }
-            if (!PERM && !RESID) prefetch();
+            if constexpr (BITS || MAPBUF) {
+                // Probe keys clustered like the probe order (lineitem by order key): the 64 rows of a slot fall into one or two
+                // neighbouring granules.  A gather instruction costs the L1 a tag lookup per four lanes whatever the addresses —
+                // rocprofv3 on Q5's lineitem launch: 16.6 TCP accesses per map read against 4 per streamed key read, the L1 busy or
+                // stalled 0.62 of the launch's 0.69 ms — so when EVERY slot of the pass is that narrow (wave-uniform test) the two words
+                // of each slot come through the SCALAR cache (s_load) and the lanes pick theirs; one slot wider than that and the
+                // pass gathers as before (random keys: orders by customer key).
+                uint32_t g0[FP_ROWS];
+                bool narrow = scalar_map;
+#pragma unroll
+                for (int k = 0; k < FP_ROWS; ++k) {
+                    const uint64_t okm = __builtin_amdgcn_ballot_w64(vo[k] != DROPPED);
+                    const uint32_t first = okm ? (uint32_t)__builtin_amdgcn_readlane((int)vo[k], (int)__builtin_ctzll(okm)) : 0u;   // wave-uniform
+                    g0[k] = first;
+                    // ... and inside the map (the gather's descriptor range-checks; a scalar read does not): first + one word <= the zero granule
+                    narrow = narrow && first < T.rzero * MAP_WORD && __builtin_amdgcn_ballot_w64(vo[k] != DROPPED && (vo[k] - first) > MAP_WORD) == 0ull;
+                }
+                if (narrow) {
+                    uint64_t w0[FP_ROWS], w1[FP_ROWS];
+#pragma unroll
+                    for (int k = 0; k < FP_ROWS; ++k) {
+                        if constexpr (BITS) {
+                            typedef const uint32_t __attribute__((address_space(4)))* cptr;
+                            const cptr mp = (cptr)(uintptr_t)(reinterpret_cast<const uint8_t*>(T.rbits) + g0[k]);
+                            w0[k] = mp[0]; w1[k] = mp[1];
+                        } else {
+                            typedef const uint64_t __attribute__((address_space(4)))* cptr;
+                            const cptr mp = (cptr)(uintptr_t)(reinterpret_cast<const uint8_t*>(rpack) + g0[k]);
+                            w0[k] = mp[0]; w1[k] = mp[1];
+                        }
+                    }
+                    if (!PERM && !RESID) prefetch();
+#pragma unroll
+                    for (int k = 0; k < FP_ROWS; ++k) pk[k] = vo[k] == DROPPED ? 0ull : (vo[k] == g0[k] ? w0[k] : w1[k]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < FP_ROWS; ++k) {
+                        if constexpr (BITS) pk[k] = __builtin_amdgcn_raw_buffer_load_b32(rmap, (int)vo[k], 0, 0);
+                        else {
+                            typedef unsigned int v2u_t __attribute__((ext_vector_type(2)));
+                            const v2u_t w = __builtin_amdgcn_raw_buffer_load_b64(rmap, (int)vo[k], 0, 0);
+                            pk[k] = ((uint64_t)w.y << 32) | w.x;
+                        }
+                    }
+                    if (!PERM && !RESID) prefetch();
+                }
+            } else {
+                if (!PERM && !RESID) prefetch();
+            }
 #pragma unroll
             for (int k = 0; k < FP_ROWS; ++k) {
                 const uint32_t bits = (uint32_t)pk[k];
