@@ -481,7 +481,8 @@ Operand ProgramBuilder::load_column(int schema_idx) {
 }
 
 bool ProgramBuilder::can_raise() const {
-    if (!keys_.empty()) return true;
+    for (auto& k : keys_)
+        if (k.kind == KP_UTF8_COL) return true;       // SCAN_ERR_KEY_TOO_LONG: only a Utf8 key part can outgrow its packed width
     for (auto& vi : instrs_)
         if (vi.ins.op == OP_DIV_I64) return true;
     return false;

@@ -396,7 +396,7 @@ GroupRec* hash_aggregate(const Exec& ex, Temp& tmp, const ScanParams& P0, const 
         radix_sort_pairs(ex, kb, pb2, (int64_t)n_spill);
         TIMED_LAUNCH_N(ex, "det_spill_combine", n_spill, launch_det_spill_combine(cfg, D, kb->as<uint64_t>(), pb2->as<uint32_t>(), n_spill));
     }
-    check_scan_status(ex, status);                   // after the one wait above: the stream is idle, this read is immediate
+    if (pb.can_raise()) check_scan_status(ex, status);   // (after the one wait above: immediate; fixed-width keys and no integer division raise nothing)
     GroupRec* table = tmp.get<GroupRec>(ng ? ng : 1);
     if (ng && distinct_runs) TIMED_LAUNCH_N(ex, "run_compact", ng, launch_run_compact(cfg, T, run_head, (uint32_t)ng, nullable, table));
     else if (ng) TIMED_LAUNCH_N(ex, "hash_agg_compact", cap, launch_hash_agg_compact(cfg, T, dense, nullable, table));

@@ -345,7 +345,7 @@ int64_t filter_indices(const Exec& ex, const Batch& in, const ExprPtr& predicate
     const int64_t n_tiles = (n + SEL_TILE - 1) / SEL_TILE;
     uint64_t* bitmap = tmp.get<uint64_t>((size_t)(n + 63) / 64 + 1);
     uint32_t* tile_counts = tmp.get<uint32_t>((size_t)n_tiles + 1);
-    ScanStatus* st = new_status(tmp);
+    ScanStatus* st = nullptr;                       // the expression VM's error flags: only when it is the VM that runs
     if (n == 0) { indices_out = make_buffer(ex, 8); return 0; }
     // AND of column-vs-literal comparisons over NULL-free numeric columns: the wide-load range kernel
     // (kernels_range.hip) writes the same bitmap + tile counts as the expression VM
@@ -379,14 +379,15 @@ int64_t filter_indices(const Exec& ex, const Batch& in, const ExprPtr& predicate
         bind_sop(rp, in);
         TIMED_LAUNCH_N(ex, "range_bitmap", n, launch_range_bitmap(ex.cfg(), rp.prog, tmp.get<SopProgram>(1), bitmap, tile_counts));
     } else {
+        st = new_status(tmp);
         TIMED_LAUNCH_N(ex, "scan_pred_bitmap", n, launch_scan_pred_bitmap(ex.cfg(), P, bitmap, tile_counts, st));
     }
     uint64_t* tile_off = tmp.get<uint64_t>((size_t)n_tiles + 1);
     uint64_t* total = tmp.get<uint64_t>(1);
     void* scan_tmp = tmp.get<uint8_t>(exclusive_scan_temp_bytes(n_tiles));
     HIP_CHECK(exclusive_scan_u32_u64(ex.stream, tile_counts, n_tiles, tile_off, false, total, scan_tmp));
-    check_scan_status(ex, st);
     const uint64_t count = read_device(ex, total);
+    if (st && pb.can_raise()) check_scan_status(ex, st);       // (after the wait above: immediate; the specialised kernels raise nothing)
     indices_out = make_buffer(ex, (size_t)count * 4 + 8);
     if (count) TIMED_LAUNCH_N(ex, "select_indices", n, launch_select_indices(ex.cfg(), bitmap, tile_off, n, indices_out->as<uint32_t>()));
     return (int64_t)count;

@@ -263,6 +263,45 @@ def test_rank_map_window_beyond_2_to_the_30(jt, order, monkeypatch):
     check(ba.HashJoinExec(lm, flt, [("lk", "rk")], jt), ["lk", "rk", "ry", "lx"])
 
 
+@pytest.mark.parametrize("key_type", ["Int32", "Int64"])
+@pytest.mark.parametrize("probe_order", ["ascending", "descending", "runs", "random"])
+@pytest.mark.parametrize("semi", [False, True])
+def test_probe_map_reads_by_key_clustering(ctx, key_type, probe_order, semi):
+    """The rank-map probe reads its map words through the scalar cache when every 64-row slot of a pass spans at most two
+    neighbouring granules counted from its first live row (keys clustered like the probe order), and gathers otherwise — decided
+    per pass, so one input mixes both.  Probe keys ascending (TPC-H lineitem by order key), descending (never narrow: the first
+    row holds the largest key), ascending runs with jumps, random; keys below, at both ends of and beyond the window (a scalar
+    read has no range check: such a slot must gather); `semi`: no build column is read, so the key-set words alone are probed
+    (4 bytes per granule) and nothing is staged.  A date filter on the probe side drops rows inside the slots."""
+    rng = np.random.default_rng(hash((key_type, probe_order, semi)) & 0xFFFF)
+    np_t = np.int64 if key_type == "Int64" else np.int32
+    n_left, n_right, base = 40_000, 300_000, 1_000_003
+    lk = np.sort(rng.permutation(4 * n_left)[:n_left]) + base                      # unique, sorted: rank = row
+    lo, hi = int(lk[0]), int(lk[-1])
+    if probe_order == "random":
+        rk = rng.integers(lo - 500, hi + 500, n_right)
+    else:
+        rk = np.sort(rng.integers(lo - 500, hi + 500, n_right))                  # ~7 probe rows per 4 key values: a slot spans ~1 granule
+        if probe_order == "descending":
+            rk = rk[::-1].copy()
+        elif probe_order == "runs":
+            rk = np.concatenate([rk[i::7] for i in range(7)])                    # seven ascending runs: jumps in the middle of passes
+    rk[:6] = [lo, hi, lo - 1, hi + 1, lo - 40, hi + 40]
+    rk[-3:] = [hi, hi + 1, hi + 33]                                               # the last slot ends at and beyond the window's last granule
+    left = OrderedDict([("lk", OCol(key_type, lk.astype(np_t))), ("lx", OCol("Float64", rng.random(n_left)))])
+    right = OrderedDict([("rk", OCol(key_type, rk.astype(np_t))), ("ry", OCol("Int64", rng.integers(0, 10 ** 9, n_right))),
+                         ("rd", OCol("Date32", rng.integers(9000, 10000, n_right).astype(np.int32)))])
+    lm, rm = helpers.memory_exec(ctx, [[left]]), helpers.memory_exec(ctx, [[right]])
+    schema = {"rk": key_type, "ry": "Int64", "rd": "Date32"}
+    flt = ba.FilterExec(E.coerce((col("rd") >= E.date32("1995-01-01")).and_(col("rd") < E.date32("1996-06-01")), schema), rm)
+    for probe_side in (rm, flt):
+        j = ba.HashJoinExec(lm, probe_side, [("lk", "rk")], ba.plan.INNER)
+        if semi:
+            check(ba.ProjectionExec([(col("rk"), "rk"), (col("ry"), "ry")], j), ["rk", "ry"])
+        else:
+            check(j, ["lk", "rk", "ry", "lx"])
+
+
 @pytest.mark.parametrize("jt", JOIN_TYPES)
 def test_parents_that_read_only_some_join_columns(ctx, jt):
     """ProjectionExec / HashAggregateExec above a join ask it for the columns they read only (HashJoinExec::execute_needed):

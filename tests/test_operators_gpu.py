@@ -388,6 +388,26 @@ def test_hash_join_empty_sides(ctx):
         run_both(plan, ordered=False)
 
 
+@pytest.mark.parametrize("n", [1, 63, 1024, 1025, 70_000])
+def test_filter_utf8_column_against_a_literal(ctx, n):
+    """`Utf8 column = / != literal` has its own kernel (offsets, the length test, then the bytes 8 at a time with an overlapping last
+    load): literals of 0, 1, 7, 8, 9, 16, 17 and 64 bytes, 65 bytes (longer than the kernel's inline literal: the expression VM answers),
+    the literal on the left, values that share the literal's length or its first / last 8 bytes, NULL rows (dropped under either
+    operator)"""
+    from collections import OrderedDict
+    rng = np.random.default_rng(n)
+    lits = ["", "B", "BUILDIN", "BUILDING", "MACHINERY", "0123456789abcdef", "0123456789abcdefg", "x" * 64, "y" * 65]
+    pool = lits + ["BUILDINH", "AUILDING", "MACHINERZ", "0123456789abcdeX", "X123456789abcdefg", "x" * 63 + "y", "y" * 64 + "z", "b", "BUILDING "]
+    vals = [pool[int(i)] for i in rng.integers(0, len(pool), n)]
+    b = OrderedDict([("s", OCol("Utf8", vals, rng.random(n) > 0.15)), ("t", OCol("Utf8", vals)), ("i", OCol("Int64", np.arange(n)))])
+    m = helpers.memory_exec(ctx, [[b]])
+    for lit_s in lits:
+        for column in ("s", "t"):
+            run_both(ba.FilterExec(col(column).eq(lit(lit_s)), m))
+            run_both(ba.FilterExec(col(column).ne(lit(lit_s)), m))
+    run_both(ba.FilterExec(E.BinaryExpr(lit("BUILDING"), "Eq", col("s")), m))
+
+
 SORTS = [
     [E.PhysicalSortExpr(col("k")), E.PhysicalSortExpr(col("g"), descending=True)],
     [E.PhysicalSortExpr(col("f"), descending=True, nulls_first=False), E.PhysicalSortExpr(col("d"))],
