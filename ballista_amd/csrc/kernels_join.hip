@@ -444,23 +444,23 @@ join_rank_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void*
         const auto rk = rsrc_of(rkeys_v, base, KW);
 #pragma unroll
         for (int k = 0; k < FP_ROWS; ++k) {
-            if constexpr (KW == 4) r.key[k] = (K)__builtin_amdgcn_raw_buffer_load_b32(rk, (int)(lane_bk + 256u * k), 0, 0);
+            if constexpr (KW == 4) r.key[k] = (K)__builtin_amdgcn_raw_buffer_load_b32(rk, (int)lane_bk, 256 * k, 0);
             else {
                 typedef unsigned int v2u_t __attribute__((ext_vector_type(2)));
-                const v2u_t v = __builtin_amdgcn_raw_buffer_load_b64(rk, (int)(lane_bk + 512u * k), 0, 0);
+                const v2u_t v = __builtin_amdgcn_raw_buffer_load_b64(rk, (int)lane_bk, 512 * k, 0);
                 r.key[k] = (K)(((uint64_t)v.y << 32) | v.x);
             }
         }
         if (RESID) {
             const auto rg = rsrc_of(resid_probe, base, 4);
 #pragma unroll
-            for (int k = 0; k < FP_ROWS; ++k) r.g[RESID ? k : 0] = __builtin_amdgcn_raw_buffer_load_b32(rg, (int)(lane_b4 + 256u * k), 0, 0);
+            for (int k = 0; k < FP_ROWS; ++k) r.g[RESID ? k : 0] = __builtin_amdgcn_raw_buffer_load_b32(rg, (int)lane_b4, 256 * k, 0);
         }
 #pragma unroll
         for (int j = 0; j < NF; ++j) {
             const auto rf = rsrc_of(F.col[j < F.n ? j : 0], base, 4);
 #pragma unroll
-            for (int k = 0; k < FP_ROWS; ++k) r.f[j][k] = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rf, (int)(lane_b4 + 256u * k), 0, 0);
+            for (int k = 0; k < FP_ROWS; ++k) r.f[j][k] = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rf, (int)lane_b4, 256 * k, 0);
         }
     };
     // The range predicates, branch-free: lo <= f <= hi  <=>  (uint32)(f - lo) <= (uint32)(hi - lo) — one subtraction and one compare
@@ -529,9 +529,14 @@ join_rank_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void*
                 __builtin_amdgcn_sched_barrier(0);
             };
             bool live[FP_ROWS];
-            uint32_t d[FP_ROWS], m[FP_ROWS], lv[FP_ROWS], vo[FP_ROWS];
+            uint32_t d[FP_ROWS], m[FP_ROWS], lv[FP_ROWS];
             uint64_t pk[FP_ROWS];
-            constexpr uint32_t MAP_WORD = BITS ? 4u : 8u, DROPPED = 0u - MAP_WORD;
+            // d = the key's offset in the window (32 bits: a map read through a descriptor is shorter than 1 GiB, its window below 2^32
+            // values), all ones for a dropped row; the byte offset of the row's map word is derived from it wherever it is needed
+            // (one register per row slot instead of two: this kernel's occupancy is set by its registers)
+            constexpr uint32_t MAP_WORD = BITS ? 4u : 8u;
+            auto vo_of = [](uint32_t dk) { return BITS ? ((dk >> 3) & ~3u) : ((dk >> 2) & ~7u); };
+            constexpr uint32_t DROPPED = BITS ? 0x1FFFFFFCu : 0x3FFFFFF8u;        // vo_of(all ones): past the end of any such map, reads 0
 #pragma unroll
             for (int k = 0; k < FP_ROWS; ++k) {
                 uint32_t ok = EDGE ? (uint32_t)((base + 64u * k + lane) < n_right) & alive : alive;
@@ -543,12 +548,10 @@ join_rank_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void*
                 // then the whole decision — ONE compare, whose lane mask is the ballot (a ballot of an AND of conditions costs two
                 // more vector instructions per row slot)
                 if constexpr (BITS || MAPBUF) {
-                    // byte offset of the granule's word = (off >> 5) * 8 = (off >> 2) & ~7 (key-set words alone: (off >> 5) * 4): 32 bits hold
-                    // it for offsets below 2^34 (the map is shorter than 2 GiB: its window ends below 2^33); 8-byte keys beyond that must
-                    // not wrap into the map.  A dropped row gets the offset of the last word a 32-bit offset can name: out of range, reads 0.
-                    if (KW == 8) ok &= (uint32_t)((off >> 34) == 0);
-                    const uint32_t voff = BITS ? ((uint32_t)(off >> 3) & ~3u) : ((uint32_t)(off >> 2) & ~7u);
-                    vo[k] = ok ? voff : DROPPED;
+                    // byte offset of the granule's word = (off >> 5) * 8 = (off >> 2) & ~7 (key-set words alone: (off >> 5) * 4); 8-byte keys
+                    // beyond 2^32 must not wrap into the map
+                    if (KW == 8) ok &= (uint32_t)((off >> 32) == 0);
+                    d[k] = ok ? (uint32_t)off : 0xFFFFFFFFu;
                 } else {
                     ok &= (uint32_t)in_window<KW>(off, T.krange64);
                     // granule index (the window holds <= 2^36 values: < 2^31 granules; 4-byte keys stay in 32-bit arithmetic)
@@ -567,11 +570,12 @@ join_rank_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void*
                 bool narrow = scalar_map;
 #pragma unroll
                 for (int k = 0; k < FP_ROWS; ++k) {
-                    const uint64_t okm = __builtin_amdgcn_ballot_w64(vo[k] != DROPPED);
-                    const uint32_t first = okm ? (uint32_t)__builtin_amdgcn_readlane((int)vo[k], (int)__builtin_ctzll(okm)) : 0u;   // wave-uniform
+                    const uint32_t vo = vo_of(d[k]);
+                    const uint64_t okm = __builtin_amdgcn_ballot_w64(vo != DROPPED);
+                    const uint32_t first = okm ? (uint32_t)__builtin_amdgcn_readlane((int)vo, (int)__builtin_ctzll(okm)) : 0u;   // wave-uniform
                     g0[k] = first;
                     // ... and inside the map (the gather's descriptor range-checks; a scalar read does not): first + one word <= the zero granule
-                    narrow = narrow && first < T.rzero * MAP_WORD && __builtin_amdgcn_ballot_w64(vo[k] != DROPPED && (vo[k] - first) > MAP_WORD) == 0ull;
+                    narrow = narrow && first < T.rzero * MAP_WORD && __builtin_amdgcn_ballot_w64(vo != DROPPED && (vo - first) > MAP_WORD) == 0ull;
                 }
                 if (narrow) {
                     uint64_t w0[FP_ROWS], w1[FP_ROWS];
@@ -589,14 +593,14 @@ join_rank_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void*
                     }
                     if (!PERM && !RESID) prefetch();
 #pragma unroll
-                    for (int k = 0; k < FP_ROWS; ++k) pk[k] = vo[k] == DROPPED ? 0ull : (vo[k] == g0[k] ? w0[k] : w1[k]);
+                    for (int k = 0; k < FP_ROWS; ++k) pk[k] = d[k] == 0xFFFFFFFFu ? 0ull : (vo_of(d[k]) == g0[k] ? w0[k] : w1[k]);
                 } else {
 #pragma unroll
                     for (int k = 0; k < FP_ROWS; ++k) {
-                        if constexpr (BITS) pk[k] = __builtin_amdgcn_raw_buffer_load_b32(rmap, (int)vo[k], 0, 0);
+                        if constexpr (BITS) pk[k] = __builtin_amdgcn_raw_buffer_load_b32(rmap, (int)vo_of(d[k]), 0, 0);
                         else {
                             typedef unsigned int v2u_t __attribute__((ext_vector_type(2)));
-                            const v2u_t w = __builtin_amdgcn_raw_buffer_load_b64(rmap, (int)vo[k], 0, 0);
+                            const v2u_t w = __builtin_amdgcn_raw_buffer_load_b64(rmap, (int)vo_of(d[k]), 0, 0);
                             pk[k] = ((uint64_t)w.y << 32) | w.x;
                         }
                     }
@@ -803,12 +807,15 @@ hipError_t launch_join_filter_probe(const LaunchCfg& cfg, const NarrowJoinTable&
     const int64_t need = (n_tiles + BLOCK / 64 - 1) / (BLOCK / 64);
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;
-    static const int probe_rows = [] { const char* v = getenv("BHIP_PROBE_ROWS"); return v ? atoi(v) : 8; }();      // 8 rows per lane and pass (4-byte keys): profiles/r02_probe_variants_q3_sf100.txt
+    // rows per lane and pass (4-byte keys).  r02: 8 (profiles/r02_probe_variants_q3_sf100.txt, at 62 registers either way); with two passes
+    // of streamed rows in flight 8 rows cost 105-135 registers (3-4 waves per SIMD), 4 rows 62-78 (6-7 waves): Q3's probes 1.52 -> 1.42 ms,
+    // Q5's 1.31 -> 1.28 (profiles/r03_probe_kernel_pmc_and_variants.txt); BHIP_PROBE_ROWS=8 for the A/B
+    static const int probe_rows = [] { const char* v = getenv("BHIP_PROBE_ROWS"); return v ? atoi(v) : 4; }();
     // the rank map without NULL probe keys and without a left join: the one-read kernel
     const bool direct = T.rpack != nullptr && rsel == nullptr && matched == nullptr && !right_outer && (staging != nullptr) == (staging_rows != nullptr);
     // the packed map through a buffer descriptor when its granules fit one (BHIP_PROBE_MAP_FLAT=1: the flat-load variant, the A/B partner)
     static const bool map_flat = [] { const char* v = getenv("BHIP_PROBE_MAP_FLAT"); return v && atoi(v) != 0; }();
-    const bool map_buf = !map_flat && T.rpack != nullptr && (uint64_t)T.rzero * 8u < 0x7FFFFFF0ull;
+    const bool map_buf = !map_flat && T.rpack != nullptr && (uint64_t)T.rzero * 8u < 0x3FFFFFF0ull;      // < 1 GiB: windows below 2^32 values (the kernel keeps 32-bit offsets)
     // nothing staged (a semi-join), sorted one-column build side: the key-set words alone (BHIP_PROBE_NO_BITS=1: the packed map, the A/B partner)
     static const bool no_bits = [] { const char* v = getenv("BHIP_PROBE_NO_BITS"); return v && atoi(v) != 0; }();
     const bool bits_only = !no_bits && map_buf && T.rbits != nullptr && staging == nullptr && T.rperm == nullptr && resid_probe == nullptr;
