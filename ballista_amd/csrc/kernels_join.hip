@@ -487,15 +487,20 @@ join_rank_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void*
     constexpr uint32_t STRIP = 192;                                   // >= 64 more than the flush threshold
     __shared__ uint2 s_strip[BLOCK / 64][STRIP];
     uint2* __restrict__ strip = s_strip[threadIdx.x >> 6];
-    // The streamed rows are loaded TWO passes ahead: even passes live in one register set, odd passes in the other, and a pass
-    // refills its own set — for the pass after next — as soon as its keys have become map offsets.  (One pass ahead, a wave had its
-    // next 512 rows in flight only while it waited for its dependent map reads: a pass took one full memory round trip with the
-    // SIMD a quarter busy — rocprofv3 on Q5's lineitem launch: 4 waves per SIMD, 188 SIMD cycles per 64-row slot for ~33 instructions.)
-    static_assert(PASSES % 2 == 0, "even and odd passes alternate between the two register sets");
-    Regs set_a, set_b;
+    // The streamed rows are loaded TWO passes ahead: the passes of a tile cycle through SETS register sets, and a pass refills its own
+    // set — for the pass SETS later — as soon as its keys have become map offsets.  (One pass ahead, a wave had its next rows in flight
+    // only while it waited for its dependent map reads: a pass took one full memory round trip with the SIMD a quarter busy — rocprofv3
+    // on Q5's lineitem launch: 4 waves per SIMD, 188 SIMD cycles per 64-row slot for ~33 instructions.)  -DBHIP_PROBE_SETS=4: a whole
+    // tile ahead with 4 rows per lane — 84-116 registers instead of 62-78, and 2-4 % slower (profiles/r03_probe_kernel_pmc_and_variants.txt).
+#ifndef BHIP_PROBE_SETS
+#define BHIP_PROBE_SETS 2
+#endif
+    constexpr int SETS = BHIP_PROBE_SETS < PASSES ? BHIP_PROBE_SETS : PASSES;
+    static_assert(PASSES % SETS == 0, "the passes of a tile cycle through the register sets");
+    Regs sets[SETS];
     if (wave_id < n_tiles) {
-        load_any(wave_id * SEL_TILE, set_a);
-        load_any(wave_id * SEL_TILE + FP_CHUNK, set_b);
+#pragma unroll
+        for (int q = 0; q < SETS; ++q) load_any(wave_id * SEL_TILE + (uint32_t)q * FP_CHUNK, sets[q]);
     }
     for (uint32_t t = wave_id; t < n_tiles; t += n_waves) {
         const uint32_t tile_base = t * SEL_TILE;
@@ -524,8 +529,8 @@ join_rank_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void*
                 __builtin_amdgcn_sched_barrier(0);
                 // (after the wave's last tile the prefetch re-reads the final rows: harmless, and no branch around the loads)
                 const uint32_t nt = t + n_waves < n_tiles ? t + n_waves : n_tiles - 1;
-                const bool wraps = c + 2 >= PASSES;
-                load_any((wraps ? nt * SEL_TILE : tile_base) + (uint32_t)(wraps ? c + 2 - PASSES : c + 2) * FP_CHUNK, cur);
+                const bool wraps = c + SETS >= PASSES;
+                load_any((wraps ? nt * SEL_TILE : tile_base) + (uint32_t)(wraps ? c + SETS - PASSES : c + SETS) * FP_CHUNK, cur);
                 __builtin_amdgcn_sched_barrier(0);
             };
             bool live[FP_ROWS];
@@ -660,10 +665,16 @@ join_rank_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void*
         };
         if (t < full_tiles) {                                                             // wave-uniform
 #pragma unroll 1
-            for (int c = 0; c < PASSES; c += 2) { pass_body(c, set_a, std::false_type{}); pass_body(c + 1, set_b, std::false_type{}); }
+            for (int c = 0; c < PASSES; c += SETS) {
+#pragma unroll
+                for (int q = 0; q < SETS; ++q) pass_body(c + q, sets[q], std::false_type{});
+            }
         } else {
 #pragma unroll 1
-            for (int c = 0; c < PASSES; c += 2) { pass_body(c, set_a, std::true_type{}); pass_body(c + 1, set_b, std::true_type{}); }
+            for (int c = 0; c < PASSES; c += SETS) {
+#pragma unroll
+                for (int q = 0; q < SETS; ++q) pass_body(c + q, sets[q], std::true_type{});
+            }
         }
         if (staged && strip_cnt != 0u) flush();
         if (lane == 0) tile_counts[t] = tile_cnt;
