@@ -444,23 +444,25 @@ join_rank_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void*
         const auto rk = rsrc_of(rkeys_v, base, KW);
 #pragma unroll
         for (int k = 0; k < FP_ROWS; ++k) {
-            if constexpr (KW == 4) r.key[k] = (K)__builtin_amdgcn_raw_buffer_load_b32(rk, (int)lane_bk, 256 * k, 0);
+            // (the row slot's step rides in the VECTOR offset: a scalar offset is left out of the descriptor's range check, and the last
+            // tile relies on that check to read zeros, not memory, past the end of the column)
+            if constexpr (KW == 4) r.key[k] = (K)__builtin_amdgcn_raw_buffer_load_b32(rk, (int)(lane_bk + 256u * k), 0, 0);
             else {
                 typedef unsigned int v2u_t __attribute__((ext_vector_type(2)));
-                const v2u_t v = __builtin_amdgcn_raw_buffer_load_b64(rk, (int)lane_bk, 512 * k, 0);
+                const v2u_t v = __builtin_amdgcn_raw_buffer_load_b64(rk, (int)(lane_bk + 512u * k), 0, 0);
                 r.key[k] = (K)(((uint64_t)v.y << 32) | v.x);
             }
         }
         if (RESID) {
             const auto rg = rsrc_of(resid_probe, base, 4);
 #pragma unroll
-            for (int k = 0; k < FP_ROWS; ++k) r.g[RESID ? k : 0] = __builtin_amdgcn_raw_buffer_load_b32(rg, (int)lane_b4, 256 * k, 0);
+            for (int k = 0; k < FP_ROWS; ++k) r.g[RESID ? k : 0] = __builtin_amdgcn_raw_buffer_load_b32(rg, (int)(lane_b4 + 256u * k), 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < NF; ++j) {
             const auto rf = rsrc_of(F.col[j < F.n ? j : 0], base, 4);
 #pragma unroll
-            for (int k = 0; k < FP_ROWS; ++k) r.f[j][k] = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rf, (int)lane_b4, 256 * k, 0);
+            for (int k = 0; k < FP_ROWS; ++k) r.f[j][k] = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rf, (int)(lane_b4 + 256u * k), 0, 0);
         }
     };
     // The range predicates, branch-free: lo <= f <= hi  <=>  (uint32)(f - lo) <= (uint32)(hi - lo) — one subtraction and one compare
@@ -598,7 +600,12 @@ join_rank_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void*
                     }
                     if (!PERM && !RESID) prefetch();
 #pragma unroll
-                    for (int k = 0; k < FP_ROWS; ++k) pk[k] = d[k] == 0xFFFFFFFFu ? 0ull : (vo_of(d[k]) == g0[k] ? w0[k] : w1[k]);
+                    for (int k = 0; k < FP_ROWS; ++k) {
+                        // (DROPPED, not "d is all ones": a key up to 31 below the window's first maps to the same out-of-range word and
+                        // was left out of the narrowness test like a dropped row — it must read zeros like one)
+                        const uint32_t vo = vo_of(d[k]);
+                        pk[k] = vo == DROPPED ? 0ull : (vo == g0[k] ? w0[k] : w1[k]);
+                    }
                 } else {
 #pragma unroll
                     for (int k = 0; k < FP_ROWS; ++k) {

@@ -288,7 +288,12 @@ def test_probe_map_reads_by_key_clustering(ctx, key_type, probe_order, semi):
             rk = np.concatenate([rk[i::7] for i in range(7)])                    # seven ascending runs: jumps in the middle of passes
     rk[:6] = [lo, hi, lo - 1, hi + 1, lo - 40, hi + 40]
     rk[-3:] = [hi, hi + 1, hi + 33]                                               # the last slot ends at and beyond the window's last granule
+    # whole passes of NARROW slots that straddle the window's ends: eight rows per key value from 20 below the first key (offsets
+    # that wrap to just under 2^32: out of range like a dropped row, and never a match) and up to 27 above the last
+    edge = np.arange(1024) // 8
+    rk = np.concatenate([lo - 20 + edge, rk, hi - 100 + edge, lo - 31 + edge])
     left = OrderedDict([("lk", OCol(key_type, lk.astype(np_t))), ("lx", OCol("Float64", rng.random(n_left)))])
+    n_right = len(rk)
     right = OrderedDict([("rk", OCol(key_type, rk.astype(np_t))), ("ry", OCol("Int64", rng.integers(0, 10 ** 9, n_right))),
                          ("rd", OCol("Date32", rng.integers(9000, 10000, n_right).astype(np.int32)))])
     lm, rm = helpers.memory_exec(ctx, [[left]]), helpers.memory_exec(ctx, [[right]])
