@@ -541,9 +541,14 @@ join_rank_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void*
             // d = the key's offset in the window (32 bits: a map read through a descriptor is shorter than 1 GiB, its window below 2^32
             // values), all ones for a dropped row; the byte offset of the row's map word is derived from it wherever it is needed
             // (one register per row slot instead of two: this kernel's occupancy is set by its registers)
+            // 8-byte keys keep the word's byte offset in a register of its own: their windows reach 2^33 values (TPC-H SF1000 order keys in
+            // dbgen's layout: 6 x 10^9, a 1.5 GB map) and those variants take 4 rows per lane anyway
             constexpr uint32_t MAP_WORD = BITS ? 4u : 8u;
-            auto vo_of = [](uint32_t dk) { return BITS ? ((dk >> 3) & ~3u) : ((dk >> 2) & ~7u); };
-            constexpr uint32_t DROPPED = BITS ? 0x1FFFFFFCu : 0x3FFFFFF8u;        // vo_of(all ones): past the end of any such map, reads 0
+            uint32_t vo8[KW == 8 ? FP_ROWS : 1];
+            auto vo_of = [&](int k) { return KW == 8 ? vo8[KW == 8 ? k : 0] : (BITS ? ((d[k] >> 3) & ~3u) : ((d[k] >> 2) & ~7u)); };
+            // the offset a dropped row carries: past the end of any map its variant reads through a descriptor (4-byte keys: what
+            // d = all ones yields; 8-byte keys: the last word a 32-bit offset can name)
+            constexpr uint32_t DROPPED = KW == 8 ? (0u - MAP_WORD) : (BITS ? 0x1FFFFFFCu : 0x3FFFFFF8u);
 #pragma unroll
             for (int k = 0; k < FP_ROWS; ++k) {
                 uint32_t ok = EDGE ? (uint32_t)((base + 64u * k + lane) < n_right) & alive : alive;
@@ -557,8 +562,12 @@ join_rank_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void*
                 if constexpr (BITS || MAPBUF) {
                     // byte offset of the granule's word = (off >> 5) * 8 = (off >> 2) & ~7 (key-set words alone: (off >> 5) * 4); 8-byte keys
                     // beyond 2^32 must not wrap into the map
-                    if (KW == 8) ok &= (uint32_t)((off >> 32) == 0);
-                    d[k] = ok ? (uint32_t)off : 0xFFFFFFFFu;
+                    if constexpr (KW == 8) {
+                        ok &= (uint32_t)((off >> 34) == 0);                  // (the word's byte offset fits 32 bits below 2^34; beyond that a key must not wrap into the map)
+                        vo8[k] = ok ? (BITS ? ((uint32_t)(off >> 3) & ~3u) : ((uint32_t)(off >> 2) & ~7u)) : DROPPED;
+                    } else {
+                        d[k] = ok ? (uint32_t)off : 0xFFFFFFFFu;
+                    }
                 } else {
                     ok &= (uint32_t)in_window<KW>(off, T.krange64);
                     // granule index (the window holds <= 2^36 values: < 2^31 granules; 4-byte keys stay in 32-bit arithmetic)
@@ -577,7 +586,7 @@ join_rank_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void*
                 bool narrow = scalar_map;
 #pragma unroll
                 for (int k = 0; k < FP_ROWS; ++k) {
-                    const uint32_t vo = vo_of(d[k]);
+                    const uint32_t vo = vo_of(k);
                     const uint64_t okm = __builtin_amdgcn_ballot_w64(vo != DROPPED);
                     const uint32_t first = okm ? (uint32_t)__builtin_amdgcn_readlane((int)vo, (int)__builtin_ctzll(okm)) : 0u;   // wave-uniform
                     g0[k] = first;
@@ -603,16 +612,16 @@ join_rank_probe_kernel(const NarrowJoinTable T, const ProbeFilter F, const void*
                     for (int k = 0; k < FP_ROWS; ++k) {
                         // (DROPPED, not "d is all ones": a key up to 31 below the window's first maps to the same out-of-range word and
                         // was left out of the narrowness test like a dropped row — it must read zeros like one)
-                        const uint32_t vo = vo_of(d[k]);
+                        const uint32_t vo = vo_of(k);
                         pk[k] = vo == DROPPED ? 0ull : (vo == g0[k] ? w0[k] : w1[k]);
                     }
                 } else {
 #pragma unroll
                     for (int k = 0; k < FP_ROWS; ++k) {
-                        if constexpr (BITS) pk[k] = __builtin_amdgcn_raw_buffer_load_b32(rmap, (int)vo_of(d[k]), 0, 0);
+                        if constexpr (BITS) pk[k] = __builtin_amdgcn_raw_buffer_load_b32(rmap, (int)vo_of(k), 0, 0);
                         else {
                             typedef unsigned int v2u_t __attribute__((ext_vector_type(2)));
-                            const v2u_t w = __builtin_amdgcn_raw_buffer_load_b64(rmap, (int)vo_of(d[k]), 0, 0);
+                            const v2u_t w = __builtin_amdgcn_raw_buffer_load_b64(rmap, (int)vo_of(k), 0, 0);
                             pk[k] = ((uint64_t)w.y << 32) | w.x;
                         }
                     }
@@ -833,7 +842,8 @@ hipError_t launch_join_filter_probe(const LaunchCfg& cfg, const NarrowJoinTable&
     const bool direct = T.rpack != nullptr && rsel == nullptr && matched == nullptr && !right_outer && (staging != nullptr) == (staging_rows != nullptr);
     // the packed map through a buffer descriptor when its granules fit one (BHIP_PROBE_MAP_FLAT=1: the flat-load variant, the A/B partner)
     static const bool map_flat = [] { const char* v = getenv("BHIP_PROBE_MAP_FLAT"); return v && atoi(v) != 0; }();
-    const bool map_buf = !map_flat && T.rpack != nullptr && (uint64_t)T.rzero * 8u < 0x3FFFFFF0ull;      // < 1 GiB: windows below 2^32 values (the kernel keeps 32-bit offsets)
+    // the packed map through a descriptor: shorter than 1 GiB for 4-byte keys (the kernel keeps their 32-bit offsets only), 2 GiB for 8-byte keys
+    const bool map_buf = !map_flat && T.rpack != nullptr && (uint64_t)T.rzero * 8u < (key_width == 8 ? 0x7FFFFFF0ull : 0x3FFFFFF0ull);
     // nothing staged (a semi-join), sorted one-column build side: the key-set words alone (BHIP_PROBE_NO_BITS=1: the packed map, the A/B partner)
     static const bool no_bits = [] { const char* v = getenv("BHIP_PROBE_NO_BITS"); return v && atoi(v) != 0; }();
     const bool bits_only = !no_bits && map_buf && T.rbits != nullptr && staging == nullptr && T.rperm == nullptr && resid_probe == nullptr;
