@@ -266,18 +266,21 @@ def test_rank_map_window_beyond_2_to_the_30(jt, order, monkeypatch):
 @pytest.mark.parametrize("key_type", ["Int32", "Int64"])
 @pytest.mark.parametrize("probe_order", ["ascending", "descending", "runs", "random"])
 @pytest.mark.parametrize("semi", [False, True])
-def test_probe_map_reads_by_key_clustering(ctx, key_type, probe_order, semi):
+@pytest.mark.parametrize("build", ["sorted", "shuffled"])
+def test_probe_map_reads_by_key_clustering(ctx, key_type, probe_order, semi, build):
     """The rank-map probe reads its map words through the scalar cache when every 64-row slot of a pass spans at most two
     neighbouring granules counted from its first live row (keys clustered like the probe order), and gathers otherwise — decided
     per pass, so one input mixes both.  Probe keys ascending (TPC-H lineitem by order key), descending (never narrow: the first
     row holds the largest key), ascending runs with jumps, random; keys below, at both ends of and beyond the window (a scalar
     read has no range check: such a slot must gather); `semi`: no build column is read, so the key-set words alone are probed
     (4 bytes per granule) and nothing is staged.  A date filter on the probe side drops rows inside the slots."""
-    rng = np.random.default_rng(hash((key_type, probe_order, semi)) & 0xFFFF)
+    rng = np.random.default_rng(sum(map(ord, key_type + probe_order + build)) + int(semi))
     np_t = np.int64 if key_type == "Int64" else np.int32
     n_left, n_right, base = 40_000, 300_000, 1_000_003
     lk = np.sort(rng.permutation(4 * n_left)[:n_left]) + base                      # unique, sorted: rank = row
     lo, hi = int(lk[0]), int(lk[-1])
+    if build == "shuffled":
+        lk = rng.permutation(lk)                                                    # rank -> row through the permutation (PERM)
     if probe_order == "random":
         rk = rng.integers(lo - 500, hi + 500, n_right)
     else:
