@@ -187,7 +187,7 @@ struct TimedLaunches {
 GroupRec* hash_aggregate(const Exec& ex, Temp& tmp, const ScanParams& P0, const ProgramBuilder& pb,
                          const std::vector<BatchPtr>& inputs, bool nullable, int64_t* n_groups, ScanStatus* status,
                          TimedLaunches& /*timer: only the register-path scan kernel is the timed (dominant) kernel*/,
-                         std::atomic<int>* clustered_hint) {
+                         std::atomic<int>* clustered_hint, SlotSource* slots_out) {
     const LaunchCfg cfg = ex.cfg();
     int64_t total_rows = 0;
     for (auto& b : inputs) total_rows += b->n_rows;
@@ -397,6 +397,19 @@ GroupRec* hash_aggregate(const Exec& ex, Temp& tmp, const ScanParams& P0, const 
         TIMED_LAUNCH_N(ex, "det_spill_combine", n_spill, launch_det_spill_combine(cfg, D, kb->as<uint64_t>(), pb2->as<uint32_t>(), n_spill));
     }
     if (pb.can_raise()) check_scan_status(ex, status);   // (after the one wait above: immediate; fixed-width keys and no integer division raise nothing)
+    *n_groups = (int64_t)ng;
+    static const bool no_slot_emit = [] { const char* v = getenv("BHIP_NO_SLOT_EMIT"); return v && atoi(v) != 0; }();
+    if (ng && distinct_runs && slots_out && !no_slot_emit) {
+        // distinct runs: slot g IS group g — the caller emits its columns straight from the slot arrays (no GroupRec table in between)
+        slots_out->keys128 = T.keys128;
+        slots_out->head = run_head;
+        slots_out->acc = T.acc;
+        slots_out->nvalid = nullable ? T.nvalid : nullptr;
+        slots_out->rows = T.rows;
+        slots_out->n_acc = T.n_acc;
+        slots_out->valid = 1;
+        return nullptr;
+    }
     GroupRec* table = tmp.get<GroupRec>(ng ? ng : 1);
     if (ng && distinct_runs) TIMED_LAUNCH_N(ex, "run_compact", ng, launch_run_compact(cfg, T, run_head, (uint32_t)ng, nullable, table));
     else if (ng) TIMED_LAUNCH_N(ex, "hash_agg_compact", cap, launch_hash_agg_compact(cfg, T, dense, nullable, table));
@@ -693,6 +706,45 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
         }
         return out;
     };
+    // ... and from the run slots of a clustered hash aggregate (kernels_util.hip: emit_slots_kernel), every column in one launch
+    SlotSource slots;
+    memset(&slots, 0, sizeof(slots));
+    auto emit_slots = [&](int64_t n) {
+        auto out = std::make_shared<Batch>();
+        out->schema = out_schema;
+        out->ctx = ex.ctx;
+        out->n_rows = n;
+        const auto& kinfo = pb.key_info();               // (the hash path packs keys with the VM's layout)
+        utf8_cols.clear();
+        EmitAllArgs A;
+        memset(&A, 0, sizeof(A));
+        A.n_keys = (int32_t)group_.size();
+        A.n_values = (int32_t)emits.size();
+        for (size_t gi = 0; gi < group_.size(); ++gi) {
+            Column c;
+            c.dtype = out_schema->fields[gi].dtype;
+            c.length = n;
+            A.key[gi] = EmitKeySpec{kinfo[gi].pos, kinfo[gi].width, kinfo[gi].nullable, c.dtype};
+            if (kinfo[gi].nullable) { c.validity = make_buffer(ex, bitmap_bytes(n) + 8); A.key_validity[gi] = c.validity->as<uint64_t>(); }
+            c.data = make_buffer(ex, (size_t)n * dtype_width(c.dtype) + 8);
+            A.key_data[gi] = c.data->ptr();
+            out->cols.push_back(std::move(c));
+        }
+        for (size_t k = 0; k < emits.size(); ++k) {
+            const Field& fld = out_schema->fields[group_.size() + k];
+            Column c;
+            c.dtype = fld.dtype;
+            c.length = n;
+            c.data = make_buffer(ex, (size_t)n * dtype_width(c.dtype) + 8);
+            if (fld.nullable) { c.validity = make_buffer(ex, bitmap_bytes(n) + 8); A.value_validity[k] = c.validity->as<uint64_t>(); }
+            A.value[k] = emits[k];
+            A.value[k].count_is_rows = nullable ? 0 : 1;
+            A.value_data[k] = c.data->ptr();
+            out->cols.push_back(std::move(c));
+        }
+        TIMED_LAUNCH_N(ex, "emit_slots", n, launch_emit_slots(cfg, slots, n, A));
+        return out;
+    };
     // the row count (and the Utf8 byte totals) once the host knows them
     auto finish_table = [&](const std::shared_ptr<Batch>& out, int64_t n, const uint64_t* host_totals) {
         out->n_rows = n;
@@ -742,7 +794,11 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
             // ---- hash path: one device-wide table, atomics ----------------------------------------
             early.reset();
             sop_layout = false;              // the hash path packs keys with the VM's layout
-            table = hash_aggregate(ex, tmp, P0, pb, inputs, nullable, &n_groups, status, timer, &clustered_hint_);
+            // (fixed-width, non-Boolean keys: a clustered input's groups can be emitted straight from their run slots)
+            bool slot_keys = group_.size() <= (size_t)EMIT_ALL_MAX_KEYS && emits.size() <= (size_t)EMIT_ALL_MAX_VALUES;
+            for (size_t gi = 0; gi < group_.size(); ++gi)
+                slot_keys = slot_keys && out_schema->fields[gi].dtype != DT_UTF8 && out_schema->fields[gi].dtype != DT_BOOLEAN;
+            table = hash_aggregate(ex, tmp, P0, pb, inputs, nullable, &n_groups, status, timer, &clustered_hint_, slot_keys ? &slots : nullptr);
             break;
         }
         // ---- register path ----------------------------------------------------------------------
@@ -839,7 +895,7 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
         finish_table(early, n_groups, tail.totals);
         return {early};
     }
-    auto out = emit_table(table, n_groups, nullptr);
+    auto out = slots.valid ? emit_slots(n_groups) : emit_table(table, n_groups, nullptr);
     if (!utf8_cols.empty()) {
         std::vector<uint64_t> host(group_.size() + 1);
         if (group_.size() <= (size_t)TAIL_TOTALS) {

@@ -919,6 +919,68 @@ emit_all_kernel(EmitAllArgs A) {
         }
     }
 }
+__global__ void __launch_bounds__(BLOCK)
+emit_slots_kernel(SlotSource S, int64_t n_groups, EmitAllArgs A) {
+    const int64_t n_round = (n_groups + 63) & ~(int64_t)63;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n_round; i += (int64_t)gridDim.x * BLOCK) {
+        const bool in = i < n_groups;
+        const int64_t j = in ? i : 0;
+        GroupRec g;                                      // (only its key words are ever read: key_get)
+        const uint32_t o = S.head[j];
+        g.k0 = S.keys128[2ull * o];
+        g.k1 = S.keys128[2ull * o + 1];
+        const uint64_t rows = S.rows[j];
+        const uint64_t* acc = S.acc + (size_t)j * S.n_acc;
+        const uint64_t* nvalid = S.nvalid ? S.nvalid + (size_t)j * S.n_acc : nullptr;
+        for (int c = 0; c < A.n_keys; ++c) {
+            const EmitKeySpec spec = A.key[c];
+            int pos = spec.pos, width = spec.width;
+            bool valid = in;
+            if (spec.nullable) { valid = in && key_get(g, pos, 1) != 0; pos += 1; width -= 1; }
+            if (A.key_validity[c] != nullptr) {
+                const uint64_t w = __ballot(valid);
+                if ((threadIdx.x & 63) == 0) A.key_validity[c][i >> 6] = w;
+            }
+            if (in) dt_store(spec.dtype, A.key_data[c], i, valid ? key_get(g, pos, width) : 0);
+        }
+        for (int c = 0; c < A.n_values; ++c) {
+            const EmitValueSpec spec = A.value[c];
+            // (emit_value_of, reading the slot arrays instead of a GroupRec)
+            const uint64_t cnt_a = spec.count_is_rows || !nvalid ? rows : nvalid[spec.acc_a];
+            bool valid = true;
+            uint64_t v = 0;
+            switch (spec.kind) {
+                case EMIT_VALUE: v = acc[spec.acc_a]; valid = cnt_a > 0; break;
+                case EMIT_COUNT: v = cnt_a; break;
+                case EMIT_ROWS: v = rows; break;
+                case EMIT_RAW: v = acc[spec.acc_a]; break;
+                case EMIT_AVG: valid = cnt_a > 0; v = valid ? d2u(u2d(acc[spec.acc_a]) / (double)cnt_a) : 0; break;
+                case EMIT_AVG_ACC: {
+                    const uint64_t cn = acc[spec.acc_b];
+                    valid = cn > 0 && (nvalid ? nvalid[spec.acc_a] : rows) > 0;
+                    v = valid ? d2u(u2d(acc[spec.acc_a]) / (double)cn) : 0;
+                } break;
+                default: break;
+            }
+            valid = valid && in;
+            if (in) dt_store(spec.dtype, A.value_data[c], i, valid ? v : 0);
+            if (A.value_validity[c] != nullptr) {
+                const uint64_t w = __ballot(valid);
+                if ((threadIdx.x & 63) == 0) A.value_validity[c][i >> 6] = w;
+            }
+        }
+    }
+}
+hipError_t launch_emit_slots(const LaunchCfg& cfg, const SlotSource& S, int64_t n_groups, const EmitAllArgs& A) {
+    if (A.n_keys > EMIT_ALL_MAX_KEYS || A.n_values > EMIT_ALL_MAX_VALUES) return hipErrorInvalidValue;
+    if (n_groups <= 0) return hipSuccess;
+    int64_t g = (n_groups + BLOCK - 1) / BLOCK;
+    const int64_t cap = (int64_t)cfg.device_cus * 16;
+    if (g > cap) g = cap;
+    hipLaunchKernelGGL(emit_slots_kernel, dim3((unsigned)g), dim3(BLOCK), 0, cfg.stream, S, n_groups, A);
+    return hipGetLastError();
+}
+
 hipError_t launch_emit_all(const LaunchCfg& cfg, const EmitAllArgs& A) {
     if (A.n_keys > EMIT_ALL_MAX_KEYS || A.n_values > EMIT_ALL_MAX_VALUES) return hipErrorInvalidValue;
     hipLaunchKernelGGL(emit_all_kernel, dim3(1), dim3(EMIT_ALL_MAX_GROUPS), 0, cfg.stream, A);

@@ -140,6 +140,19 @@ struct EmitAllArgs {
     uint64_t* value_validity[EMIT_ALL_MAX_VALUES];
 };
 hipError_t launch_emit_all(const LaunchCfg& cfg, const EmitAllArgs& A);
+// The same columns for ANY number of groups straight from the run slots of a clustered hash aggregate (host/ops_agg.cpp: distinct
+// runs — slot g IS group g): key of the run's first row, accumulators of slot g; no GroupRec table is written and read back
+// (Q3's 1.13 M groups: run_compact + four emit launches were 0.22 ms).  Fixed-width, non-Boolean keys only; A.table / A.status unused.
+struct SlotSource {
+    const uint64_t* keys128;   // packed keys of every input row
+    const uint32_t* head;      // first row of run g
+    const uint64_t* acc;       // [groups][n_acc]
+    const uint64_t* nvalid;    // [groups][n_acc], or null: every accumulator saw every row of its group
+    const uint64_t* rows;      // [groups]
+    int32_t n_acc;
+    int32_t valid;             // host side: this source is set
+};
+hipError_t launch_emit_slots(const LaunchCfg& cfg, const SlotSource& S, int64_t n_groups, const EmitAllArgs& A);
 
 // n_groups <= EMIT_UTF8_SMALL_MAX: lengths + prefix sum + offsets (n + 1) + bytes + validity + byte total in one launch
 constexpr int64_t EMIT_UTF8_SMALL_MAX = 4096;
