@@ -135,6 +135,32 @@ Column upload_chunk(const Exec& ex, const PqColumn& pc, const HostChunk& hc, std
     // Here a chunk is one set of buffers: page bytes copied behind each other, ONE run table (out_start and byte offsets re-based,
     // the bit width travels with each run), ONE expansion, ONE gather — one host wait per string column chunk — and PLAIN pages are
     // copied straight to their rows of the column.
+    if (hc.staged == pq::STAGED_FIXED) {                      // the host walk left ONE buffer: one copy
+        Column c;
+        c.dtype = pc.dtype;
+        c.length = hc.rows;
+        const double t0 = trace_now();
+        c.data = make_buffer(ex, hc.staged_bytes.size() + 16);
+        if (!hc.staged_bytes.empty()) HIP_CHECK(hipMemcpyAsync(c.data->ptr(), hc.staged_bytes.data(), hc.staged_bytes.size(), hipMemcpyHostToDevice, ex.stream));
+        g_trace.copies += trace_now() - t0;
+        return c;
+    }
+    if (hc.staged == pq::STAGED_DICT) {                       // ... one buffer of index bytes and one run table: two copies, one expansion, one gather
+        const int64_t rows_total = hc.rows;
+        BufferPtr dbytes = upload(ex, hc.staged_bytes.data(), hc.staged_bytes.size());
+        BufferPtr druns = upload(ex, hc.staged_runs.data(), hc.staged_runs.size() * sizeof(PqRun));
+        BufferPtr dense = make_buffer(ex, (size_t)rows_total * 4 + 16);
+        keep.push_back(dbytes); keep.push_back(druns); keep.push_back(dense);
+        const double t1 = trace_now();
+        TIMED_LAUNCH_N(ex, "pq_expand_runs", rows_total, launch_pq_expand_runs(cfg, druns->as<PqRun>(), (uint32_t)hc.staged_runs.size(), dbytes->as<uint8_t>(), 0,
+                                                                               (uint32_t)rows_total, (uint32_t)dict.length, dense->as<uint32_t>()));
+        Column g = take_column(ex, dict, dense->as<uint32_t>(), rows_total);
+        g.dtype = pc.dtype;
+        g.validity = nullptr;
+        g.length = rows_total;
+        g_trace.dict += trace_now() - t1;
+        return g;
+    }
     bool any_nulls = false, all_dict = !hc.pages.empty(), all_fixed = !hc.pages.empty();
     int64_t rows_total = 0;
     size_t bytes_total = 0, runs_total = 0;
@@ -368,9 +394,11 @@ public:
             static const bool trace = [] { const char* v = getenv("BHIP_PARQUET_TRACE"); return v && atoi(v) != 0; }();
             double t_walk = 0, t_issue = 0, t_dev = 0;
             auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-            // the host walks run AHEAD row groups in front of the device half (default 2: a row group has about as many chunks as
-            // columns, and two of them keep sixteen walkers busy; every group in flight holds its decoded pages in pinned memory)
-            static const size_t ahead = [] { const char* v = getenv("BHIP_PARQUET_AHEAD"); const int a = v ? atoi(v) : 2; return (size_t)(a < 1 ? 1 : a > 8 ? 8 : a); }();
+            // the host walks run AHEAD row groups in front of the device half (default 4: a row group has about as many chunks as
+            // columns and its string chunks take several times as long as the others — with the device half down to ~60 ms of issue
+            // work per GiB the calling thread otherwise waits for the slowest walker of every group: 215 / 265 / 271 M rows/s at
+            // 2 / 3 / 4; every group in flight holds its decoded chunks in pinned memory, ~0.3 GB each for lineitem)
+            static const size_t ahead = [] { const char* v = getenv("BHIP_PARQUET_AHEAD"); const int a = v ? atoi(v) : 4; return (size_t)(a < 1 ? 1 : a > 8 ? 8 : a); }();
             std::deque<Parsed> inflight;
             size_t started = 0;
             for (; started < units.size() && started < ahead; ++started) inflight.push_back(start(units[started]));

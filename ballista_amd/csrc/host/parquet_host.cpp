@@ -484,6 +484,49 @@ void parse_dictionary(const PqColumn& pc, const uint8_t* vals, size_t nbytes, in
 
 }  // namespace
 
+// pages -> one set of chunk buffers where that is possible (parquet_host.hpp: ChunkStaging); BHIP_PARQUET_PER_PAGE=1 keeps the pages
+static void stage_chunk(HostChunk& hc, size_t width) {
+    static const bool per_page = [] { const char* v = getenv("BHIP_PARQUET_PER_PAGE"); return v && atoi(v) != 0; }();
+    if (per_page || hc.pages.size() < 2) return;
+    bool any_nulls = false, all_dict = true, all_fixed = true;
+    int64_t rows_total = 0;
+    size_t bytes_total = 0, runs_total = 0;
+    for (const HostPage& pg : hc.pages) {
+        any_nulls = any_nulls || pg.has_nulls;
+        all_dict = all_dict && pg.kind == PG_DICT;
+        all_fixed = all_fixed && pg.kind == PG_FIXED;
+        rows_total += pg.n;
+        bytes_total += pg.bytes.size();
+        runs_total += pg.runs.size();
+    }
+    if (any_nulls) return;
+    if (all_fixed && width) {
+        hc.staged_bytes.reserve(bytes_total);
+        for (HostPage& pg : hc.pages) {
+            hc.staged_bytes.insert(hc.staged_bytes.end(), pg.bytes.begin(), pg.bytes.begin() + width * (size_t)pg.n);
+            HostVec<uint8_t>().swap(pg.bytes);
+        }
+        hc.staged = STAGED_FIXED;
+    } else if (all_dict && bytes_total < 0xFFFFFFF0u && rows_total < 0xFFFFFFF0ll) {
+        hc.staged_bytes.reserve(bytes_total);
+        hc.staged_runs.reserve(runs_total);
+        int64_t row = 0;
+        for (HostPage& pg : hc.pages) {
+            const size_t byte_base = hc.staged_bytes.size();
+            hc.staged_bytes.insert(hc.staged_bytes.end(), pg.bytes.begin(), pg.bytes.end());
+            for (PqRun r : pg.runs) {
+                r.out_start += (uint32_t)row;
+                if (r.packed) r.value += (uint32_t)byte_base;
+                hc.staged_runs.push_back(r);
+            }
+            row += pg.n;
+            HostVec<uint8_t>().swap(pg.bytes);
+            std::vector<PqRun>().swap(pg.runs);
+        }
+        hc.staged = STAGED_DICT;
+    }
+}
+
 HostChunk parse_chunk(const uint8_t* raw, size_t len, const PqColumn& pc, const PqChunk& ch, int64_t n_rows) {
     if (ch.codec != 0 && ch.codec != 1) fail(BHIP_ENOTIMPL, "Parquet: column '" + pc.name + "' uses compression codec " + std::to_string(ch.codec) + " (UNCOMPRESSED and SNAPPY are read)");
     HostChunk out;
@@ -624,6 +667,7 @@ HostChunk parse_chunk(const uint8_t* raw, size_t len, const PqColumn& pc, const 
         }
         out.rows += n;
     }
+    stage_chunk(out, width);
     return out;
 }
 
