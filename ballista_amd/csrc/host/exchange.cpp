@@ -450,8 +450,8 @@ public:
         if (fits) pack_batch(ex, *mine, send->as<uint8_t>() + head_bytes);
         t_->all_gather(send->ptr(), recv->ptr(), SLOT, stream_);
         std::vector<int64_t> heads((size_t)world_ * H);
-        for (int r = 0; r < world_; ++r)
-            HIP_CHECK(hipMemcpyAsync(&heads[(size_t)r * H], recv->as<uint8_t>() + (size_t)r * SLOT, H * 8, hipMemcpyDeviceToHost, stream_));
+        // every rank's header in ONE strided copy (a copy call per rank is ~10 us each: eight of them per all_gather of an 8-GPU step)
+        HIP_CHECK(hipMemcpy2DAsync(heads.data(), H * 8, recv->ptr(), SLOT, H * 8, (size_t)world_, hipMemcpyDeviceToHost, stream_));
         HIP_CHECK(hipStreamSynchronize(stream_));
         for (int r = 0; r < world_; ++r) check_header(&heads[(size_t)r * H], *schema, "all_gather");
         bool all_fit = true;

@@ -811,7 +811,21 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
         const bool lean_now = use_lean && (gmax == 1 || gmax == 4);
         const bool sop_now = !lean_now && use_sop;
         sop_layout = lean_now || sop_now;
+        // several SMALL input batches on the VM kernel (the partial states of N ranks under a Final aggregate: one 4-row batch per
+        // rank): one launch for all of them — the kernel's fixed cost is ~0.1 ms per launch with 16 accumulators, which a rank of an
+        // 8-GPU Q1 would pay eight times per step
+        int64_t cur_rows = 0;
+        for (auto& b : cur) cur_rows += b->n_rows;
+        const bool together = !lean_now && !sop_now && cur.size() > 1 && cur.size() <= 4096 && cur_rows <= (1 << 20);
+        if (together) {
+            std::vector<ScanParams> Ps(cur.size(), P0);
+            for (size_t i = 0; i < cur.size(); ++i) ProgramBuilder::bind(Ps[i], pb.columns(), *cur[i], nullable);
+            int grid = 0;
+            HIP_CHECK(launch_scan_agg_lowcard(cfg, Ps[0], tmp.get<ScanParams>(cur.size()), gmax, partials, partial_ng, max_grid, status, &grid, (int)cur.size()));
+            n_part = grid;
+        }
         for (auto& b : cur) {
+            if (together) break;
             ScanParams P = P0;
             ProgramBuilder::bind(P, pb.columns(), *b, nullable);
             int grid = 0;

@@ -39,9 +39,11 @@ struct LaunchCfg {
 // low-cardinality fused scan+aggregate; gmax in {1,4,8}.  partials: grid*gmax GroupRec,
 // partial_ng: grid uint32.  Returns the grid size used in *grid_out.
 // dparams: device scratch for the per-launch copy of P (sizeof(ScanParams)), must outlive the kernel.
+// n_batches > 1: &P is the first of n_batches ScanParams (one program bound to several small batches), dparams holds as many: ONE launch,
+// blockIdx.y = batch; *grid_out = workgroups over all batches (the partial tables written)
 hipError_t launch_scan_agg_lowcard(const LaunchCfg& cfg, const ScanParams& P, ScanParams* dparams, int gmax,
                                    GroupRec* partials, uint32_t* partial_ng, int max_grid,
-                                   ScanStatus* status, int* grid_out);
+                                   ScanStatus* status, int* grid_out, int n_batches = 1);
 int scan_agg_lowcard_max_grid(const LaunchCfg& cfg);
 
 // merge per-workgroup partials (n_part*gmax records) into `table` (capacity cap groups)

@@ -64,7 +64,9 @@ constexpr int lowcard_min_blocks(int gmax, int nacc, bool nulls) {
 template <int R, bool NULLS, int GMAX, bool PREFETCH, int NACC_ = AGG_NACC>
 __global__ void __launch_bounds__(BLOCK, lowcard_min_blocks(GMAX, NACC_, NULLS))
 scan_agg_lowcard_kernel(const ScanParams* __restrict__ Pp, const AggLowCardArgs<GMAX> A) {
-    const ScanParams& P = *Pp;
+    // blockIdx.y = the input batch (one ScanParams each: several small batches — the partial states of N ranks in front of a Final
+    // aggregate — go through ONE launch; this kernel's fixed cost, the 16-accumulator epilogue above all, is ~0.1 ms per launch)
+    const ScanParams& P = Pp[blockIdx.y];
     constexpr int TILE = BLOCK * R;
     constexpr int NACC = NACC_;
     extern __shared__ __align__(16) uint8_t lds_raw[];
@@ -277,7 +279,8 @@ scan_agg_lowcard_kernel(const ScanParams* __restrict__ Pp, const AggLowCardArgs<
     __syncthreads();
     if (tid < GMAX * NACC) tot_nv = S->red[0][tid] + S->red[1][tid] + S->red[2][tid] + S->red[3][tid];
 
-    GroupRec* out = A.partials + (size_t)blockIdx.x * GMAX;
+    const size_t part = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    GroupRec* out = A.partials + part * GMAX;
     if (tid < GMAX) {
         out[tid].k0 = S->keys[tid].k0;
         out[tid].k1 = S->keys[tid].k1;
@@ -288,7 +291,7 @@ scan_agg_lowcard_kernel(const ScanParams* __restrict__ Pp, const AggLowCardArgs<
         out[tid / NACC].nvalid[tid % NACC] = tot_nv;
     }
     if (tid == 0) {
-        A.partial_ng[blockIdx.x] = (uint32_t)ng;
+        A.partial_ng[part] = (uint32_t)ng;
         if (S->overflow) atomicOr(&A.status->flags, SCAN_OVERFLOW_GROUPS);
     }
     if (err) atomicOr(&A.status->flags, err);
@@ -420,11 +423,13 @@ int scan_agg_lowcard_max_grid(const LaunchCfg& cfg) { return cfg.device_cus * 8;
 
 template <int R, bool NULLS, int GMAX, bool PREFETCH, int NACC_ = AGG_NACC>
 static hipError_t launch_lowcard_t(const LaunchCfg& cfg, const ScanParams& P, ScanParams* dparams, GroupRec* partials,
-                                   uint32_t* partial_ng, int max_grid, ScanStatus* status, int* grid_out) {
+                                   uint32_t* partial_ng, int max_grid, ScanStatus* status, int* grid_out, int n_batches = 1) {
+    // n_batches > 1: &P is the first of n_batches ScanParams (the same program bound to different batches), dparams has room for all
     constexpr int TILE = BLOCK * R;
     const size_t lds = host_tile_bytes<R>(P.prog) + sizeof(AggLds);
     if (lds > LDS_PER_CU) return hipErrorInvalidValue;
-    const int64_t n_tiles = (P.n_rows + TILE - 1) / TILE;
+    int64_t n_tiles = 0;
+    for (int b = 0; b < n_batches; ++b) n_tiles = std::max<int64_t>(n_tiles, ((&P)[b].n_rows + TILE - 1) / TILE);
     auto k = scan_agg_lowcard_kernel<R, NULLS, GMAX, PREFETCH, NACC_>;
     hipError_t e = set_lds(k, lds);
     if (e != hipSuccess) return e;
@@ -439,11 +444,11 @@ static hipError_t launch_lowcard_t(const LaunchCfg& cfg, const ScanParams& P, Sc
     if (grid > n_tiles) grid = n_tiles;
     if (grid > max_grid) grid = max_grid;
     if (grid < 1) grid = 1;
-    e = hipMemcpyAsync(dparams, &P, sizeof(ScanParams), hipMemcpyHostToDevice, cfg.stream);
+    e = hipMemcpyAsync(dparams, &P, sizeof(ScanParams) * (size_t)n_batches, hipMemcpyHostToDevice, cfg.stream);
     if (e != hipSuccess) return e;
     AggLowCardArgs<GMAX> A{partials, partial_ng, status};
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(BLOCK), lds, cfg.stream, (const ScanParams*)dparams, A);
-    *grid_out = (int)grid;
+    hipLaunchKernelGGL(k, dim3((unsigned)grid, (unsigned)n_batches), dim3(BLOCK), lds, cfg.stream, (const ScanParams*)dparams, A);
+    *grid_out = (int)grid * n_batches;
     return hipGetLastError();
 }
 
@@ -451,8 +456,8 @@ static hipError_t launch_lowcard_t(const LaunchCfg& cfg, const ScanParams& P, Sc
 // (DESIGN.md "Kernel tuning"); BHIP_SCAN_R / BHIP_PREFETCH select other variants in a -DBHIP_TUNE build.
 template <bool NULLS>
 static hipError_t launch_lowcard_n(const LaunchCfg& cfg, const ScanParams& P, ScanParams* dparams, int gmax,
-                                   GroupRec* partials, uint32_t* partial_ng, int max_grid, ScanStatus* status, int* grid_out) {
-#define BHIP_LC(R_, G_, PF_) launch_lowcard_t<R_, NULLS, G_, PF_>(cfg, P, dparams, partials, partial_ng, max_grid, status, grid_out)
+                                   GroupRec* partials, uint32_t* partial_ng, int max_grid, ScanStatus* status, int* grid_out, int n_batches) {
+#define BHIP_LC(R_, G_, PF_) launch_lowcard_t<R_, NULLS, G_, PF_>(cfg, P, dparams, partials, partial_ng, max_grid, status, grid_out, n_batches)
 #ifdef BHIP_TUNE
     static const int r_env = [] { const char* v = getenv("BHIP_SCAN_R"); return v ? atoi(v) : 0; }();
     static const int pf_env = [] { const char* v = getenv("BHIP_PREFETCH"); return v ? atoi(v) : -1; }();
@@ -465,14 +470,14 @@ static hipError_t launch_lowcard_n(const LaunchCfg& cfg, const ScanParams& P, Sc
     }
 #endif
     if (P.n_acc > AGG_NACC) {                      // tiny inputs only (host/ops_agg.cpp): 16 accumulator registers per group
-        if (gmax == 4) return launch_lowcard_t<1, NULLS, 4, false, VM_MAX_ACC>(cfg, P, dparams, partials, partial_ng, max_grid, status, grid_out);
-        if (gmax == 1) return launch_lowcard_t<1, NULLS, 1, false, VM_MAX_ACC>(cfg, P, dparams, partials, partial_ng, max_grid, status, grid_out);
+        if (gmax == 4) return launch_lowcard_t<1, NULLS, 4, false, VM_MAX_ACC>(cfg, P, dparams, partials, partial_ng, max_grid, status, grid_out, n_batches);
+        if (gmax == 1) return launch_lowcard_t<1, NULLS, 1, false, VM_MAX_ACC>(cfg, P, dparams, partials, partial_ng, max_grid, status, grid_out, n_batches);
         return hipErrorInvalidValue;
     }
     // 8 groups x 8 accumulators take 128 VGPRs: no room for prefetch registers
     if (P.n_acc <= 4) {                            // (TPC-H Q3 / Q5 / Q6 carry one SUM): a quarter / half of the accumulator registers
-        if (gmax == 8) return launch_lowcard_t<2, NULLS, 8, false, 4>(cfg, P, dparams, partials, partial_ng, max_grid, status, grid_out);
-        if (gmax == 4) return launch_lowcard_t<AGG_DEFAULT_R, NULLS, 4, AGG_DEFAULT_PREFETCH, 4>(cfg, P, dparams, partials, partial_ng, max_grid, status, grid_out);
+        if (gmax == 8) return launch_lowcard_t<2, NULLS, 8, false, 4>(cfg, P, dparams, partials, partial_ng, max_grid, status, grid_out, n_batches);
+        if (gmax == 4) return launch_lowcard_t<AGG_DEFAULT_R, NULLS, 4, AGG_DEFAULT_PREFETCH, 4>(cfg, P, dparams, partials, partial_ng, max_grid, status, grid_out, n_batches);
     }
     if (gmax == 8) return BHIP_LC(2, 8, false);
     if (gmax == 4) return BHIP_LC(AGG_DEFAULT_R, 4, AGG_DEFAULT_PREFETCH);
@@ -482,9 +487,10 @@ static hipError_t launch_lowcard_n(const LaunchCfg& cfg, const ScanParams& P, Sc
 }
 
 hipError_t launch_scan_agg_lowcard(const LaunchCfg& cfg, const ScanParams& P, ScanParams* dparams, int gmax,
-                                   GroupRec* partials, uint32_t* partial_ng, int max_grid, ScanStatus* status, int* grid_out) {
-    return P.prog.nullable ? launch_lowcard_n<true>(cfg, P, dparams, gmax, partials, partial_ng, max_grid, status, grid_out)
-                           : launch_lowcard_n<false>(cfg, P, dparams, gmax, partials, partial_ng, max_grid, status, grid_out);
+                                   GroupRec* partials, uint32_t* partial_ng, int max_grid, ScanStatus* status, int* grid_out, int n_batches) {
+    if (n_batches < 1 || n_batches > 65535) return hipErrorInvalidValue;
+    return P.prog.nullable ? launch_lowcard_n<true>(cfg, P, dparams, gmax, partials, partial_ng, max_grid, status, grid_out, n_batches)
+                           : launch_lowcard_n<false>(cfg, P, dparams, gmax, partials, partial_ng, max_grid, status, grid_out, n_batches);
 }
 
 hipError_t launch_merge_partials(const LaunchCfg& cfg, const GroupRec* partials, const uint32_t* partial_ng,
