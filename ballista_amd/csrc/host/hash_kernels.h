@@ -146,6 +146,13 @@ struct NarrowJoinTable {
 // one pass over the build keys (kernels_join.hip): stats[0] / [1] = min / max of (key ^ sign bit) as unsigned (seed ~0 / 0),
 // stats[2] != 0 when the keys are not strictly increasing (or some are NULL)
 hipError_t launch_join_key_stats(const LaunchCfg& cfg, const void* keys, int key_width, const uint64_t* sel, uint32_t n, uint64_t* stats);
+// at most tiny_rank_build_max_rows() build keys: statistics AND — when the keys span at most 2^16 values — the packed map (rpack:
+// tiny_rank_build_map_words() words) and the rank -> row permutation (rperm, n entries; may be null) in ONE launch.
+// out[0] / out[1] = min / max of (key ^ sign bit) as for launch_join_key_stats, out[2] = unsorted | duplicate keys << 1 | map built << 2
+int tiny_rank_build_max_rows();
+size_t tiny_rank_build_map_words();
+hipError_t launch_tiny_rank_build(const LaunchCfg& cfg, const void* keys, int key_width, const uint64_t* sel, uint32_t n, uint64_t* rpack, uint32_t* rperm,
+                                  uint64_t* out);
 // rank map build: key-set bits (zeroed by the caller; 64 keys per word = two granules), then launch_rank_pack (util_kernels.h), perm
 hipError_t launch_rank_bits(const LaunchCfg& cfg, const void* keys, int key_width, const uint64_t* sel, uint32_t n, uint64_t kmin, bool sorted,
                             uint64_t* bits, uint32_t* dup_flag);

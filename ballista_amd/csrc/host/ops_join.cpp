@@ -264,10 +264,39 @@ std::shared_ptr<const JoinBuildSide> HashJoinExec::build_side(const Exec& ex) co
         memset(&bs->ntable, 0, sizeof(bs->ntable));
         bs->narrow_width = nkw;
         bs->dup = make_buffer(ex, 8);
-        // one pass: min / max / "strictly increasing"
         Temp tmp(ex);
-        uint64_t* stats = tmp.get<uint64_t>(3);
         struct Stats3 { uint64_t v[3]; };
+        // a dimension table's keys (<= 1024 rows spanning <= 2^16 values: Q5's nation and region): statistics, key set, packed map and
+        // permutation in ONE launch and ONE host read (kernels_join.hip: tiny_rank_build_kernel) instead of four launches and two or
+        // three reads; anything else — a wider span, duplicate keys — carries on below as if nothing had happened
+        static const bool no_tiny = [] { const char* v = getenv("BHIP_NO_TINY_BUILD"); return v && atoi(v) != 0; }();
+        static const bool radix_join_ab = [] { const char* v = getenv("BHIP_JOIN_RADIX"); return v && atoi(v) != 0; }();
+        if (!no_tiny && !force_table && !radix_join_ab && n >= 1 && n <= tiny_rank_build_max_rows()) {
+            BufferPtr rp = make_buffer(ex, tiny_rank_build_map_words() * 8 + 16), pm = make_buffer(ex, (size_t)n * 4 + 8);
+            uint64_t* out = tmp.get<uint64_t>(3);
+            TIMED_LAUNCH(ex, "tiny_rank_build", launch_tiny_rank_build(ex.cfg(), kc.data->ptr(), nkw, ksel, (uint32_t)n, rp->as<uint64_t>(), pm->as<uint32_t>(), out));
+            const Stats3 got = read_device(ex, reinterpret_cast<const Stats3*>(out));    // (the kernel has finished: the map is complete before it is published)
+            const bool unsorted = got.v[2] & 1, dup = got.v[2] & 2, built = got.v[2] & 4;
+            if (built && !dup) {
+                const uint64_t bias = nkw == 4 ? 0x80000000ull : (1ull << 63);
+                const uint64_t range = got.v[1] - got.v[0], kmin = got.v[0] ^ bias;
+                bs->rpack = rp;
+                if (unsorted) bs->rperm = pm;
+                bs->ntable.kmin64 = kmin;
+                bs->ntable.kmin = (uint32_t)kmin;
+                bs->ntable.rpack = rp->as<uint64_t>();
+                bs->ntable.rbits = nullptr;
+                static const bool no_scalar = [] { const char* v = getenv("BHIP_PROBE_NO_SCALAR_MAP"); return v && atoi(v) != 0; }();
+                bs->ntable.scalar_map = no_scalar ? 0u : 1u;
+                bs->ntable.rzero = 2u * ((uint32_t)(range >> 6) + 1u);
+                bs->ntable.rperm = unsorted ? pm->as<uint32_t>() : nullptr;
+                bs->ntable.krange64 = range;
+                bs->narrow = bs->unique = true;
+                return true;
+            }
+        }
+        // one pass: min / max / "strictly increasing"
+        uint64_t* stats = tmp.get<uint64_t>(3);
         {
             FillMany fm;                                         // the duplicate flag and the seed {~0, 0, 0} of the statistics: one launch
             fm.add(bs->dup->ptr(), 8);

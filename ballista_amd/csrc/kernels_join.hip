@@ -121,6 +121,82 @@ join_key_stats_kernel(const void* __restrict__ keys_v, const uint64_t* __restric
     }
 }
 
+// ---- a whole rank-map build of at most TINY_BUILD_ROWS keys in ONE launch of one workgroup ---------------------------------------------
+// (a dimension table's keys — Q5's nation: 25, region: 5: key statistics -> host decides -> fill -> key set -> packed map [-> rank ->
+// row permutation] were four launches and two or three host waits, ~80 us, for a few bytes of map.)  Statistics as join_key_stats; when
+// the keys span at most TINY_BUILD_WINDOW values the key set is built in LDS (an atomicOr per key finds duplicates), its prefix
+// popcounts make the packed words, an unsorted side gets its rank -> row permutation; `out` = {min, max (biased), flags}: the host
+// reads it ONCE and either takes the map or carries on with the statistics on the general path.
+constexpr int TINY_BUILD_ROWS = 1024;
+constexpr uint32_t TINY_BUILD_WINDOW = 1u << 16;                 // values: 2048 granules, 16 KiB of packed map
+template <int KW>
+__global__ void __launch_bounds__(TINY_BUILD_ROWS)
+tiny_rank_build_kernel(const void* __restrict__ keys_v, const uint64_t* __restrict__ sel, uint32_t n, uint64_t* __restrict__ rpack,
+                       uint32_t* __restrict__ rperm, unsigned long long* __restrict__ out) {
+    using K = typename KeyT<KW>::type;
+    const K* __restrict__ keys = static_cast<const K*>(keys_v);
+    constexpr int N_GRAN_MAX = (int)(TINY_BUILD_WINDOW / 32);
+    __shared__ uint32_t s_bits[N_GRAN_MAX + 2];
+    __shared__ uint32_t s_before[N_GRAN_MAX + 2];
+    __shared__ uint64_t s_lo[TINY_BUILD_ROWS / 64], s_hi[TINY_BUILD_ROWS / 64];
+    __shared__ uint32_t s_flag[TINY_BUILD_ROWS / 64], s_wave[TINY_BUILD_ROWS / 64];
+    __shared__ uint32_t s_dup;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t bias = KW == 4 ? 0x80000000ull : (1ull << 63), kmask = KW == 4 ? 0xFFFFFFFFull : ~0ull;
+    const bool live = tid < n && (sel == nullptr || jbit_at(sel, tid));
+    const uint64_t b = live ? (((uint64_t)keys[tid] ^ bias) & kmask) : 0;
+    uint64_t lo = live ? b : ~0ull, hi = live ? b : 0;
+    // "strictly increasing, no NULL" as join_key_stats has it: a NULL-able column counts as unsorted
+    uint32_t unsorted = sel != nullptr ? 1u : 0u;
+    if (live && tid + 1 < n && ((((uint64_t)keys[tid + 1] ^ bias) & kmask) <= b)) unsorted = 1u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint64_t l2 = __shfl_down((unsigned long long)lo, d, 64), h2 = __shfl_down((unsigned long long)hi, d, 64);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    const bool any_unsorted = __ballot(unsorted != 0) != 0ull;
+    if (lane == 0) { s_lo[wave] = lo; s_hi[wave] = hi; s_flag[wave] = any_unsorted ? 1u : 0u; }
+    if (tid == 0) s_dup = 0;
+    for (uint32_t g = tid; g < (uint32_t)N_GRAN_MAX + 2; g += TINY_BUILD_ROWS) s_bits[g] = 0;
+    __syncthreads();
+    uint32_t un = 0;
+    lo = ~0ull; hi = 0;
+    for (int w = 0; w < TINY_BUILD_ROWS / 64; ++w) { lo = s_lo[w] < lo ? s_lo[w] : lo; hi = s_hi[w] > hi ? s_hi[w] : hi; un |= s_flag[w]; }
+    const bool any_key = lo <= hi;
+    const uint64_t range = any_key ? hi - lo : 0;
+    const bool build = any_key && range < TINY_BUILD_WINDOW;
+    const uint32_t n_gran = 2u * ((uint32_t)(range >> 6) + 1u);                      // as the host sizes the map: whole 64-bit words
+    const uint32_t off = (uint32_t)(b - lo);
+    if (build && live) {
+        const uint32_t bit = 1u << (off & 31u);
+        if (atomicOr(&s_bits[off >> 5], bit) & bit) s_dup = 1u;
+    }
+    __syncthreads();
+    if (build) {
+        // set bits before each granule: two granules per thread, a workgroup scan of the pair sums
+        const uint32_t g0 = 2 * tid, c0 = g0 < n_gran ? (uint32_t)__popc(s_bits[g0]) : 0u, c1 = g0 + 1 < n_gran ? (uint32_t)__popc(s_bits[g0 + 1]) : 0u;
+        uint32_t x = c0 + c1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d, 64); if (lane >= (uint32_t)d) x += y; }
+        if (lane == 63) s_wave[wave] = x;
+        __syncthreads();
+        uint32_t before = x - (c0 + c1);
+        for (uint32_t w = 0; w < wave; ++w) before += s_wave[w];
+        if (g0 < n_gran) { s_before[g0] = before; rpack[g0] = (uint64_t)s_bits[g0] | ((uint64_t)before << 32); }
+        if (g0 + 1 < n_gran) { s_before[g0 + 1] = before + c0; rpack[g0 + 1] = (uint64_t)s_bits[g0 + 1] | ((uint64_t)(before + c0) << 32); }
+        if (tid < 2) rpack[n_gran + tid] = 0;                                       // NarrowJoinTable::rzero and the word behind it
+        __syncthreads();
+        if (live && rperm != nullptr && s_dup == 0u)
+            rperm[s_before[off >> 5] + (uint32_t)__popc(s_bits[off >> 5] & ((1u << (off & 31u)) - 1u))] = tid;
+    }
+    if (tid == 0) {
+        out[0] = lo;
+        out[1] = hi;
+        out[2] = (un ? 1ull : 0ull) | (s_dup ? 2ull : 0ull) | (build ? 4ull : 0ull);
+    }
+}
+
 // sorted, unique build keys: lanes whose keys fall into the same 32-bit piece of the bitmap are neighbours; the last lane of each
 // run writes the combined bits — with a plain store when the run lies strictly inside the wave (then no other wave holds a key
 // of that piece), with an atomicOr when it touches the wave's first or last lane.  (32-bit pieces: the segmented scan moves two
@@ -777,6 +853,16 @@ hipError_t launch_join_key_stats(const LaunchCfg& cfg, const void* keys, int key
     const unsigned stats_grid = (unsigned)(g < 1 ? 1 : g);
     if (key_width == 4) hipLaunchKernelGGL(join_key_stats_kernel<4>, dim3(stats_grid), dim3(BLOCK), 0, cfg.stream, keys, sel, n, st);
     else hipLaunchKernelGGL(join_key_stats_kernel<8>, dim3(stats_grid), dim3(BLOCK), 0, cfg.stream, keys, sel, n, st);
+    return hipGetLastError();
+}
+
+int tiny_rank_build_max_rows() { return TINY_BUILD_ROWS; }
+size_t tiny_rank_build_map_words() { return (size_t)(TINY_BUILD_WINDOW / 32) + 2; }
+hipError_t launch_tiny_rank_build(const LaunchCfg& cfg, const void* keys, int key_width, const uint64_t* sel, uint32_t n, uint64_t* rpack, uint32_t* rperm,
+                                  uint64_t* out) {
+    if (n == 0 || n > (uint32_t)TINY_BUILD_ROWS || (key_width != 4 && key_width != 8)) return hipErrorInvalidValue;
+    if (key_width == 4) hipLaunchKernelGGL(tiny_rank_build_kernel<4>, dim3(1), dim3(TINY_BUILD_ROWS), 0, cfg.stream, keys, sel, n, rpack, rperm, (unsigned long long*)out);
+    else hipLaunchKernelGGL(tiny_rank_build_kernel<8>, dim3(1), dim3(TINY_BUILD_ROWS), 0, cfg.stream, keys, sel, n, rpack, rperm, (unsigned long long*)out);
     return hipGetLastError();
 }
 
