@@ -264,6 +264,40 @@ def test_rank_map_window_beyond_2_to_the_30(jt, order, monkeypatch):
 
 
 @pytest.mark.parametrize("key_type", ["Int32", "Int64"])
+@pytest.mark.parametrize("n_left,span", [(1, 1), (5, 5), (25, 65535), (25, 65536), (25, 65537), (1024, 65536), (1025, 5000), (700, 10 ** 7)])
+@pytest.mark.parametrize("shape", ["sorted", "shuffled", "nulls", "duplicates"])
+def test_dimension_table_build_in_one_launch(ctx, key_type, n_left, span, shape):
+    """A build side of at most 1024 keys spanning at most 2^16 values is built by ONE launch (statistics, key set in LDS, packed
+    map, permutation): both sides of the row limit and of the span limit, one key, negative keys, unsorted keys, NULL keys,
+    duplicate keys (which send the join to the general table) — inner and left joins, with probe keys below, inside and above."""
+    rng = np.random.default_rng(n_left * 7 + span % 1000 + len(shape))
+    np_t = np.int64 if key_type == "Int64" else np.int32
+    base = -40_000 if key_type == "Int32" else -(2 ** 40)
+    if n_left == 1:
+        lk = np.array([0])
+    else:
+        inner = rng.permutation(max(span - 2, 0))[: max(n_left - 2, 0)] + 1 if span > 2 else np.zeros(0, dtype=np.int64)
+        lk = np.sort(np.concatenate([[0, span - 1], inner]))[:n_left] if span >= 2 else np.arange(n_left)
+        lk[-1] = span - 1                                                            # the keys span exactly `span` values
+    n_left = len(lk)
+    lv = None
+    if shape == "shuffled":
+        lk = rng.permutation(lk)
+    elif shape == "nulls":
+        lv = rng.random(n_left) > 0.2
+    elif shape == "duplicates" and n_left > 1:
+        lk[n_left // 2] = lk[0]
+    n_right = 5000
+    rk = rng.integers(-50, span + 50, n_right)
+    rk[:4] = [0, span - 1, -1, span]
+    left = OrderedDict([("lk", OCol(key_type, (lk + base).astype(np_t), lv)), ("lx", OCol("Float64", rng.random(n_left)))])
+    right = OrderedDict([("rk", OCol(key_type, (rk + base).astype(np_t))), ("ry", OCol("Int64", rng.integers(0, 10 ** 9, n_right)))])
+    lm, rm = helpers.memory_exec(ctx, [[left]]), helpers.memory_exec(ctx, [[right]])
+    for jt in (ba.plan.INNER, ba.plan.LEFT):
+        check(ba.HashJoinExec(lm, rm, [("lk", "rk")], jt), ["lk", "rk", "ry", "lx"])
+
+
+@pytest.mark.parametrize("key_type", ["Int32", "Int64"])
 @pytest.mark.parametrize("probe_order", ["ascending", "descending", "runs", "random"])
 @pytest.mark.parametrize("semi", [False, True])
 @pytest.mark.parametrize("build", ["sorted", "shuffled"])
