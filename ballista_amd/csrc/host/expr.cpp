@@ -480,6 +480,24 @@ Operand ProgramBuilder::load_column(int schema_idx) {
     return o;
 }
 
+bool ProgramBuilder::plain_fixed_keys(std::vector<PlainKeyPart>& parts) const {
+    parts.clear();
+    if (keys_.empty() || key_bytes_ > 16) return false;
+    for (size_t i = 0; i < keys_.size(); ++i) {
+        const KeyV& k = keys_[i];
+        if (k.kind != KP_VSLOT || k.nullable) return false;
+        int load = -1;
+        for (size_t j = 0; j < load_vregs_.size(); ++j)
+            if (load_vregs_[j] == k.src) load = (int)j;
+        if (load < 0) return false;                                            // a computed key
+        const int dt = loads_[(size_t)load].dtype;
+        if (dt_is_float(dt) || dt == DT_BOOLEAN || dt == DT_UTF8) return false;
+        if (key_info_[i].width != dtype_width(dt) || key_info_[i].nullable) return false;
+        parts.push_back(PlainKeyPart{col_map_[loads_[(size_t)load].col], key_info_[i].width, key_info_[i].pos});
+    }
+    return true;
+}
+
 bool ProgramBuilder::can_raise() const {
     for (auto& k : keys_)
         if (k.kind == KP_UTF8_COL) return true;       // SCAN_ERR_KEY_TOO_LONG: only a Utf8 key part can outgrow its packed width

@@ -103,6 +103,10 @@ public:
     static void bind(ScanParams& P, const std::vector<int>& col_map, const Batch& b, bool creates_nulls);
 
     const std::vector<int>& columns() const { return col_map_; }   // VM column index -> input schema index
+    // every key part a plain NULL-free integer / date / timestamp column: per part {input schema index, width, byte position in the
+    // packed key} (after finish()); false otherwise — such keys are packed by a small streaming kernel instead of the VM
+    struct PlainKeyPart { int schema_index, width, pos; };
+    bool plain_fixed_keys(std::vector<PlainKeyPart>& parts) const;
     bool creates_nulls() const { return creates_nulls_; }
     // the program can set an error flag in its ScanStatus (integer division; a Utf8 key part longer than its packed width):
     // only then does a caller have to read the status back before it hands the result on

@@ -225,11 +225,30 @@ GroupRec* hash_aggregate(const Exec& ex, Temp& tmp, const ScanParams& P0, const 
 
     // ---- the packed key of every row --------------------------------------------------------------------------------------
     {
+        // plain NULL-free integer / date key columns: a streaming pack (kernels_util.hip) instead of a launch of the expression VM
+        static const bool no_fixed_pack = [] { const char* v = getenv("BHIP_NO_FIXED_KEY_PACK"); return v && atoi(v) != 0; }();
+        std::vector<ProgramBuilder::PlainKeyPart> parts;
+        const bool plain = !no_fixed_pack && pb.plain_fixed_keys(parts) && parts.size() <= (size_t)FIXED_KEY_PARTS_MAX;
         uint32_t row_base = 0;
         for (auto& b : inputs) {
-            ScanParams P = P0;
-            ProgramBuilder::bind(P, pb.columns(), *b, nullable);
-            TIMED_LAUNCH_N(ex, "scan_keys", b->n_rows, launch_scan_keys(cfg, P, keys + 2ull * row_base, nullptr, nullptr, status));
+            bool packed = false;
+            if (plain) {
+                FixedKeyParts K;
+                memset(&K, 0, sizeof(K));
+                K.n = (int32_t)parts.size();
+                packed = true;
+                for (size_t p = 0; p < parts.size(); ++p) {
+                    const Column& c = b->cols[(size_t)parts[p].schema_index];
+                    if (c.validity || c.is_view() || !c.data) { packed = false; break; }
+                    K.src[p] = c.data->ptr(); K.width[p] = (uint8_t)parts[p].width; K.pos[p] = (uint8_t)parts[p].pos;
+                }
+                if (packed) TIMED_LAUNCH_N(ex, "pack_fixed_keys", b->n_rows, launch_pack_fixed_keys(cfg, K, b->n_rows, keys + 2ull * row_base));
+            }
+            if (!packed) {
+                ScanParams P = P0;
+                ProgramBuilder::bind(P, pb.columns(), *b, nullable);
+                TIMED_LAUNCH_N(ex, "scan_keys", b->n_rows, launch_scan_keys(cfg, P, keys + 2ull * row_base, nullptr, nullptr, status));
+            }
             row_base += (uint32_t)b->n_rows;
         }
     }

@@ -1010,6 +1010,38 @@ hipError_t launch_widen_key(const LaunchCfg& cfg, const void* src, int width, in
     return hipGetLastError();
 }
 
+__global__ void __launch_bounds__(BLOCK)
+pack_fixed_keys_kernel(FixedKeyParts K, int64_t n, uint64_t* keys128) {
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+        uint64_t k0 = 0, k1 = 0;
+        for (int p = 0; p < K.n; ++p) {
+            const int w = K.width[p], pos = K.pos[p];
+            uint64_t v;
+            if (w == 8) v = reinterpret_cast<const uint64_t*>(K.src[p])[i];
+            else if (w == 4) v = reinterpret_cast<const uint32_t*>(K.src[p])[i];
+            else if (w == 2) v = reinterpret_cast<const uint16_t*>(K.src[p])[i];
+            else v = reinterpret_cast<const uint8_t*>(K.src[p])[i];
+            if (pos < 8) {
+                k0 |= v << (8 * pos);
+                if (pos + w > 8) k1 |= v >> (8 * (8 - pos));
+            } else {
+                k1 |= v << (8 * (pos - 8));
+            }
+        }
+        ulonglong2 k;
+        k.x = k0; k.y = k1;
+        reinterpret_cast<ulonglong2*>(keys128)[i] = k;
+    }
+}
+hipError_t launch_pack_fixed_keys(const LaunchCfg& cfg, const FixedKeyParts& K, int64_t n, uint64_t* keys128) {
+    if (K.n < 1 || K.n > FIXED_KEY_PARTS_MAX) return hipErrorInvalidValue;
+    for (int p = 0; p < K.n; ++p)
+        if ((K.width[p] != 1 && K.width[p] != 2 && K.width[p] != 4 && K.width[p] != 8) || K.pos[p] + K.width[p] > 16) return hipErrorInvalidValue;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_fixed_keys_kernel, dim3(grid_for(cfg, n)), dim3(BLOCK), 0, cfg.stream, K, n, keys128);
+    return hipGetLastError();
+}
+
 // ---- pack many small device buffers into one block (one launch + one D2H copy on export) ---------------
 __global__ void __launch_bounds__(BLOCK)
 pack_buffers_kernel(PackDesc d, uint8_t* out) {

@@ -140,6 +140,12 @@ struct EmitAllArgs {
     uint64_t* value_validity[EMIT_ALL_MAX_VALUES];
 };
 hipError_t launch_emit_all(const LaunchCfg& cfg, const EmitAllArgs& A);
+// the packed 16-byte key of every row from plain NULL-free integer / date columns: the low `width` bytes of part p at byte `pos` (the
+// layout the expression VM packs: vm_device.h key_put) — a streaming pass with a few hundred bytes of code where the VM kernel's launch
+// alone costs ~0.06 ms of instruction fetch (Q3's aggregate keys: three Int32 / Date32 columns of 3.2 M rows)
+constexpr int FIXED_KEY_PARTS_MAX = 8;
+struct FixedKeyParts { int32_t n; const void* src[FIXED_KEY_PARTS_MAX]; uint8_t width[FIXED_KEY_PARTS_MAX], pos[FIXED_KEY_PARTS_MAX]; };
+hipError_t launch_pack_fixed_keys(const LaunchCfg& cfg, const FixedKeyParts& K, int64_t n, uint64_t* keys128);
 // The same columns for ANY number of groups straight from the run slots of a clustered hash aggregate (host/ops_agg.cpp: distinct
 // runs — slot g IS group g): key of the run's first row, accumulators of slot g; no GroupRec table is written and read back
 // (Q3's 1.13 M groups: run_compact + four emit launches were 0.22 ms).  Fixed-width, non-Boolean keys only; A.table / A.status unused.

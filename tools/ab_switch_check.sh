@@ -35,6 +35,7 @@ run BHIP_PROBE_NO_SCALAR_MAP=1 "$J"
 run BHIP_NO_BUCKET_SORT=1 "$A -k not(bucket_path)"
 run BHIP_NO_UTF8_EQ_FILTER=1 "$A"
 run BHIP_NO_SLOT_EMIT=1 "$A"
+run BHIP_NO_FIXED_KEY_PACK=1 "$A"
 run BHIP_NO_TINY_BUILD=1 "$J"
 run BHIP_NO_STREAMING_SHUFFLE=1 "tests/test_exchange_gpu.py -k not(streaming_shuffle)"
 run BHIP_PARQUET_PAGEABLE=1 "tests/test_parquet_gpu.py"
