@@ -836,8 +836,9 @@ std::vector<BatchPtr> HashAggregateExec::run_packed(int partition, const Exec& e
         int64_t cur_rows = 0;
         for (auto& b : cur) cur_rows += b->n_rows;
         const bool together = !lean_now && !sop_now && cur.size() > 1 && cur.size() <= 4096 && cur_rows <= (1 << 20);
+        std::vector<ScanParams> Ps;                    // (lives until this round's host wait below: the copy to the device may read it late)
         if (together) {
-            std::vector<ScanParams> Ps(cur.size(), P0);
+            Ps.assign(cur.size(), P0);
             for (size_t i = 0; i < cur.size(); ++i) ProgramBuilder::bind(Ps[i], pb.columns(), *cur[i], nullable);
             int grid = 0;
             HIP_CHECK(launch_scan_agg_lowcard(cfg, Ps[0], tmp.get<ScanParams>(cur.size()), gmax, partials, partial_ng, max_grid, status, &grid, (int)cur.size()));
